@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (build container only).
+
+    python3 -B oracle/gen_golden.py            # writes tests/golden/
+
+The reference (/root/reference, read-only) is imported through oracle/_refload.py; every
+number stored below is an output of the reference's own code (numpy 2.2.6 / torch
+2.10.0+rocm7.0 CPU -- versions are recorded in each file).  Fixtures hold data only:
+seeds, injected inputs and expected outputs.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import _refload  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+VERS = {"numpy": np.__version__, "torch": torch.__version__}
+
+
+def sd_to_np(sd):
+    return {k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------- env traces
+def scripted_action(t, env, mode, rng):
+    """Action scripts that exercise: random walk, 'stay', boundary hugging, homing on the source."""
+    if mode == "random":
+        return int(rng.randint(0, 5))
+    if mode == "stay":
+        return 0 if t % 3 else int(rng.randint(0, 5))
+    if mode == "edge":          # run along x=0 then along y, bouncing into the walls
+        return (2, 4, 1, 4, 3)[(t // 40) % 5]
+    # homing: greedy axis move toward the source
+    d = env.source_pos - env.agent_pos
+    if abs(d[0]) > abs(d[1]):
+        return 3 if d[0] > 0 else 4
+    return 1 if d[1] > 0 else 2
+
+
+def gen_env():
+    out = {}
+    for ver, var, steps in (("PPOV2.0", "v2.0", 700), ("PPOV2.1", "v2.1", 700), ("PPOV1.1", "v1.1", 500)):
+        _, envm, _, _ = _refload.load(ver)
+        seed = {"v2.0": 11, "v2.1": 12, "v1.1": 13}[var]
+        np.random.seed(seed)
+        env = envm.MethaneEnv()
+        rng = np.random.RandomState(100 + seed)
+        modes = ["homing", "random", "edge", "stay", "homing", "homing"]
+        # curriculum values per episode; the 3rd makes explore_bonus an np.float64 (f64 path)
+        curr = [(50.0, 0.6), (50.0, 0.6), (20.0, np.float64(0.4321)), (8.0, np.float64(0.25)),
+                (12.5, 0.1), (50.0, 0.6)]
+        ep = 0
+        rec = {k: [] for k in ("act", "obs", "rew", "done", "reached", "info", "pos", "ep")}
+        sources = [env.source_pos.copy()]
+        obs0 = [env._get_obs()]
+        for t in range(steps):
+            a = scripted_action(t, env, modes[min(ep, len(modes) - 1)], rng)
+            # cap episode length of the non-terminating scripts so several resets are covered
+            o, r, d, info = env.step(a)
+            rec["act"].append(a)
+            rec["obs"].append(o)
+            rec["rew"].append(r)
+            rec["done"].append(d)
+            rec["reached"].append(env.trajectory[-1]["reached"])
+            rec["info"].append([info["concentration_reward"], info["explore_reward"],
+                                info["move_penalty"], info["tke_penalty"], info["boundary_penalty"]])
+            rec["pos"].append(env.agent_pos.copy())
+            rec["ep"].append(ep)
+            force = (not d) and env.step_count >= 120
+            if d or force:
+                ep += 1
+                obs0.append(env.reset())
+                sources.append(env.source_pos.copy())
+                rad, bon = curr[min(ep, len(curr) - 1)]
+                env.current_radius, env.explore_bonus = rad, bon
+            rec["done"][-1] = bool(d)
+            rec.setdefault("reset_after", []).append(bool(d or force))
+        out[f"{var}_seed"] = seed
+        out[f"{var}_act"] = np.asarray(rec["act"], np.int8)
+        out[f"{var}_obs"] = np.asarray(rec["obs"], np.float32)
+        out[f"{var}_rew"] = np.asarray(rec["rew"], np.float64)
+        out[f"{var}_done"] = np.asarray(rec["done"], bool)
+        out[f"{var}_reached"] = np.asarray(rec["reached"], bool)
+        out[f"{var}_info"] = np.asarray(rec["info"], np.float64)
+        out[f"{var}_pos"] = np.asarray(rec["pos"], np.float32)
+        out[f"{var}_reset_after"] = np.asarray(rec["reset_after"], bool)
+        out[f"{var}_sources"] = np.asarray(sources, np.float64)
+        out[f"{var}_obs0"] = np.asarray(obs0, np.float32)
+        out[f"{var}_curr_radius"] = np.asarray([c[0] for c in curr], np.float64)
+        out[f"{var}_curr_bonus"] = np.asarray([float(c[1]) for c in curr], np.float64)
+        out[f"{var}_curr_bonus_is_f64"] = np.asarray([isinstance(c[1], np.float64) for c in curr])
+        print(var, "episodes", ep, "reached", int(np.sum(rec["reached"])))
+    np.savez_compressed(os.path.join(OUT, "env_traces.npz"), versions=str(VERS), **out)
+
+
+# --------------------------------------------------------------------------- policy + update
+class Capture:
+    """Records total_loss at each .backward() and the norm returned by clip_grad_norm_."""
+
+    def __init__(self):
+        self.loss, self.gnorm = [], []
+
+    def __enter__(self):
+        self._bw = torch.Tensor.backward
+        self._clip = torch.nn.utils.clip_grad_norm_
+        cap = self
+
+        def bw(t, *a, **k):
+            cap.loss.append(float(t.detach()))
+            return cap._bw(t, *a, **k)
+
+        def clip(params, max_norm, *a, **k):
+            n = cap._clip(params, max_norm, *a, **k)
+            cap.gnorm.append(float(n))
+            return n
+
+        torch.Tensor.backward = bw
+        torch.nn.utils.clip_grad_norm_ = clip
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.backward = self._bw
+        torch.nn.utils.clip_grad_norm_ = self._clip
+
+
+SMALL = ("feature.0.bias", "feature.1.weight", "feature.1.bias", "feature.3.bias",
+         "feature.4.weight", "feature.4.bias", "actor.weight", "actor.bias",
+         "critic.weight", "critic.bias")
+
+
+def fill_buffer(buf, L, rng, done_at=()):
+    obs = rng.rand(L, 6).astype(np.float32)
+    act = rng.randint(0, 5, L)
+    rew = rng.randn(L).astype(np.float32) * 2
+    val = rng.randn(L).astype(np.float32)
+    logp = (np.log(0.2) + 0.05 * rng.randn(L)).astype(np.float32)
+    done = np.zeros(L, np.float32)
+    for i in done_at:
+        done[i] = 1.0
+    for i in range(L):
+        buf.store(obs[i], act[i], rew[i], val[i], logp[i], done[i])
+    return obs, act, rew, val, logp, done
+
+
+def gen_policy_update():
+    _, _, mdl, train = _refload.load("PPOV2.0")
+    torch.manual_seed(1234)
+    model = mdl.PPOActorCritic(6, 5)
+    sd0 = sd_to_np(model.state_dict())
+    out = {f"init/{k}": v for k, v in sd0.items()}
+    rng = np.random.RandomState(5)
+    x = rng.rand(64, 6).astype(np.float32)
+    x[:4] = [[0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1], [0.998, 0.002, 1, 1.6, 0.5, 0.2], [0.3, 0.9, 0.0, -0.09, 1, 1]]
+    with torch.no_grad():
+        probs, value = model(torch.from_numpy(x))
+    out.update(fwd_x=x, fwd_probs=probs.numpy(), fwd_value=value.numpy())
+
+    cases = {"L256": (256, (17, 100, 101, 255)), "L7": (7, (2, 6)), "L7b": (7, (0, 3)), "L1": (1, ())}
+    for name, (L, done_at) in cases.items():
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd0.items()})
+        opt = torch.optim.Adam(model.parameters(), lr=3e-5)
+        buf = mdl.PPOBuffer()
+        obs, act, rew, val, logp, done = fill_buffer(buf, L, rng, done_at)
+        torch.manual_seed(99)                      # randperm: a permutation of a full batch
+        with Capture() as cap, contextlib.redirect_stdout(io.StringIO()):
+            train._update_model(buf, model, opt)
+        post = sd_to_np(model.state_dict())
+        out.update({f"{name}/obs": obs, f"{name}/act": act.astype(np.int64), f"{name}/rew": rew,
+                    f"{name}/val": val, f"{name}/logp": logp, f"{name}/done": done,
+                    f"{name}/loss": np.asarray(cap.loss), f"{name}/gnorm": np.asarray(cap.gnorm)})
+        names = [n for n, _ in model.named_parameters()]
+        for n, p in zip(names, model.parameters()):
+            st = opt.state[p]
+            if name == "L256" or n in SMALL:
+                out[f"{name}/post/{n}"] = post[n]
+            out[f"{name}/post_sum/{n}"] = np.float64(post[n].astype(np.float64).sum())
+            out[f"{name}/post_abs/{n}"] = np.float64(np.abs(post[n].astype(np.float64) - sd0[n]).sum())
+            if n in SMALL:
+                out[f"{name}/m/{n}"] = st["exp_avg"].numpy().copy()
+                out[f"{name}/v/{n}"] = st["exp_avg_sq"].numpy().copy()
+            out[f"{name}/m_sum/{n}"] = np.float64(st["exp_avg"].double().sum())
+            out[f"{name}/v_sum/{n}"] = np.float64(st["exp_avg_sq"].double().sum())
+        print(name, "loss", cap.loss, "gnorm", cap.gnorm)
+    np.savez_compressed(os.path.join(OUT, "policy_update.npz"), versions=str(VERS), **out)
+
+
+# --------------------------------------------------------------------------- curriculum
+def gen_curriculum():
+    _, _, mdl, _ = _refload.load("PPOV2.0")
+
+    class E:
+        current_radius, explore_bonus = 50.0, 0.6
+
+    out = {}
+    rng = np.random.RandomState(3)
+    seqs = {
+        "all_success": np.ones(400, bool),
+        "all_fail": np.zeros(400, bool),
+        "mixed70": rng.rand(1000) < 0.7,
+        "mixed20_then_90": np.concatenate([rng.rand(360) < 0.9, rng.rand(300) < 0.1, rng.rand(400) < 0.95]),
+        "mid": rng.rand(500) < 0.45,
+    }
+    for name, seq in seqs.items():
+        env = E()
+        tr = mdl.PPOTrainer(env, None, None)
+        trace = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for s in seq:
+                tr.update(bool(s))
+                trace.append([tr.current_radius, tr.explore_bonus, env.current_radius, env.explore_bonus])
+        out[f"{name}/seq"] = seq
+        out[f"{name}/trace"] = np.asarray(trace, np.float64)
+    np.savez_compressed(os.path.join(OUT, "curriculum.npz"), versions=str(VERS), **out)
+
+
+# --------------------------------------------------------------------------- end to end (N=1)
+def gen_e2e(n_updates=24):
+    """The reference's training loop body (train_ppo2.0.py:138-198,245) driven for n_updates
+    buffer flushes under fixed seeds; every arithmetic step is the reference's own objects."""
+    cfg, envm, mdl, train = _refload.load("PPOV2.0")
+    env_seed, torch_seed = 21, 22
+    np.random.seed(env_seed)
+    torch.manual_seed(torch_seed)
+    env = envm.MethaneEnv()
+    model = mdl.PPOActorCritic(6, 5)
+    sd0 = sd_to_np(model.state_dict())
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.LEARNING_RATE)
+    buf = mdl.PPOBuffer()
+    trainer = mdl.PPOTrainer(env, model, opt)
+    rec = {k: [] for k in ("act", "val", "logp", "rew", "done", "reached", "obs")}
+    curr = []
+    updates = 0
+    with Capture() as cap, contextlib.redirect_stdout(io.StringIO()):
+        while updates < n_updates:
+            state = env.reset()
+            done = False
+            while not done and updates < n_updates:
+                st = torch.FloatTensor(state).unsqueeze(0)
+                with torch.no_grad():
+                    probs, value = model(st)
+                dist = torch.distributions.Categorical(probs)
+                a = dist.sample().item()
+                nxt, r, done, info = env.step(a)
+                lp = dist.log_prob(torch.tensor(a)).item()
+                buf.store(state, a, r, value.item(), lp, done)
+                rec["obs"].append(np.asarray(state, np.float32))
+                rec["act"].append(a)
+                rec["val"].append(value.item())
+                rec["logp"].append(lp)
+                rec["rew"].append(r)
+                rec["done"].append(done)
+                rec["reached"].append(env.trajectory[-1]["reached"])
+                if len(buf.states) >= cfg.BATCH_SIZE:
+                    train._update_model(buf, model, opt)
+                    buf.clear()
+                    updates += 1
+                state = nxt
+            if done:
+                trainer.update(bool(env.trajectory[-1]["reached"]))
+                curr.append([trainer.current_radius, trainer.explore_bonus])
+    post = sd_to_np(model.state_dict())
+    out = {f"init/{k}": v for k, v in sd0.items()}
+    out.update({f"post/{k}": post[k] for k in SMALL})
+    out.update({f"post_sum/{k}": np.float64(v.astype(np.float64).sum()) for k, v in post.items()})
+    out.update(env_seed=env_seed, torch_seed=torch_seed, n_updates=n_updates,
+               act=np.asarray(rec["act"], np.int8), val=np.asarray(rec["val"], np.float32),
+               logp=np.asarray(rec["logp"], np.float32), rew=np.asarray(rec["rew"], np.float64),
+               done=np.asarray(rec["done"], bool), reached=np.asarray(rec["reached"], bool),
+               obs=np.asarray(rec["obs"], np.float32),
+               loss=np.asarray(cap.loss), gnorm=np.asarray(cap.gnorm), curriculum=np.asarray(curr))
+    print("e2e steps", len(rec["act"]), "episodes", len(curr), "loss[:5]", cap.loss[:5])
+    np.savez_compressed(os.path.join(OUT, "e2e_v20.npz"), versions=str(VERS), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e"]
+    if "env" in which:
+        gen_env()
+    if "policy" in which:
+        gen_policy_update()
+    if "curriculum" in which:
+        gen_curriculum()
+    if "e2e" in which:
+        gen_e2e()
