@@ -1,0 +1,183 @@
+/*
+ * uavppo.h -- C ABI of libuavppo.so: the MI355X (gfx950) hot path of the PPOV2.0/2.1 trainer.
+ *
+ * The reference (su1phurd/UAV-WRF-LES-PPO-LSTM) has no FFI layer: its boundary is the Python
+ * module surface used by PPOV2.0/train_ppo2.0.py:8-13 (config / environment / model).  The
+ * Python modules under uav-wrf-les-ppo-lstm_amd/ keep that surface and bind these entry points
+ * with ctypes (INTEGRATION.md shows the stub).  Each entry point names the reference code it
+ * replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (owned by the caller, e.g. a torch tensor) unless a
+ *     parameter is documented "host";
+ *   - `stream` is a hipStream_t passed as void*; no entry point synchronises with the host;
+ *   - return 0 on success, non-zero on error (uav_last_error() gives the text); the Python
+ *     side raises RuntimeError, the reference's error convention (model.py:47-49);
+ *   - rollout buffers are (env, T, feat) row-major: x[n][t][f];
+ *   - thread-compatible: one caller thread per handle.
+ */
+#ifndef UAVPPO_H
+#define UAVPPO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
+typedef void* uav_stream;         /* hipStream_t */
+
+#define UAV_ABI_VERSION 1
+
+/* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
+#define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
+#define UAV_GAE_STANDARD        1  /* mask from done[t], bootstrap from last_val            */
+
+/* environment variants */
+#define UAV_ENV_V20 0   /* sigma = 500/16, clip 499      PPOV2.0/environment.py:54,105 */
+#define UAV_ENV_V21 1   /* sigma = 15                    PPOV2.1/environment.py:56     */
+#define UAV_ENV_V11 2   /* clip 500-1e-6, MAX_STEPS 5000 PPOV1.1/environment.py:105    */
+
+/* field sources for the plume sampler */
+#define UAV_FIELD_PROCEDURAL   0  /* counter-RNG field, O(1) memory per env           */
+#define UAV_FIELD_MATERIALISED 1  /* bank of [F][500][500][2] f64 tables in HBM       */
+
+int         uav_abi_version(void);
+const char* uav_last_error(void);
+
+/* ws_bytes: scratch for deterministic two-stage reductions and split-K slabs (>= 1 MiB). */
+int  uav_create(uav_ctx** out, int device, size_t ws_bytes);
+void uav_destroy(uav_ctx* ctx);
+
+/* ---- G1: GAE scan.  Replaces train_ppo2.0.py:18-32 (one wavefront per env row, affine
+ * suffix scan over T with wave shuffles).  rew,val,done,adv: f32 [n_env][horizon].
+ * last_val: f32 [n_env] (STANDARD mode) or NULL. */
+int uav_gae(uav_ctx* ctx, const float* rew, const float* val, const float* done,
+            const float* last_val, int n_env, int horizon, float gamma, float lam, int mode,
+            float* adv, uav_stream stream);
+
+/* ---- G2: whole-buffer advantage statistics and normalisation (train_ppo2.0.py:35-40).
+ * uav_adv_stats writes stats3 = {sum, sum of squares, count} (f64, device); ranks all-reduce
+ * stats3 between the two calls.  uav_adv_normalise: adv_out = (adv-mean)/(std+1e-6) with the
+ * unbiased std and the reference's guard (std<1e-6 or NaN -> 1), ret_out = adv_out + val. */
+int uav_adv_stats(uav_ctx* ctx, const float* adv, int64_t n, double* stats3, uav_stream stream);
+int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t n,
+                      const double* stats3, float* adv_out, float* ret_out, uav_stream stream);
+
+/* ---- U2: clipped-PPO loss forward + backward in one pass (train_ppo2.0.py:55-83).
+ * logits f32 [n][n_act] (pre-softmax), value f32 [n], act i32 [n]; inv_n = 1/(global sample
+ * count).  loss_sums (f64 [4], device): {sum -min(s1,s2), sum 0.5*max(.), sum entropy,
+ * count of NaN probabilities}.  dlogits [n][n_act], dvalue [n] are d(total)/d(.) where
+ * total = policy + value - ent_beta*entropy, each a mean over 1/inv_n samples. */
+int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const int32_t* act,
+                 const float* logp_old, const float* adv, const float* ret, const float* val_old,
+                 int64_t n, int n_act, float inv_n, float clip, float ent_beta,
+                 double* loss_sums, float* dlogits, float* dvalue, uav_stream stream);
+
+/* ---- K3 (sampling part): softmax + Categorical sample + log_prob + NaN check
+ * (train_ppo2.0.py:161-163,189; torch Categorical(probs) semantics).  u: uniforms in [0,1)
+ * [n] or NULL to use the counter RNG (seed, counter).  forced_act: i32 [n] or NULL; when
+ * given, act_out = forced_act (parity tests / greedy callers).  nan_count: i32[1] device. */
+int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, const float* u,
+                      uint64_t seed, uint64_t counter, const int32_t* forced_act,
+                      int32_t* act_out, float* logp_out, float* probs_out, int32_t* nan_count,
+                      uav_stream stream);
+
+/* ---- U3: global-norm clip + Adam on one flat f32 buffer (train_ppo2.0.py:87-88,114;
+ * torch clip_grad_norm_ / optim.Adam formulas).  `step` is the 1-based optimiser step.
+ * gnorm_out: f32[1] device (pre-clip global L2 norm) or NULL. */
+int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, float* exp_avg,
+                  float* exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
+                  float eps, float max_norm, float* gnorm_out, uav_stream stream);
+
+/* ---- dense f32 building block (exact-f32 MFMA): C[M][N] (+)= op(A)[M][K] * op(B)[K][N] + bias[N].
+ * Element (i,k) of op(A) is A[i*sa_m + k*sa_k]; element (k,j) of op(B) is B[k*sb_k + j*sb_n]
+ * (strides in elements, so NN / NT / TN are all the same call).  accumulate!=0 adds into C. */
+int uav_gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m,
+                 int64_t sa_k, const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc,
+                 const float* bias, int accumulate, uav_stream stream);
+
+/* ---- M2: the reference's MLP policy (model.py:17-53), forward and backward.
+ * params: flat f32[36230-like] in the order W1[h1][in] b1 g1 be1 W2[h2][h1] b2 g2 be2
+ * Whead[n_act+1][h2] bhead[n_act+1] (actor rows then the critic row).
+ * stash: f32 [B][h1 + h2 + h1 + h2 + 2] (LN inputs normalised, post-ReLU activations, rstd) or
+ * NULL for inference.  heads: f32 [B][n_act+1] = logits | value.
+ * uav_mlp_bwd: dheads [B][n_act+1] -> grad (flat, same layout as params; overwritten). */
+int64_t uav_mlp_param_count(int in_dim, int h1, int h2, int n_act);
+int64_t uav_mlp_stash_floats(int h1, int h2);
+int uav_mlp_fwd(uav_ctx* ctx, const float* params, const float* x, int64_t B, int in_dim, int h1,
+                int h2, int n_act, float* heads, float* stash, uav_stream stream);
+int uav_mlp_bwd(uav_ctx* ctx, const float* params, const float* x, float* stash,
+                const float* dheads, int64_t B, int in_dim, int h1, int h2, int n_act,
+                float* grad, uav_stream stream);
+
+/* ---- L1: nn.LSTM-semantics sequence kernels (gate order i,f,g,o; bias b_ih+b_hh;
+ * PPOV2.0/model.py:206-212, PPOV2.1/model.py:263).  One layer per call.
+ * x [N][T][I], keep [N][T] (1 = carry the recurrent state into step t, 0 = restart from zero;
+ * NULL = all ones), h0,c0 [N][H].  Outputs y [N][T][H], hn,cn [N][H] and, when stash != NULL,
+ * the BPTT stash f32 [N][T][6H] = gates(i,f,g,o after activation) | c_prev | h_prev.
+ * w_ih [4H][I], w_hh [4H][H], b_ih,b_hh [4H]. */
+int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* c0,
+                 const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 int N, int T, int I, int H, float* y, float* hn, float* cn, float* stash,
+                 uav_stream stream);
+/* dy [N][T][H] (gradient of y), dhn,dcn [N][H] or NULL.  Writes dx [N][T][I] (or NULL to skip),
+ * dw_ih, dw_hh, db (= db_ih = db_hh) [4H], dh0, dc0 [N][H] (or NULL).  dgates: scratch f32
+ * [N][T][4H] provided by the caller. */
+int uav_lstm_bwd(uav_ctx* ctx, const float* x, const float* keep, const float* stash,
+                 const float* w_ih, const float* w_hh, const float* dy, const float* dhn,
+                 const float* dcn, int N, int T, int I, int H, float* dgates, float* dx,
+                 float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, uav_stream stream);
+
+/* ---- E1-E5: vectorised plume environment (environment.py:19-169).  State lives in one
+ * caller-owned device blob of uav_env_state_bytes(n_env) bytes. */
+typedef struct uav_env_cfg {
+    int32_t variant;        /* UAV_ENV_*                                                    */
+    int32_t field_mode;     /* UAV_FIELD_*                                                  */
+    int32_t n_fields;       /* F (materialised mode)                                        */
+    int32_t bonus_is_f64;   /* explore_bonus became np.float64 (model.py:142): f64 arithmetic */
+    double  radius;         /* current_radius  (model.py:132)                               */
+    double  bonus;          /* explore_bonus   (model.py:133)                               */
+    uint64_t seed;          /* counter-RNG key (procedural fields, sources, step noise)     */
+    const double* bank;     /* [F][500][500][2] (conc, tke) f64, materialised mode          */
+    const double* bank_src; /* [F][2] source positions, materialised mode                   */
+} uav_env_cfg;
+
+size_t uav_env_state_bytes(int n_env);
+/* reset every env (environment.py:41-49); obs_out f32 [n_env][6] */
+int uav_env_reset(uav_ctx* ctx, void* state, int n_env, int env_offset, const uav_env_cfg* cfg /*host*/,
+                  float* obs_out, uav_stream stream);
+/* one step of every env with auto-reset (environment.py:82-169 + the reset of
+ * train_ppo2.0.py:139).  act i32 [n]; noise f64 [n][2] standard normals or NULL (counter RNG).
+ * obs_out [n][6] = next state to act on; rew f32 [n]; done f32 [n]; flags u8 [n] (bit0 done,
+ * bit1 reached); info f32 [n][5] or NULL; term_obs [n][6] or NULL (obs of the ended step). */
+int uav_env_step(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg /*host*/,
+                 const int32_t* act, const double* noise, float* obs_out, float* rew, float* done,
+                 uint8_t* flags, float* info, float* term_obs, double* rew64, uav_stream stream);
+/* copy out per-env state for tests / the drop-in attributes: pos f32 [n][2], source f64 [n][2],
+ * steps i32 [n], episode i32 [n] (any may be NULL) */
+int uav_env_peek(uav_ctx* ctx, const void* state, int n_env, float* pos, double* source,
+                 int32_t* steps, int32_t* episode, uav_stream stream);
+
+/* ---- R1: fused persistent rollout (train_ppo2.0.py:157-198 for n_env environments):
+ * policy step + sample + env step + store, T steps in one launch; one workgroup owns a tile
+ * of envs and keeps h/c in LDS/registers across the time loop.
+ * policy_kind 0 = MLP (params as uav_mlp_fwd), 1 = single-layer LSTM (params: w_ih w_hh b_ih
+ * b_hh Whead bhead).  Buffers (env,T,.) : obs [N][T][6], act i32, rew, val, logp, done f32
+ * [N][T], flags u8 [N][T].  cur_obs [N][6] in/out (state to act on), h,c [N][H] in/out (LSTM),
+ * keep [N][T] out (LSTM: 0 where the state restarted), last_val [N] out or NULL (V of the state
+ * after the last step, for UAV_GAE_STANDARD).  forced_act i32 [N][T] / noise f64 [N][T][2] are
+ * NULL outside parity tests. */
+int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg /*host*/,
+                int policy_kind, const float* params, int hidden, int horizon, uint64_t iter,
+                float* cur_obs, float* h, float* c, float* obs, int32_t* act, float* rew,
+                float* val, float* logp, float* done, uint8_t* flags, float* keep, float* last_val,
+                const int32_t* forced_act, const double* noise, int32_t* nan_count,
+                uav_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAVPPO_H */

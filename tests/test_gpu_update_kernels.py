@@ -1,0 +1,253 @@
+"""HIP kernels of the update path vs the oracle, through the C ABI (ctypes).  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.asarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from uavppo import ops as o
+    return o
+
+
+def _rollout_like(n, T, seed, p_done=0.02):
+    rng = np.random.RandomState(seed)
+    rew = (rng.randn(n, T) * 2).astype(np.float32)
+    val = rng.randn(n, T).astype(np.float32)
+    done = (rng.rand(n, T) < p_done).astype(np.float32)
+    return rew, val, done
+
+
+@pytest.mark.parametrize("n,T", [(1, 256), (1, 1), (3, 7), (5, 64), (4, 65), (9, 128), (2, 300)])
+@pytest.mark.parametrize("mode", ["reference_exact", "standard"])
+def test_gae_matches_oracle(ops, n, T, mode):
+    rew, val, done = _rollout_like(n, T, seed=n * 1000 + T, p_done=0.1)
+    done[:, -1] = (np.arange(n) % 2)          # done on the very last step for half the rows
+    if T > 2:
+        done[0, 0] = 1.0
+    last = np.random.RandomState(1).randn(n).astype(np.float32)
+    if mode == "reference_exact":
+        want = po.gae_reference_exact(rew, val, done)
+        got = ops.gae(dev(rew), dev(val), dev(done), 0.99, 0.95, mode)
+    else:
+        want = po.gae_standard(rew, val, done, last)
+        got = ops.gae(dev(rew), dev(val), dev(done), 0.99, 0.95, mode, last_val=dev(last))
+    # f32 tolerance: the wave scan re-associates the recurrence (oracle is strictly sequential)
+    assert np.allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_gae_golden_case(ops, golden):
+    g = golden("policy_update.npz")
+    for case in ("L256", "L7", "L7b", "L1"):
+        r, v, d = g[f"{case}/rew"][None], g[f"{case}/val"][None], g[f"{case}/done"][None]
+        got = ops.gae(dev(r), dev(v), dev(d), 0.99, 0.95).cpu().numpy()
+        assert np.allclose(got, po.gae_reference_exact(r, v, d), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 256), (1, 1), (1, 2), (64, 128), (4096, 128)])
+def test_normalise_matches_oracle(ops, shape):
+    rng = np.random.RandomState(shape[0])
+    adv = (rng.randn(*shape) * 3 + 1.5).astype(np.float32)
+    val = rng.randn(*shape).astype(np.float32)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want_a, want_r = po.normalise(adv, val)
+    a = dev(adv)
+    stats = ops.adv_stats(a)
+    ga, gr = ops.adv_normalise(a, dev(val), stats)
+    assert np.allclose(ga.cpu().numpy().reshape(-1), want_a.numpy(), rtol=1e-5, atol=1e-5)
+    assert np.allclose(gr.cpu().numpy().reshape(-1), want_r.numpy(), rtol=1e-5, atol=1e-5)
+    s = stats.cpu().numpy()
+    assert s[2] == adv.size and np.isclose(s[0], adv.astype(np.float64).sum(), rtol=1e-12, atol=1e-9)
+
+
+def test_normalise_constant_buffer_guard(ops):
+    """std < 1e-6 -> divide by (1 + 1e-6): train_ppo2.0.py:37-39."""
+    adv = np.full((2, 8), 0.25, np.float32)
+    val = np.arange(16, dtype=np.float32).reshape(2, 8)
+    a = dev(adv)
+    ga, gr = ops.adv_normalise(a, dev(val), ops.adv_stats(a))
+    assert np.allclose(ga.cpu().numpy(), 0.0, atol=1e-7) and np.allclose(gr.cpu().numpy(), val, atol=1e-6)
+
+
+def _loss_inputs(n, seed, A=5, extreme=False):
+    rng = np.random.RandomState(seed)
+    logits = (rng.randn(n, A) * (6.0 if extreme else 1.0)).astype(np.float32)
+    value = rng.randn(n).astype(np.float32)
+    act = rng.randint(0, A, n).astype(np.int32)
+    logp_old = (np.log(0.2) + 0.3 * rng.randn(n)).astype(np.float32)
+    adv = rng.randn(n).astype(np.float32)
+    ret = (value + 0.5 * rng.randn(n)).astype(np.float32)
+    val_old = (value + 0.3 * rng.randn(n)).astype(np.float32)
+    return logits, value, act, logp_old, adv, ret, val_old
+
+
+@pytest.mark.parametrize("n,extreme", [(1, False), (7, False), (256, False), (5000, True), (70001, False)])
+def test_ppo_loss_fwd_bwd(ops, n, extreme):
+    logits, value, act, lpo, adv, ret, vo = _loss_inputs(n, n, extreme=extreme)
+    if extreme:
+        logits[0] = [60, 0, 0, 0, -60]      # clamp of Categorical(probs) active (q -> 1-eps / eps)
+        act[0] = 0
+        logits[1] = [60, 0, 0, 0, -60]
+        act[1] = 4
+    z = torch.tensor(logits, requires_grad=True)
+    v = torch.tensor(value, requires_grad=True)
+    total, pl, vl, ent = po.ppo_losses(torch.softmax(z, -1), v, torch.tensor(act), torch.tensor(lpo),
+                                       torch.tensor(adv), torch.tensor(ret), torch.tensor(vo))
+    total.backward()
+    sums, dz, dv = ops.ppo_loss(dev(logits), dev(value), dev(act), dev(lpo), dev(adv), dev(ret), dev(vo),
+                                1.0 / n, 0.2, 0.01)
+    s = sums.cpu().numpy()
+    assert s[3] == 0
+    assert np.allclose(s[:3] / n, [float(pl), float(vl), float(ent)], rtol=2e-5, atol=1e-6)
+    assert np.allclose(dz.cpu().numpy(), z.grad.numpy(), rtol=1e-4, atol=2e-6 / n + 1e-9)
+    assert np.allclose(dv.cpu().numpy(), v.grad.numpy(), rtol=1e-4, atol=2e-6 / n + 1e-9)
+
+
+def test_ppo_loss_nan_is_counted(ops):
+    logits, value, act, lpo, adv, ret, vo = _loss_inputs(300, 3)
+    logits[17, 2] = np.nan
+    sums, _, _ = ops.ppo_loss(dev(logits), dev(value), dev(act), dev(lpo), dev(adv), dev(ret), dev(vo),
+                              1.0 / 300, 0.2, 0.01)
+    assert sums.cpu().numpy()[3] == 1      # host raises RuntimeError("NaN in probs") on this flag
+
+
+def test_policy_sample(ops):
+    rng = np.random.RandomState(0)
+    n = 200000
+    logits = np.tile(np.array([[0.5, -1.0, 2.0, 0.0, 1.0]], np.float32), (n, 1))
+    p = torch.softmax(torch.tensor(logits[0]), -1).numpy()
+    act, logp, probs, nan = ops.policy_sample(dev(logits), seed=7, counter=3, want_probs=True)
+    a = act.cpu().numpy()
+    freq = np.bincount(a, minlength=5) / n
+    assert np.abs(freq - p).max() < 5e-3 and nan.item() == 0
+    want_lp = po.categorical_logp(torch.tensor(p)[None].repeat(n, 1), torch.tensor(a)).numpy()
+    assert np.allclose(logp.cpu().numpy(), want_lp, atol=1e-6)
+    assert np.allclose(probs.cpu().numpy()[0], p, atol=1e-7)
+    # injected uniforms = inverse CDF; forced actions pass through
+    u = rng.rand(64).astype(np.float32)
+    act2, _, _, _ = ops.policy_sample(dev(logits[:64]), u=dev(u))
+    cdf = np.cumsum(p / p.sum())
+    assert np.array_equal(act2.cpu().numpy(), np.minimum(np.searchsorted(cdf, u, side="right"), 4))
+    forced = rng.randint(0, 5, 64).astype(np.int32)
+    act3, lp3, _, _ = ops.policy_sample(dev(logits[:64]), forced_act=dev(forced))
+    assert np.array_equal(act3.cpu().numpy(), forced)
+    # same (seed, counter) -> same draw; different counter -> different draw
+    b1 = ops.policy_sample(dev(logits[:4096]), seed=7, counter=3)[0].cpu().numpy()
+    b2 = ops.policy_sample(dev(logits[:4096]), seed=7, counter=4)[0].cpu().numpy()
+    assert np.array_equal(b1, a[:4096]) and not np.array_equal(b1, b2)
+
+
+def test_clip_adam_matches_torch(ops):
+    torch.manual_seed(0)
+    n = 36230
+    p0 = torch.randn(n)
+    p_ref = {"w": p0.clone()}
+    adam = po.AdamState(p_ref)
+    p = p0.to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    gn = torch.zeros(1, device=DEV)
+    for step in range(1, 6):
+        g = torch.randn(n) * (3.0 if step % 2 else 1e-3)     # clipped and unclipped steps
+        grads = {"w": g.clone()}
+        norm = po.clip_grads(grads)
+        adam.step(p_ref, grads)
+        ops.clip_adam(p, g.to(DEV), m, v, step, 3e-5, gnorm_out=gn)
+        assert np.isclose(gn.item(), norm, rtol=1e-5)
+        assert torch.allclose(p.cpu(), p_ref["w"], rtol=0, atol=2e-7)
+        assert torch.allclose(m.cpu(), adam.m["w"], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(v.cpu(), adam.v["w"], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", [(1, 6, 128, False, True), (256, 256, 6, False, True), (300, 128, 256, False, True),
+                                         (257, 130, 70, False, False), (6, 128, 5000, True, False),
+                                         (512, 134, 40000, True, False), (1000, 6, 128, False, True)])
+def test_gemm(ops, M, N, K, ta, tb):
+    rng = np.random.RandomState(M + N + K)
+    a = rng.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    b = rng.randn(*((N, K) if tb else (K, N))).astype(np.float32)
+    bias = rng.randn(N).astype(np.float32)
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
+    got = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias)).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5 * np.sqrt(K))
+    c0 = rng.randn(M, N).astype(np.float32)
+    out = dev(c0)
+    ops.gemm(dev(a), dev(b), ta, tb, out=out, accumulate=True)
+    assert np.allclose(out.cpu().numpy(), want - bias + c0, rtol=1e-5, atol=1e-5 * np.sqrt(K))
+
+
+def flat_from_state_dict(p):
+    """reference state_dict -> the flat layout of csrc/mlp.hip."""
+    order = ["feature.0.weight", "feature.0.bias", "feature.1.weight", "feature.1.bias", "feature.3.weight",
+             "feature.3.bias", "feature.4.weight", "feature.4.bias"]
+    parts = [p[k].reshape(-1) for k in order]
+    parts += [p["actor.weight"].reshape(-1), p["critic.weight"].reshape(-1), p["actor.bias"], p["critic.bias"]]
+    return torch.cat(parts)
+
+
+def grads_to_state_dict(flat):
+    f = flat.cpu()
+    o = 0
+    out = {}
+    for k, shape in (("feature.0.weight", (256, 6)), ("feature.0.bias", (256,)), ("feature.1.weight", (256,)),
+                     ("feature.1.bias", (256,)), ("feature.3.weight", (128, 256)), ("feature.3.bias", (128,)),
+                     ("feature.4.weight", (128,)), ("feature.4.bias", (128,)), ("actor.weight", (5, 128)),
+                     ("critic.weight", (1, 128)), ("actor.bias", (5,)), ("critic.bias", (1,))):
+        n = int(np.prod(shape))
+        out[k] = f[o:o + n].reshape(shape)
+        o += n
+    assert o == f.numel()
+    return out
+
+
+@pytest.mark.parametrize("B", [1, 64, 257, 5000])
+def test_mlp_fwd_bwd_vs_oracle(ops, golden, B):
+    g = golden("policy_update.npz")
+    p = {k: torch.from_numpy(g["init/" + k].copy()) for k in po.MLP_KEYS}
+    # make LayerNorm affine non-trivial so their gradients are exercised
+    torch.manual_seed(B)
+    for k in ("feature.1.weight", "feature.1.bias", "feature.4.weight", "feature.4.bias"):
+        p[k] = p[k] + 0.1 * torch.randn_like(p[k])
+    x = torch.rand(B, 6)
+    if B >= 64:
+        x[:64] = torch.from_numpy(g["fwd_x"])
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    probs, value, logits = po.mlp_forward(leaf, x)
+    dheads = torch.randn(B, 6) / B
+    (torch.cat([logits, value], 1) * dheads).sum().backward()
+
+    flat = flat_from_state_dict(p).to(DEV)
+    heads, stash = ops.mlp_fwd(flat, x.to(DEV))
+    assert torch.allclose(heads[:, :5].cpu(), logits.detach(), atol=2e-6, rtol=1e-5)
+    assert torch.allclose(heads[:, 5:].cpu(), value.detach(), atol=5e-6, rtol=1e-5)
+    grad = ops.mlp_bwd(flat, x.to(DEV), stash, dheads.to(DEV))
+    got = grads_to_state_dict(grad)
+    for k in po.MLP_KEYS:
+        want = leaf[k].grad
+        scale = want.abs().max().item() + 1e-12
+        assert torch.allclose(got[k], want, rtol=1e-3, atol=2e-5 * scale), (k, (got[k] - want).abs().max().item(), scale)
+
+
+def test_mlp_forward_golden(ops, golden):
+    """Reference PPOActorCritic.forward outputs (model.py:42-53) reproduced by the HIP path."""
+    g = golden("policy_update.npz")
+    p = {k: torch.from_numpy(g["init/" + k].copy()) for k in po.MLP_KEYS}
+    heads, _ = ops.mlp_fwd(flat_from_state_dict(p).to(DEV), dev(g["fwd_x"]))
+    probs = torch.softmax(heads[:, :5], -1).cpu().numpy()
+    assert np.allclose(probs, g["fwd_probs"], atol=1e-6)
+    assert np.allclose(heads[:, 5:].cpu().numpy(), g["fwd_value"], atol=5e-6)

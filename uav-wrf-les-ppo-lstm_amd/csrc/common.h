@@ -1,0 +1,68 @@
+// common.h -- shared device/host helpers for libuavppo (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/uavppo.h"
+
+struct uav_ctx {
+    int device;
+    int num_cu;
+    void* ws;          // scratch for two-stage reductions / split-K slabs
+    size_t ws_bytes;
+};
+
+void uav_set_error(const char* fmt, ...);
+
+#define UAV_CHECK_HIP(expr)                                                          \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            uav_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+#define UAV_REQUIRE(cond, ...)                                                       \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            uav_set_error(__VA_ARGS__);                                              \
+            return 2;                                                                \
+        }                                                                            \
+    } while (0)
+
+#define UAV_LAUNCH_CHECK() UAV_CHECK_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(uav_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int WAVE = 64;
+
+// ---- wave / block reductions (deterministic: fixed tree, no atomics) -------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;   // valid in lane 0
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over a 256-thread block; result valid in thread 0. `sm` has >= 4 slots.
+template <typename T>
+__device__ __forceinline__ T block256_sum(T v, T* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    T r = T(0);
+    if (threadIdx.x == 0) r = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    __syncthreads();
+    return r;
+}

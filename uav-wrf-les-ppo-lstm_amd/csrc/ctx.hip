@@ -1,0 +1,46 @@
+// ctx.hip -- handle, error string, ABI version.
+#include <stdarg.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void uav_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int uav_abi_version(void) { return UAV_ABI_VERSION; }
+const char* uav_last_error(void) { return g_err; }
+
+int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
+    UAV_REQUIRE(out != nullptr, "uav_create: out is NULL");
+    UAV_REQUIRE(ws_bytes >= (1u << 20), "uav_create: ws_bytes must be >= 1 MiB");
+    UAV_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    UAV_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    UAV_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+                "libuavppo is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    uav_ctx* c = new uav_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    c->ws_bytes = ws_bytes;
+    if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
+        delete c;
+        uav_set_error("uav_create: hipMalloc(%zu) failed", ws_bytes);
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+void uav_destroy(uav_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipFree(ctx->ws);
+    delete ctx;
+}
+
+}  // extern "C"

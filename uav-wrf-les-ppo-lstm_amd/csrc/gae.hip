@@ -1,0 +1,164 @@
+// gae.hip -- G1 (GAE scan) and G2 (whole-buffer advantage normalisation + returns).
+//
+// Reference: PPOV2.0/train_ppo2.0.py:18-32 (scan), :35-40 (normalise, returns).
+// HBM-bound: per env-step 12 B read + 4 B write (scan), 4 B read (stats), 8 B read + 8 B
+// write (normalise).  Layout (env, T): one wavefront owns one env row, lane i <-> t = 64c+i,
+// so every load/store of a chunk is one coalesced 256-B wave access.
+#include "common.h"
+
+// A[t] = b_t + a_t * A[t+1] is an affine map; the suffix composition over a 64-step chunk is a
+// Hillis-Steele scan on (a, b) pairs with wave shuffles:  (a1,b1) o (a2,b2) = (a1*a2, b1 + a1*b2).
+__global__ __launch_bounds__(256) void gae_scan_kernel(const float* __restrict__ rew,
+                                                       const float* __restrict__ val,
+                                                       const float* __restrict__ done,
+                                                       const float* __restrict__ last_val, int n_env,
+                                                       int T, float gamma, float gl, int mode,
+                                                       float* __restrict__ adv) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int env = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (env >= n_env) return;   // whole wave exits together (env is wave-uniform)
+    const size_t row = (size_t)env * T;
+    const int nchunk = (T + 63) >> 6;
+    float carry = 0.f;          // A at the first step of the chunk to the right
+    float v_right = 0.f, d_right = 0.f;   // val/done of that step
+    for (int c = nchunk - 1; c >= 0; --c) {
+        const int t = c * 64 + lane;
+        const bool in = t < T;
+        const float r = in ? rew[row + t] : 0.f;
+        const float v = in ? val[row + t] : 0.f;
+        const float d = in ? done[row + t] : 0.f;
+        // value / done of step t+1: lane+1, or the saved first element of the next chunk
+        float v1 = __shfl_down(v, 1, 64);
+        float d1 = __shfl_down(d, 1, 64);
+        if (lane == 63) { v1 = v_right; d1 = d_right; }
+        float a = 1.f, b = 0.f;
+        if (in) {
+            float nnt, nv;
+            const bool last = (t == T - 1);
+            if (mode == UAV_GAE_REFERENCE_EXACT) {
+                // train_ppo2.0.py:23-28: mask from done[t+1]; the last step uses its own done/value
+                nnt = 1.0f - (last ? d : d1);
+                nv = (last ? v : v1) * nnt;
+            } else {
+                nnt = 1.0f - d;
+                nv = (last ? (last_val ? last_val[env] : 0.f) : v1) * nnt;
+            }
+            b = (r + gamma * nv) - v;     // delta, train_ppo2.0.py:30
+            a = gl * nnt;                 // gamma*lambda*next_non_terminal, :31
+        }
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float a2 = __shfl_down(a, o, 64);
+            const float b2 = __shfl_down(b, o, 64);
+            if (lane + o < 64) {
+                b = b + a * b2;
+                a = a * a2;
+            }
+        }
+        const float A = b + a * carry;
+        if (in) adv[row + t] = A;
+        carry = __shfl(A, 0, 64);
+        v_right = __shfl(v, 0, 64);
+        d_right = __shfl(d, 0, 64);
+    }
+}
+
+// ---- statistics: deterministic two-stage f64 reduction ------------------------------------------
+constexpr int STATS_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void adv_stats_partial(const float* __restrict__ x, int64_t n,
+                                                         double* __restrict__ partial) {
+    __shared__ double sm[4];
+    double s = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = (double)x[i];
+        s += v;
+        q += v * v;
+    }
+    s = block256_sum(s, sm);
+    q = block256_sum(q, sm);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void adv_stats_final(const double* __restrict__ partial, int nb,
+                                                       int64_t n, double* __restrict__ stats3) {
+    __shared__ double sm[4];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        s += partial[2 * i];
+        q += partial[2 * i + 1];
+    }
+    s = block256_sum(s, sm);
+    q = block256_sum(q, sm);
+    if (threadIdx.x == 0) {
+        stats3[0] = s;
+        stats3[1] = q;
+        stats3[2] = (double)n;
+    }
+}
+
+__global__ __launch_bounds__(256) void adv_normalise_kernel(const float* __restrict__ adv,
+                                                            const float* __restrict__ val, int64_t n,
+                                                            const double* __restrict__ stats3,
+                                                            float* __restrict__ adv_out,
+                                                            float* __restrict__ ret_out) {
+#pragma clang fp contract(off)
+    const double cnt = stats3[2];
+    const double mean_d = stats3[0] / cnt;
+    // unbiased variance (torch .std()); cnt==1 gives 0/0 = NaN, caught by the reference's guard
+    const double var = (stats3[1] - cnt * mean_d * mean_d) / (cnt - 1.0);
+    const float mean = (float)mean_d;
+    float sd = (float)sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+    if (sd < 1e-6f || sd != sd) sd = 1.0f;            // train_ppo2.0.py:37-38
+    const float den = sd + 1e-6f;                     // :39
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float a = (adv[i] - mean) / den;
+        adv_out[i] = a;
+        ret_out[i] = a + val[i];                      // :40 returns from the NORMALISED advantage
+    }
+}
+
+extern "C" {
+
+int uav_gae(uav_ctx* ctx, const float* rew, const float* val, const float* done,
+            const float* last_val, int n_env, int horizon, float gamma, float lam, int mode,
+            float* adv, uav_stream stream) {
+    UAV_REQUIRE(ctx && rew && val && done && adv, "uav_gae: NULL argument");
+    UAV_REQUIRE(n_env > 0 && horizon > 0, "uav_gae: n_env=%d horizon=%d", n_env, horizon);
+    UAV_REQUIRE(mode == UAV_GAE_REFERENCE_EXACT || mode == UAV_GAE_STANDARD, "uav_gae: mode %d", mode);
+    const float gl = (float)((double)gamma * (double)lam);
+    // the reference multiplies the python floats first (GAMMA * LAMBDA, f64) then rounds to f32
+    const int blocks = (n_env + 3) / 4;
+    hipLaunchKernelGGL(gae_scan_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), rew, val, done,
+                       last_val, n_env, horizon, gamma, gl, mode, adv);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_adv_stats(uav_ctx* ctx, const float* adv, int64_t n, double* stats3, uav_stream stream) {
+    UAV_REQUIRE(ctx && adv && stats3 && n > 0, "uav_adv_stats: bad argument");
+    int nb = (int)((n + 1023) / 1024);
+    if (nb > STATS_BLOCKS) nb = STATS_BLOCKS;
+    double* partial = (double*)ctx->ws;
+    hipLaunchKernelGGL(adv_stats_partial, dim3(nb), dim3(256), 0, as_stream(stream), adv, n, partial);
+    hipLaunchKernelGGL(adv_stats_final, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, n, stats3);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t n,
+                      const double* stats3, float* adv_out, float* ret_out, uav_stream stream) {
+    UAV_REQUIRE(ctx && adv && val && stats3 && adv_out && ret_out && n > 0, "uav_adv_normalise: bad argument");
+    int nb = (int)((n + 1023) / 1024);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adv_normalise_kernel, dim3(nb), dim3(256), 0, as_stream(stream), adv, val, n, stats3,
+                       adv_out, ret_out);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

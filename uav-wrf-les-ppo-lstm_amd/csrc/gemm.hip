@@ -1,0 +1,149 @@
+// gemm.hip -- exact-f32 MFMA GEMM building block: C[M][N] (+)= op(A) * op(B) + bias.
+//
+// Used by the MLP policy (model.py:20-40 Linear layers, forward and backward), the policy
+// heads and the LSTM weight gradients.  v_mfma_f32_32x32x2_f32 is bit-for-bit an f32 fmaf
+// chain (no TF32 on gfx950), so results equal a CPU fp32 matmul up to summation order.
+// 64x64x16 block tile, 4 waves (2x2), each wave one 32x32 accumulator tile; operands staged
+// through LDS k-major so fragment reads are conflict-free ds_read_b32.  Generic strides make
+// NN / NT / TN one kernel; split-K (grid.z) writes slabs to the context workspace and a second
+// kernel reduces them in a fixed order (deterministic, no float atomics).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int LDT = BM + 4;   // padded row of the k-major LDS tiles
+
+// Stage a [rows=64][k=16] operand tile into T[k][row].  (r, k) element = base[r*s_r + k*s_k].
+__device__ __forceinline__ void stage_tile(float (*T)[LDT], const float* __restrict__ base, int64_t s_r,
+                                           int64_t s_k, int64_t r0, int64_t k0, int64_t R, int64_t Kend) {
+    const int t = threadIdx.x;
+    if (s_k == 1) {
+        // k contiguous: one float4 along k per thread (64 rows x 4 quads)
+        const int r = t >> 2, kq = (t & 3) * 4;
+        const int64_t gr = r0 + r, gk = k0 + kq;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gr < R) {
+            const float* p = base + gr * s_r + gk;
+            if (gk + 3 < Kend && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gk + j < Kend) v[j] = p[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T[kq + j][r] = v[j];
+    } else {
+        // row index contiguous (or fully generic): four consecutive rows at one k per thread
+        const int k = t >> 4, rq = (t & 15) * 4;
+        const int64_t gk = k0 + k, gr = r0 + rq;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gk < Kend) {
+            const float* p = base + gk * s_k + gr * s_r;
+            if (s_r == 1 && gr + 3 < R && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gr + j < R) v[j] = p[j * s_r];
+            }
+        }
+        *reinterpret_cast<float4*>(&T[k][rq]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(int64_t M, int64_t N, int64_t K,
+                                                       const float* __restrict__ A, int64_t sa_m, int64_t sa_k,
+                                                       const float* __restrict__ B, int64_t sb_k, int64_t sb_n,
+                                                       float* __restrict__ C, int64_t ldc,
+                                                       const float* __restrict__ bias, int accumulate,
+                                                       int64_t k_per_split, float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+    const int64_t kb = (int64_t)blockIdx.z * k_per_split;
+    const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+    f32x16 acc = {0};
+    for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+        stage_tile(As, A, sa_m, sa_k, m0, k0, M, ke);
+        stage_tile(Bs, B, sb_n, sb_k, n0, k0, N, ke);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int64_t col = n0 + wn * 32 + (lane & 31);
+    if (col >= N) return;
+    const float bv = (bias && !slabs) ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= M) continue;
+        if (slabs) {
+            slabs[((int64_t)blockIdx.z * M + row) * N + col] = acc[r];
+        } else {
+            float* c = C + row * ldc + col;
+            *c = (accumulate ? *c : 0.f) + acc[r] + bv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, int64_t M,
+                                                            int64_t N, float* __restrict__ C, int64_t ldc,
+                                                            const float* __restrict__ bias, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    const int64_t row = i / N, col = i % N;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slabs[(int64_t)z * M * N + i];
+    float* c = C + row * ldc + col;
+    *c = (accumulate ? *c : 0.f) + s + (bias ? bias[col] : 0.f);
+}
+
+int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
+             const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
+             int accumulate, hipStream_t st) {
+    UAV_REQUIRE(ctx && A && B && C && M > 0 && N > 0 && K > 0, "uav_gemm_f32: bad argument");
+    const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+    UAV_REQUIRE(tm < (1ll << 31) && tn <= 65535, "uav_gemm_f32: grid too large");
+    // split K when the tile grid cannot fill the chip and K is deep
+    int64_t S = 1;
+    const int64_t tiles = tm * tn;
+    if (tiles < 2 * ctx->num_cu && K >= 16 * BK) {
+        S = (2 * ctx->num_cu + tiles - 1) / tiles;
+        const int64_t maxS_k = K / (8 * BK);
+        if (S > maxS_k) S = maxS_k;
+        const int64_t maxS_ws = (int64_t)(ctx->ws_bytes / sizeof(float)) / (M * N);
+        if (S > maxS_ws) S = maxS_ws;
+        if (S < 1) S = 1;
+    }
+    int64_t kps = ((K + S - 1) / S + BK - 1) / BK * BK;
+    S = (K + kps - 1) / kps;
+    float* slabs = (S > 1) ? (float*)ctx->ws : nullptr;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tm, (unsigned)tn, (unsigned)S), dim3(256), 0, st, M, N, K, A,
+                       sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, accumulate, kps, slabs);
+    if (S > 1) {
+        const int64_t nb = (M * N + 255) / 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, slabs, (int)S, M, N, C, ldc,
+                           bias, accumulate);
+    }
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uav_gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m,
+                            int64_t sa_k, const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc,
+                            const float* bias, int accumulate, uav_stream stream) {
+    return gemm_f32(ctx, M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, accumulate, as_stream(stream));
+}

@@ -1,0 +1,232 @@
+// loss.hip -- U2 (clipped-PPO loss fwd+bwd) and the sampling half of K3.
+//
+// Reference: PPOV2.0/train_ppo2.0.py:55-83 (loss), :161-163,189 (sample + log_prob); the
+// Categorical(probs) behaviour restated here (renormalise, clamp to [eps, 1-eps], log) is
+// torch.distributions' -- see oracle/ppo_oracle.py:categorical_logp.
+// HBM-bound elementwise kernels: loss reads 4*(A+6) B and writes 4*(A+1) B per sample.
+#include "common.h"
+#include "philox.h"
+
+constexpr float F32_EPS = 1.1920928955078125e-07f;
+
+template <int A>
+__device__ __forceinline__ void softmax_row(const float* z, float* p) {
+    float m = z[0];
+#pragma unroll
+    for (int k = 1; k < A; ++k) m = fmaxf(m, z[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        p[k] = expf(z[k] - m);
+        s += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < A; ++k) p[k] = p[k] / s;
+}
+
+constexpr int LOSS_BLOCKS = 1024;
+
+template <int A>
+__global__ __launch_bounds__(256) void ppo_loss_kernel(
+    const float* __restrict__ logits, const float* __restrict__ value, const int32_t* __restrict__ act,
+    const float* __restrict__ logp_old, const float* __restrict__ adv, const float* __restrict__ ret,
+    const float* __restrict__ val_old, int64_t n, float inv_n, float clip, float beta,
+    double* __restrict__ partial, float* __restrict__ dlogits, float* __restrict__ dvalue) {
+    __shared__ double sm[4];
+    double s_pl = 0.0, s_vl = 0.0, s_en = 0.0, s_nan = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float z[A], p[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) z[k] = logits[i * A + k];
+        softmax_row<A>(z, p);
+        const int a = act[i];
+        float psum = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            psum += p[k];
+            bad |= (p[k] != p[k]);
+        }
+        if (bad) s_nan += 1.0;
+        // Categorical(probs): q = p / sum p, clamped to [eps, 1-eps]
+        float q[A];
+        float qa = 0.f, pa = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            q[k] = p[k] / psum;
+            if (k == a) { qa = q[k]; pa = p[k]; }
+        }
+        (void)pa;
+        const bool clamp_open = (qa >= F32_EPS) && (qa <= 1.0f - F32_EPS);
+        const float qc = fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS);
+        const float logp = logf(qc);
+        const float ratio = expf(logp - logp_old[i]);
+        const float Ad = adv[i];
+        const float lo = 1.0f - clip, hi = 1.0f + clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float s1 = ratio * Ad, s2 = rc * Ad;
+        s_pl += (double)(-fminf(s1, s2));
+        const bool in_rng = (ratio >= lo) && (ratio <= hi);
+        // torch.min backward: ties split 1/2 - 1/2; clamp backward passes inside [lo,hi]
+        float g_ratio;
+        if (s1 < s2) g_ratio = Ad;
+        else if (s1 == s2) g_ratio = 0.5f * Ad + (in_rng ? 0.5f * Ad : 0.f);
+        else g_ratio = in_rng ? Ad : 0.f;
+        const float g_logp = clamp_open ? (-inv_n * g_ratio * ratio) : 0.f;   // dL/dlogp
+
+        // value loss, train_ppo2.0.py:74-78
+        const float V = value[i], R = ret[i], vo = val_old[i];
+        const float dv = V - vo;
+        const float vc = vo + fminf(fmaxf(dv, -clip), clip);
+        const float e1 = (V - R) * (V - R), e2 = (vc - R) * (vc - R);
+        s_vl += (double)(0.5f * fmaxf(e1, e2));
+        const float d1 = 2.0f * (V - R);
+        const float d2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - R) : 0.f;
+        const float gV = (e1 > e2) ? d1 : ((e1 < e2) ? d2 : 0.5f * (d1 + d2));
+        dvalue[i] = 0.5f * inv_n * gV;
+
+        // entropy, train_ppo2.0.py:81 :  H = -sum p log(p + 1e-8)
+        float Hs = 0.f, hk[A], ph = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float lg = logf(p[k] + 1e-8f);
+            Hs -= p[k] * lg;
+            hk[k] = -lg - p[k] / (p[k] + 1e-8f);      // dH/dp_k
+            ph += p[k] * hk[k];
+        }
+        s_en += (double)Hs;
+        // through the softmax: d/dz_k = p_k (g_k - sum_j p_j g_j)
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const float dpol = g_logp * ((k == a ? 1.0f : 0.0f) - q[k]);
+            const float dent = -beta * inv_n * p[k] * (hk[k] - ph);
+            dlogits[i * A + k] = dpol + dent;
+        }
+    }
+    s_pl = block256_sum(s_pl, sm);
+    s_vl = block256_sum(s_vl, sm);
+    s_en = block256_sum(s_en, sm);
+    s_nan = block256_sum(s_nan, sm);
+    if (threadIdx.x == 0) {
+        partial[4 * blockIdx.x + 0] = s_pl;
+        partial[4 * blockIdx.x + 1] = s_vl;
+        partial[4 * blockIdx.x + 2] = s_en;
+        partial[4 * blockIdx.x + 3] = s_nan;
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nb,
+                                                         double* __restrict__ out4) {
+    __shared__ double sm[4];
+    double s[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nb; i += 256)
+        for (int k = 0; k < 4; ++k) s[k] += partial[4 * i + k];
+    for (int k = 0; k < 4; ++k) {
+        const double r = block256_sum(s[k], sm);
+        if (threadIdx.x == 0) out4[k] = r;
+    }
+}
+
+// ---- sampling ------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(256) void policy_sample_kernel(
+    const float* __restrict__ logits, int64_t n, const float* __restrict__ u, uint64_t seed,
+    uint64_t counter, const int32_t* __restrict__ forced, int32_t* __restrict__ act_out,
+    float* __restrict__ logp_out, float* __restrict__ probs_out, int32_t* __restrict__ nan_count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float z[A], p[A];
+#pragma unroll
+    for (int k = 0; k < A; ++k) z[k] = logits[i * A + k];
+    softmax_row<A>(z, p);
+    float psum = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        psum += p[k];
+        bad |= (p[k] != p[k]);
+    }
+    if (bad) atomicAdd(nan_count, 1);
+    int a;
+    if (forced) {
+        a = forced[i];
+    } else {
+        float uu;
+        if (u) uu = u[i];
+        else {
+            const Philox4 r = philox4x32_10(seed, (uint32_t)i, (uint32_t)(i >> 32), (uint32_t)counter, RNG_ACTION);
+            uu = u01_f32(r.x);
+        }
+        // inverse-CDF draw over the normalised probabilities (torch.multinomial semantics)
+        float cdf = 0.f;
+        a = A - 1;
+        const float target = uu * psum;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            cdf += p[k];
+            if (target < cdf) { a = k; break; }
+        }
+    }
+    float qa = 0.f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        if (probs_out) probs_out[i * A + k] = p[k];
+        if (k == a) qa = p[k] / psum;
+    }
+    act_out[i] = a;
+    logp_out[i] = logf(fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS));
+}
+
+extern "C" {
+
+int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const int32_t* act,
+                 const float* logp_old, const float* adv, const float* ret, const float* val_old,
+                 int64_t n, int n_act, float inv_n, float clip, float ent_beta, double* loss_sums,
+                 float* dlogits, float* dvalue, uav_stream stream) {
+    UAV_REQUIRE(ctx && logits && value && act && logp_old && adv && ret && val_old && loss_sums && dlogits && dvalue,
+                "uav_ppo_loss: NULL argument");
+    UAV_REQUIRE(n > 0, "uav_ppo_loss: n=%lld", (long long)n);
+    int nb = (int)((n + 255) / 256);
+    if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
+    double* partial = (double*)ctx->ws;
+#define LAUNCH_LOSS(A_)                                                                                  \
+    hipLaunchKernelGGL(ppo_loss_kernel<A_>, dim3(nb), dim3(256), 0, as_stream(stream), logits, value,   \
+                       act, logp_old, adv, ret, val_old, n, inv_n, clip, ent_beta, partial, dlogits, dvalue)
+    switch (n_act) {
+        case 2: LAUNCH_LOSS(2); break;
+        case 3: LAUNCH_LOSS(3); break;
+        case 4: LAUNCH_LOSS(4); break;
+        case 5: LAUNCH_LOSS(5); break;
+        case 6: LAUNCH_LOSS(6); break;
+        case 8: LAUNCH_LOSS(8); break;
+        default: UAV_REQUIRE(false, "uav_ppo_loss: n_act=%d unsupported", n_act);
+    }
+#undef LAUNCH_LOSS
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, loss_sums);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, const float* u,
+                      uint64_t seed, uint64_t counter, const int32_t* forced_act, int32_t* act_out,
+                      float* logp_out, float* probs_out, int32_t* nan_count, uav_stream stream) {
+    UAV_REQUIRE(ctx && logits && act_out && logp_out && nan_count && n > 0, "uav_policy_sample: bad argument");
+    const int nb = (int)((n + 255) / 256);
+#define LAUNCH_S(A_)                                                                                      \
+    hipLaunchKernelGGL(policy_sample_kernel<A_>, dim3(nb), dim3(256), 0, as_stream(stream), logits, n, u, \
+                       seed, counter, forced_act, act_out, logp_out, probs_out, nan_count)
+    switch (n_act) {
+        case 2: LAUNCH_S(2); break;
+        case 3: LAUNCH_S(3); break;
+        case 4: LAUNCH_S(4); break;
+        case 5: LAUNCH_S(5); break;
+        case 6: LAUNCH_S(6); break;
+        case 8: LAUNCH_S(8); break;
+        default: UAV_REQUIRE(false, "uav_policy_sample: n_act=%d unsupported", n_act);
+    }
+#undef LAUNCH_S
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// mlp.hip -- M2: the reference's MLP actor-critic, forward and backward.
+//
+// Reference: PPOV2.0/model.py:17-53  Linear(in,256)->LayerNorm->ReLU->Linear(256,128)->LayerNorm
+// ->ReLU->actor Linear(128,A) | critic Linear(128,1).  The Linear layers run on gemm.hip
+// (exact-f32 MFMA); LayerNorm+ReLU forward/backward are one-wave-per-row kernels (row fits one
+// wave's registers, reductions by shuffles), parameter gradients by deterministic two-stage
+// column reductions.  Flat parameter layout (heads contiguous so actor|critic is ONE GEMM):
+//   W1[h1][in] b1[h1] g1[h1] be1[h1] W2[h2][h1] b2[h2] g2[h2] be2[h2] Wh[A+1][h2] bh[A+1]
+// Stash (consumed by the backward): xhat1[B][h1] a1[B][h1] xhat2[B][h2] a2[B][h2] rstd1[B] rstd2[B].
+#include "common.h"
+
+int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
+             const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
+             int accumulate, hipStream_t st);
+
+constexpr float LN_EPS = 1e-5f;
+
+struct MlpLayout {
+    int64_t W1, b1, g1, be1, W2, b2, g2, be2, Wh, bh, total;
+};
+static MlpLayout mlp_layout(int in, int h1, int h2, int A) {
+    MlpLayout L;
+    int64_t o = 0;
+    L.W1 = o; o += (int64_t)h1 * in;
+    L.b1 = o; o += h1;
+    L.g1 = o; o += h1;
+    L.be1 = o; o += h1;
+    L.W2 = o; o += (int64_t)h2 * h1;
+    L.b2 = o; o += h2;
+    L.g2 = o; o += h2;
+    L.be2 = o; o += h2;
+    L.Wh = o; o += (int64_t)(A + 1) * h2;
+    L.bh = o; o += A + 1;
+    L.total = o;
+    return L;
+}
+
+// z (in place -> xhat), a = relu(xhat*g + b), rstd.  One wave per row, VPT values per lane.
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float* __restrict__ z, float* __restrict__ a,
+                                                          float* __restrict__ rstd_out,
+                                                          const float* __restrict__ g,
+                                                          const float* __restrict__ be, int64_t B) {
+    constexpr int C = VPT * 64;
+    const int lane = threadIdx.x & 63;
+    float gg[VPT], bb[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        gg[j] = g[j * 64 + lane];
+        bb[j] = be[j * 64 + lane];
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < B; row += (int64_t)gridDim.x * 4) {
+        float v[VPT], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            v[j] = z[row * C + j * 64 + lane];
+            s += v[j];
+        }
+        const float mean = wave_allsum(s) * (1.0f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            v[j] -= mean;
+            q += v[j] * v[j];
+        }
+        const float rstd = 1.0f / sqrtf(wave_allsum(q) * (1.0f / C) + LN_EPS);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            const float xh = v[j] * rstd;
+            z[row * C + j * 64 + lane] = xh;
+            a[row * C + j * 64 + lane] = fmaxf(xh * gg[j] + bb[j], 0.f);
+        }
+        if (lane == 0) rstd_out[row] = rstd;
+    }
+}
+
+// d (in place: dL/da -> dL/dz), partial[block][2][C] = per-block sums of (dgamma, dbeta)
+template <int VPT>
+__global__ __launch_bounds__(256) void ln_relu_bwd_kernel(float* __restrict__ d, const float* __restrict__ xhat,
+                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ g,
+                                                          const float* __restrict__ be, int64_t B,
+                                                          float* __restrict__ partial) {
+    constexpr int C = VPT * 64;
+    __shared__ float sm[4][2][C];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float gg[VPT], bb[VPT], dg[VPT], db[VPT];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        gg[j] = g[j * 64 + lane];
+        bb[j] = be[j * 64 + lane];
+        dg[j] = 0.f;
+        db[j] = 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < B; row += (int64_t)gridDim.x * 4) {
+        const float rs = rstd[row];
+        float xh[VPT], dxh[VPT], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            xh[j] = xhat[row * C + j * 64 + lane];
+            float dy = d[row * C + j * 64 + lane];
+            if (!(xh[j] * gg[j] + bb[j] > 0.f)) dy = 0.f;     // ReLU mask (recomputed pre-activation)
+            dg[j] += dy * xh[j];
+            db[j] += dy;
+            dxh[j] = dy * gg[j];
+            s1 += dxh[j];
+            s2 += dxh[j] * xh[j];
+        }
+        const float m1 = wave_allsum(s1) * (1.0f / C), m2 = wave_allsum(s2) * (1.0f / C);
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) d[row * C + j * 64 + lane] = rs * (dxh[j] - m1 - xh[j] * m2);
+    }
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        sm[w][0][j * 64 + lane] = dg[j];
+        sm[w][1][j * 64 + lane] = db[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        partial[((int64_t)blockIdx.x * 2 + which) * C + c] =
+            ((sm[0][which][c] + sm[1][which][c]) + sm[2][which][c]) + sm[3][which][c];
+    }
+}
+
+// out[c] = sum_b partial[b][c]  (fixed order)
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ partial, int nb, int C,
+                                                          float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * C + c];
+    out[c] = s;
+}
+
+// partial[block][C] = sum over the block's rows of X[row][c]   (C <= 1024)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t B, int C,
+                                                             int64_t rows_per_block, float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += X[r * C + c];
+        partial[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st) {
+    // column sums are tiny next to the GEMMs; keep them simple and deterministic
+    int nb = (int)((B + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    const int64_t rpb = (B + nb - 1) / nb;
+    nb = (int)((B + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, nb, C, out);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int VPT>
+static int ln_fwd(float* z, float* a, float* rstd, const float* g, const float* be, int64_t B, hipStream_t st) {
+    int nb = (int)((B + 3) / 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(ln_relu_fwd_kernel<VPT>, dim3(nb), dim3(256), 0, st, z, a, rstd, g, be, B);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+static int ln_fwd_any(int C, float* z, float* a, float* rstd, const float* g, const float* be, int64_t B,
+                      hipStream_t st) {
+    switch (C) {
+        case 64: return ln_fwd<1>(z, a, rstd, g, be, B, st);
+        case 128: return ln_fwd<2>(z, a, rstd, g, be, B, st);
+        case 256: return ln_fwd<4>(z, a, rstd, g, be, B, st);
+        case 512: return ln_fwd<8>(z, a, rstd, g, be, B, st);
+    }
+    uav_set_error("mlp: LayerNorm width %d unsupported (64/128/256/512)", C);
+    return 2;
+}
+
+constexpr int LNB_BLOCKS = 512;
+template <int VPT>
+static int ln_bwd(uav_ctx* ctx, float* d, const float* xhat, const float* rstd, const float* g, const float* be,
+                  int64_t B, float* dg_out, float* db_out, float* scratch, hipStream_t st) {
+    constexpr int C = VPT * 64;
+    int nb = (int)((B + 3) / 4);
+    if (nb > LNB_BLOCKS) nb = LNB_BLOCKS;
+    hipLaunchKernelGGL(ln_relu_bwd_kernel<VPT>, dim3(nb), dim3(256), 0, st, d, xhat, rstd, g, be, B, scratch);
+    // partial is [nb][2][C]: reduce as 2C columns, then split
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, scratch, nb, 2 * C,
+                       scratch + (int64_t)LNB_BLOCKS * 2 * C);
+    UAV_CHECK_HIP(hipMemcpyAsync(dg_out, scratch + (int64_t)LNB_BLOCKS * 2 * C, C * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+    UAV_CHECK_HIP(hipMemcpyAsync(db_out, scratch + (int64_t)LNB_BLOCKS * 2 * C + C, C * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+static int ln_bwd_any(uav_ctx* ctx, int C, float* d, const float* xhat, const float* rstd, const float* g,
+                      const float* be, int64_t B, float* dg, float* db, float* scratch, hipStream_t st) {
+    switch (C) {
+        case 64: return ln_bwd<1>(ctx, d, xhat, rstd, g, be, B, dg, db, scratch, st);
+        case 128: return ln_bwd<2>(ctx, d, xhat, rstd, g, be, B, dg, db, scratch, st);
+        case 256: return ln_bwd<4>(ctx, d, xhat, rstd, g, be, B, dg, db, scratch, st);
+        case 512: return ln_bwd<8>(ctx, d, xhat, rstd, g, be, B, dg, db, scratch, st);
+    }
+    uav_set_error("mlp: LayerNorm width %d unsupported (64/128/256/512)", C);
+    return 2;
+}
+
+extern "C" {
+
+int64_t uav_mlp_param_count(int in_dim, int h1, int h2, int n_act) { return mlp_layout(in_dim, h1, h2, n_act).total; }
+int64_t uav_mlp_stash_floats(int h1, int h2) { return 2 * (int64_t)h1 + 2 * (int64_t)h2 + 2; }
+
+int uav_mlp_fwd(uav_ctx* ctx, const float* params, const float* x, int64_t B, int in_dim, int h1, int h2,
+                int n_act, float* heads, float* stash, uav_stream stream) {
+    UAV_REQUIRE(ctx && params && x && heads && stash && B > 0, "uav_mlp_fwd: bad argument (stash is required)");
+    const MlpLayout L = mlp_layout(in_dim, h1, h2, n_act);
+    hipStream_t st = as_stream(stream);
+    float* xhat1 = stash;
+    float* a1 = xhat1 + B * h1;
+    float* xhat2 = a1 + B * h1;
+    float* a2 = xhat2 + B * h2;
+    float* rstd1 = a2 + B * h2;
+    float* rstd2 = rstd1 + B;
+    int rc;
+    // z1 = x W1^T + b1   (NT: op(B)[k][j] = W1[j][k])
+    if ((rc = gemm_f32(ctx, B, h1, in_dim, x, in_dim, 1, params + L.W1, 1, in_dim, xhat1, h1, params + L.b1, 0, st))) return rc;
+    if ((rc = ln_fwd_any(h1, xhat1, a1, rstd1, params + L.g1, params + L.be1, B, st))) return rc;
+    if ((rc = gemm_f32(ctx, B, h2, h1, a1, h1, 1, params + L.W2, 1, h1, xhat2, h2, params + L.b2, 0, st))) return rc;
+    if ((rc = ln_fwd_any(h2, xhat2, a2, rstd2, params + L.g2, params + L.be2, B, st))) return rc;
+    return gemm_f32(ctx, B, n_act + 1, h2, a2, h2, 1, params + L.Wh, 1, h2, heads, n_act + 1, params + L.bh, 0, st);
+}
+
+int uav_mlp_bwd(uav_ctx* ctx, const float* params, const float* x, float* stash, const float* dheads, int64_t B,
+                int in_dim, int h1, int h2, int n_act, float* grad, uav_stream stream) {
+    UAV_REQUIRE(ctx && params && x && stash && dheads && grad && B > 0, "uav_mlp_bwd: bad argument");
+    const MlpLayout L = mlp_layout(in_dim, h1, h2, n_act);
+    hipStream_t st = as_stream(stream);
+    float* xhat1 = stash;
+    float* a1 = xhat1 + B * h1;
+    float* xhat2 = a1 + B * h1;
+    float* a2 = xhat2 + B * h2;
+    float* rstd1 = a2 + B * h2;
+    float* rstd2 = rstd1 + B;
+    const int A1 = n_act + 1;
+    // scratch for column reductions lives behind the split-K slab area of the workspace
+    const size_t red_floats = (size_t)LNB_BLOCKS * 2 * 512 + 2 * 512 + 1024 * 512;
+    UAV_REQUIRE(ctx->ws_bytes >= (red_floats + (1 << 18)) * sizeof(float), "uav_mlp_bwd: workspace too small");
+    float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
+    uav_ctx sub = *ctx;                       // GEMM slabs may use everything in front of `red`
+    sub.ws_bytes = ctx->ws_bytes - red_floats * sizeof(float);
+    int rc;
+    // heads: dWh = dheads^T a2 ; dbh = colsum(dheads) ; da2 = dheads Wh   (da2 overwrites a2)
+    if ((rc = gemm_f32(&sub, A1, h2, B, dheads, 1, A1, a2, h2, 1, grad + L.Wh, h2, nullptr, 0, st))) return rc;
+    if ((rc = colsum(&sub, dheads, B, A1, grad + L.bh, red, st))) return rc;
+    if ((rc = gemm_f32(&sub, B, h2, A1, dheads, A1, 1, params + L.Wh, h2, 1, a2, h2, nullptr, 0, st))) return rc;
+    if ((rc = ln_bwd_any(&sub, h2, a2, xhat2, rstd2, params + L.g2, params + L.be2, B, grad + L.g2, grad + L.be2, red, st))) return rc;
+    // layer 2: dW2 = dz2^T a1 ; db2 ; da1 = dz2 W2  (overwrites a1)
+    if ((rc = gemm_f32(&sub, h2, h1, B, a2, 1, h2, a1, h1, 1, grad + L.W2, h1, nullptr, 0, st))) return rc;
+    if ((rc = colsum(&sub, a2, B, h2, grad + L.b2, red, st))) return rc;
+    if ((rc = gemm_f32(&sub, B, h1, h2, a2, h2, 1, params + L.W2, h1, 1, a1, h1, nullptr, 0, st))) return rc;
+    if ((rc = ln_bwd_any(&sub, h1, a1, xhat1, rstd1, params + L.g1, params + L.be1, B, grad + L.g1, grad + L.be1, red, st))) return rc;
+    // layer 1: dW1 = dz1^T x ; db1
+    if ((rc = gemm_f32(&sub, h1, in_dim, B, a1, 1, h1, x, in_dim, 1, grad + L.W1, in_dim, nullptr, 0, st))) return rc;
+    return colsum(&sub, a1, B, h1, grad + L.b1, red, st);
+}
+
+}  // extern "C"

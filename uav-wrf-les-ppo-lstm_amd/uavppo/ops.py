@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype/device checks on the host, then one call
+into libuavppo.so on torch's current HIP stream.  PyTorch only supplies device memory and
+streams here; every number is produced by the hand-written HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EnvCfg, check, lib
+
+GAE_MODES = {"reference_exact": 0, "standard": 1}
+WS_BYTES = 256 << 20
+
+
+class Context:
+    """One uav_ctx per device (opaque handle: CU count + scratch workspace)."""
+    _per_device: dict = {}
+
+    def __init__(self, device_index):
+        if not torch.cuda.is_available():
+            raise RuntimeError("uavppo needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                               "and there is no CPU fallback")
+        h = C.c_void_p()
+        check(lib().uav_create(C.byref(h), int(device_index), WS_BYTES), "uav_create")
+        self.handle = h
+        self.device = device_index
+
+    @classmethod
+    def get(cls, device=None):
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        if idx not in cls._per_device:
+            cls._per_device[idx] = cls(idx)
+        return cls._per_device[idx]
+
+
+def _h(t):
+    return Context.get(t.device).handle
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype=None, shape=None, name="tensor"):
+    """Device pointer of a checked tensor (None passes through as NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+F32, F64, I32, U8 = torch.float32, torch.float64, torch.int32, torch.uint8
+
+
+# ----------------------------------------------------------------------------- G1 / G2
+def gae(rew, val, done, gamma, lam, mode="reference_exact", last_val=None, out=None):
+    n, T = rew.shape
+    adv = torch.empty_like(rew) if out is None else out
+    check(lib().uav_gae(_h(rew), _p(rew, F32, (n, T), "rew"), _p(val, F32, (n, T), "val"),
+                        _p(done, F32, (n, T), "done"), _p(last_val, F32, (n,), "last_val"), n, T,
+                        float(gamma), float(lam), GAE_MODES[mode], _p(adv, F32, (n, T), "adv"), _stream()),
+          "uav_gae")
+    return adv
+
+
+def adv_stats(adv, out=None):
+    stats = torch.empty(3, dtype=F64, device=adv.device) if out is None else out
+    check(lib().uav_adv_stats(_h(adv), _p(adv, F32, name="adv"), adv.numel(), _p(stats, F64, (3,), "stats3"),
+                              _stream()), "uav_adv_stats")
+    return stats
+
+
+def adv_normalise(adv, val, stats3, adv_out=None, ret_out=None):
+    adv_out = torch.empty_like(adv) if adv_out is None else adv_out
+    ret_out = torch.empty_like(adv) if ret_out is None else ret_out
+    if val.shape != adv.shape:
+        raise RuntimeError("adv_normalise: val/adv shape mismatch")
+    check(lib().uav_adv_normalise(_h(adv), _p(adv, F32, name="adv"), _p(val, F32, name="val"), adv.numel(),
+                                  _p(stats3, F64, (3,), "stats3"), _p(adv_out, F32, adv.shape, "adv_out"),
+                                  _p(ret_out, F32, adv.shape, "ret_out"), _stream()), "uav_adv_normalise")
+    return adv_out, ret_out
+
+
+# ----------------------------------------------------------------------------- U2 / K3
+def ppo_loss(logits, value, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta,
+             loss_sums=None, dlogits=None, dvalue=None):
+    n, A = logits.shape
+    loss_sums = torch.empty(4, dtype=F64, device=logits.device) if loss_sums is None else loss_sums
+    dlogits = torch.empty_like(logits) if dlogits is None else dlogits
+    dvalue = torch.empty(n, dtype=F32, device=logits.device) if dvalue is None else dvalue
+    check(lib().uav_ppo_loss(_h(logits), _p(logits, F32, (n, A), "logits"), _p(value.reshape(-1), F32, (n,), "value"),
+                             _p(act, I32, (n,), "act"), _p(logp_old, F32, (n,), "logp_old"),
+                             _p(adv, F32, (n,), "adv"), _p(ret, F32, (n,), "ret"), _p(val_old, F32, (n,), "val_old"),
+                             n, A, float(inv_n), float(clip), float(ent_beta), _p(loss_sums, F64, (4,), "loss_sums"),
+                             _p(dlogits, F32, (n, A), "dlogits"), _p(dvalue, F32, (n,), "dvalue"), _stream()),
+          "uav_ppo_loss")
+    return loss_sums, dlogits, dvalue
+
+
+def policy_sample(logits, u=None, seed=0, counter=0, forced_act=None, want_probs=False, nan_count=None):
+    n, A = logits.shape
+    dev = logits.device
+    act = torch.empty(n, dtype=I32, device=dev)
+    logp = torch.empty(n, dtype=F32, device=dev)
+    probs = torch.empty(n, A, dtype=F32, device=dev) if want_probs else None
+    nan_count = torch.zeros(1, dtype=I32, device=dev) if nan_count is None else nan_count
+    check(lib().uav_policy_sample(_h(logits), _p(logits, F32, (n, A), "logits"), n, A, _p(u, F32, (n,), "u"),
+                                  int(seed), int(counter), _p(forced_act, I32, (n,), "forced_act"),
+                                  _p(act), _p(logp), _p(probs), _p(nan_count, I32, (1,), "nan_count"), _stream()),
+          "uav_policy_sample")
+    return act, logp, probs, nan_count
+
+
+# ----------------------------------------------------------------------------- U3
+def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.5,
+              gnorm_out=None):
+    n = param.numel()
+    for t, nm in ((grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if t.numel() != n:
+            raise RuntimeError(f"clip_adam: {nm} has {t.numel()} elements, param has {n}")
+    check(lib().uav_clip_adam(_h(param), _p(param, F32, name="param"), _p(grad, F32, name="grad"),
+                              _p(exp_avg, F32, name="exp_avg"), _p(exp_avg_sq, F32, name="exp_avg_sq"), n, int(step),
+                              float(lr), float(beta1), float(beta2), float(eps), float(max_norm),
+                              _p(gnorm_out, F32, (1,), "gnorm_out"), _stream()), "uav_clip_adam")
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False):
+    """out[M,N] (+)= op(a) @ op(b) + bias with 2-D row-major tensors (op = optional transpose)."""
+    if a.dim() != 2 or b.dim() != 2:
+        raise RuntimeError("gemm: 2-D tensors expected")
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if K != K2:
+        raise RuntimeError(f"gemm: inner dimensions differ ({K} vs {K2})")
+    sa_m, sa_k = (1, a.shape[1]) if trans_a else (a.shape[1], 1)
+    sb_k, sb_n = (1, b.shape[1]) if trans_b else (b.shape[1], 1)
+    if out is None:
+        if accumulate:
+            raise RuntimeError("gemm: accumulate needs out")
+        out = torch.empty(M, N, dtype=F32, device=a.device)
+    check(lib().uav_gemm_f32(_h(a), M, N, K, _p(a, F32, name="a"), sa_m, sa_k, _p(b, F32, name="b"), sb_k, sb_n,
+                             _p(out, F32, (M, N), "out"), N, _p(bias, F32, (N,), "bias"), int(accumulate), _stream()),
+          "uav_gemm_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- M2
+def mlp_param_count(in_dim=6, h1=256, h2=128, n_act=5):
+    return int(lib().uav_mlp_param_count(in_dim, h1, h2, n_act))
+
+
+def mlp_fwd(params, x, in_dim=6, h1=256, h2=128, n_act=5, stash=None):
+    B = x.shape[0]
+    if params.numel() != mlp_param_count(in_dim, h1, h2, n_act):
+        raise RuntimeError("mlp_fwd: flat parameter buffer has the wrong size")
+    heads = torch.empty(B, n_act + 1, dtype=F32, device=x.device)
+    per = int(lib().uav_mlp_stash_floats(h1, h2))
+    if stash is None:
+        stash = torch.empty(B * per, dtype=F32, device=x.device)
+    elif stash.numel() < B * per:
+        raise RuntimeError("mlp_fwd: stash too small")
+    check(lib().uav_mlp_fwd(_h(x), _p(params, F32, name="params"), _p(x, F32, (B, in_dim), "x"), B, in_dim, h1, h2,
+                            n_act, _p(heads), _p(stash, F32, name="stash"), _stream()), "uav_mlp_fwd")
+    return heads, stash
+
+
+def mlp_bwd(params, x, stash, dheads, in_dim=6, h1=256, h2=128, n_act=5, grad=None):
+    B = x.shape[0]
+    grad = torch.empty_like(params) if grad is None else grad
+    check(lib().uav_mlp_bwd(_h(x), _p(params, F32, name="params"), _p(x, F32, (B, in_dim), "x"),
+                            _p(stash, F32, name="stash"), _p(dheads, F32, (B, n_act + 1), "dheads"), B, in_dim, h1,
+                            h2, n_act, _p(grad, F32, params.shape, "grad"), _stream()), "uav_mlp_bwd")
+    return grad
