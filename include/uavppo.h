@@ -138,6 +138,8 @@ typedef struct uav_env_cfg {
     int32_t field_mode;     /* UAV_FIELD_*                                                  */
     int32_t n_fields;       /* F (materialised mode)                                        */
     int32_t bonus_is_f64;   /* explore_bonus became np.float64 (model.py:142): f64 arithmetic */
+    int32_t env_offset;     /* global index of this rank's env 0 (RNG key / field choice)   */
+    int32_t n_env_total;    /* envs over all ranks; episode k of env e uses field (e+k*total)%F */
     double  radius;         /* current_radius  (model.py:132)                               */
     double  bonus;          /* explore_bonus   (model.py:133)                               */
     uint64_t seed;          /* counter-RNG key (procedural fields, sources, step noise)     */
@@ -147,7 +149,7 @@ typedef struct uav_env_cfg {
 
 size_t uav_env_state_bytes(int n_env);
 /* reset every env (environment.py:41-49); obs_out f32 [n_env][6] */
-int uav_env_reset(uav_ctx* ctx, void* state, int n_env, int env_offset, const uav_env_cfg* cfg /*host*/,
+int uav_env_reset(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg /*host*/,
                   float* obs_out, uav_stream stream);
 /* one step of every env with auto-reset (environment.py:82-169 + the reset of
  * train_ppo2.0.py:139).  act i32 [n]; noise f64 [n][2] standard normals or NULL (counter RNG).

@@ -8,11 +8,6 @@ int uav_lstm_fwd(uav_ctx*, const float*, const float*, const float*, const float
 int uav_lstm_bwd(uav_ctx*, const float*, const float*, const float*, const float*, const float*, const float*,
                  const float*, const float*, int, int, int, int, float*, float*, float*, float*, float*, float*, float*,
                  uav_stream) { NOT_YET("uav_lstm_bwd"); }
-size_t uav_env_state_bytes(int) { return 0; }
-int uav_env_reset(uav_ctx*, void*, int, int, const uav_env_cfg*, float*, uav_stream) { NOT_YET("uav_env_reset"); }
-int uav_env_step(uav_ctx*, void*, int, const uav_env_cfg*, const int32_t*, const double*, float*, float*, float*,
-                 uint8_t*, float*, float*, double*, uav_stream) { NOT_YET("uav_env_step"); }
-int uav_env_peek(uav_ctx*, const void*, int, float*, double*, int32_t*, int32_t*, uav_stream) { NOT_YET("uav_env_peek"); }
 int uav_rollout(uav_ctx*, void*, int, const uav_env_cfg*, int, const float*, int, int, uint64_t, float*, float*, float*,
                 float*, int32_t*, float*, float*, float*, float*, uint8_t*, float*, float*, const int32_t*,
                 const double*, int32_t*, uav_stream) { NOT_YET("uav_rollout"); }

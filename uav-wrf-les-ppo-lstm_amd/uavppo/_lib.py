@@ -18,7 +18,8 @@ P, I32, I64, U64, F32, F64, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c
 class EnvCfg(C.Structure):
     """struct uav_env_cfg (include/uavppo.h)."""
     _fields_ = [("variant", C.c_int32), ("field_mode", C.c_int32), ("n_fields", C.c_int32),
-                ("bonus_is_f64", C.c_int32), ("radius", C.c_double), ("bonus", C.c_double),
+                ("bonus_is_f64", C.c_int32), ("env_offset", C.c_int32), ("n_env_total", C.c_int32),
+                ("radius", C.c_double), ("bonus", C.c_double),
                 ("seed", C.c_uint64), ("bank", C.c_void_p), ("bank_src", C.c_void_p)]
 
 
@@ -42,7 +43,7 @@ SIGNATURES = {
     "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
     "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),
-    "uav_env_reset": (I32, [P, P, I32, I32, C.POINTER(EnvCfg), P, P]),
+    "uav_env_reset": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P]),
     "uav_env_step": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P, P, P, P, P, P, P, P, P]),
     "uav_env_peek": (I32, [P, P, I32, P, P, P, P, P]),
     "uav_rollout": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, I32, I32, U64, P, P, P, P, P, P, P, P, P, P,

@@ -183,3 +183,53 @@ def mlp_bwd(params, x, stash, dheads, in_dim=6, h1=256, h2=128, n_act=5, grad=No
                             _p(stash, F32, name="stash"), _p(dheads, F32, (B, n_act + 1), "dheads"), B, in_dim, h1,
                             h2, n_act, _p(grad, F32, params.shape, "grad"), _stream()), "uav_mlp_bwd")
     return grad
+
+
+# ----------------------------------------------------------------------------- E1-E5
+ENV_VARIANTS = {"v2.0": 0, "v2.1": 1, "v1.1": 2}
+ENV_MAX_STEPS = {"v2.0": 1000, "v2.1": 1000, "v1.1": 5000}
+
+
+def env_state_bytes(n_env):
+    return int(lib().uav_env_state_bytes(int(n_env)))
+
+
+def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_offset=0, n_env_total=0):
+    """uav_env_cfg (host struct).  bonus: python float -> the reference's f32 expression,
+    numpy.float64 -> its f64 expression (see csrc/env_core.h, environment.py:133)."""
+    import numpy as np
+    cfg = EnvCfg()
+    cfg.variant = ENV_VARIANTS[variant]
+    cfg.field_mode = 1 if bank is not None else 0
+    cfg.n_fields = 0 if bank is None else int(bank.shape[0])
+    cfg.bonus_is_f64 = int(isinstance(bonus, np.float64))
+    cfg.env_offset = int(env_offset)
+    cfg.n_env_total = int(n_env_total)
+    cfg.radius = float(radius)
+    cfg.bonus = float(bonus)
+    cfg.seed = int(seed)
+    if bank is not None:
+        F_ = bank.shape[0]
+        cfg.bank = _p(bank, F64, (F_, 500, 500, 2), "bank").value
+        cfg.bank_src = _p(bank_src, F64, (F_, 2), "bank_src").value
+    return cfg
+
+
+def env_reset(state, n_env, cfg, obs_out):
+    check(lib().uav_env_reset(_h(state), _p(state, U8, name="env state"), n_env, C.byref(cfg),
+                              _p(obs_out, F32, (n_env, 6), "obs_out"), _stream()), "uav_env_reset")
+
+
+def env_step(state, n_env, cfg, act, obs_out, rew, done, flags, noise=None, info=None, term_obs=None, rew64=None):
+    check(lib().uav_env_step(_h(state), _p(state, U8, name="env state"), n_env, C.byref(cfg),
+                             _p(act, I32, (n_env,), "act"), _p(noise, F64, (n_env, 2), "noise"),
+                             _p(obs_out, F32, (n_env, 6), "obs_out"), _p(rew, F32, (n_env,), "rew"),
+                             _p(done, F32, (n_env,), "done"), _p(flags, U8, (n_env,), "flags"),
+                             _p(info, F32, (n_env, 5), "info"), _p(term_obs, F32, (n_env, 6), "term_obs"),
+                             _p(rew64, F64, (n_env,), "rew64"), _stream()), "uav_env_step")
+
+
+def env_peek(state, n_env, pos=None, source=None, steps=None, episode=None):
+    check(lib().uav_env_peek(_h(state), _p(state, U8, name="env state"), n_env, _p(pos, F32, (n_env, 2), "pos"),
+                             _p(source, F64, (n_env, 2), "source"), _p(steps, I32, (n_env,), "steps"),
+                             _p(episode, I32, (n_env,), "episode"), _stream()), "uav_env_peek")
