@@ -1,0 +1,100 @@
+"""HIP LSTM sequence kernels vs torch.nn.LSTM (CPU, the module the reference uses:
+PPOV2.0/model.py:206-212, PPOV2.1/model.py:263) and the oracle's episode-reset variant.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from uavppo import ops as o
+    return o
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= atol * max(scale, 1.0) + rtol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("T,N,I,H", [(8, 4, 6, 64), (16, 8, 6, 128), (70, 37, 6, 128), (5, 16, 8, 64),
+                                     (12, 20, 64, 64), (9, 17, 128, 128), (1, 1, 6, 128)])
+@pytest.mark.parametrize("use_keep", [False, True])
+def test_lstm_layer_fwd_bwd(ops, T, N, I, H, use_keep):
+    torch.manual_seed(T * 100 + N)
+    ref = torch.nn.LSTM(I, H, 1)
+    w_ih, w_hh, b_ih, b_hh = [p.detach().clone().requires_grad_(True) for p in ref.parameters()]
+    x = torch.randn(T, N, I, requires_grad=True)
+    h0 = torch.randn(N, H, requires_grad=True)
+    c0 = torch.randn(N, H, requires_grad=True)
+    keep = (torch.rand(T, N) > 0.2).float() if use_keep else None
+    if use_keep:
+        keep[0, 0] = 0.0
+    y, hn, cn = po.lstm_layer_forward(x, h0, c0, w_ih, w_hh, b_ih, b_hh, keep)
+    if not use_keep:                      # restatement == torch.nn.LSTM itself
+        y2, (hn2, cn2) = ref(x.detach(), (h0.detach()[None], c0.detach()[None]))
+        assert torch.allclose(y, y2, atol=1e-6) and torch.allclose(cn, cn2[0], atol=1e-6)
+    dy = torch.randn(T, N, H)
+    dhn, dcn = torch.randn(N, H), torch.randn(N, H)
+    ((y * dy).sum() + (hn * dhn).sum() + (cn * dcn).sum()).backward()
+
+    d = lambda t: t.detach().to(DEV).contiguous()
+    xg = d(x.transpose(0, 1))                      # (env, T, feat)
+    kg = d(keep.transpose(0, 1)) if use_keep else None
+    yg, hng, cng, stash = ops.lstm_fwd(xg, kg, d(h0), d(c0), d(w_ih), d(w_hh), d(b_ih), d(b_hh))
+    _close(yg.transpose(0, 1), y, 1e-5, 2e-6)
+    _close(hng, hn, 1e-5, 2e-6)
+    _close(cng, cn, 1e-5, 2e-6)
+    g = ops.lstm_bwd(xg, kg, stash, d(w_ih), d(w_hh), dy=d(dy.transpose(0, 1)), dhn=d(dhn), dcn=d(dcn), need_dx=True)
+    _close(g["dx"].transpose(0, 1), x.grad)
+    _close(g["dw_ih"], w_ih.grad)
+    _close(g["dw_hh"], w_hh.grad)
+    _close(g["db"], b_ih.grad)
+    _close(g["dh0"], h0.grad)
+    _close(g["dc0"], c0.grad)
+
+
+def test_lstm_bwd_fused_heads_equals_explicit_dy(ops):
+    """dheads + w_head path (dy formed in registers) == passing dy = dheads @ w_head."""
+    torch.manual_seed(3)
+    N, T, I, H = 33, 40, 6, 128
+    dev = DEV
+    x = torch.randn(N, T, I, device=dev)
+    keep = (torch.rand(N, T, device=dev) > 0.1).float()
+    w_ih, w_hh = torch.randn(4 * H, I, device=dev) * 0.1, torch.randn(4 * H, H, device=dev) * 0.1
+    b = torch.randn(4 * H, device=dev) * 0.1
+    h0, c0 = torch.randn(N, H, device=dev), torch.randn(N, H, device=dev)
+    y, hn, cn, stash = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b, b)
+    dheads = torch.randn(N, T, 6, device=dev)
+    w_head = torch.randn(6, H, device=dev)
+    dy = (dheads.reshape(-1, 6).cpu().double() @ w_head.cpu().double()).float().reshape(N, T, H).to(dev)
+    g1 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, dy=dy)
+    g2 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, dheads=dheads, w_head=w_head)
+    for k in ("dw_ih", "dw_hh", "db", "dh0", "dc0"):
+        _close(g2[k], g1[k], 1e-4, 1e-5)
+
+
+def test_lstm_two_layer_stack_matches_torch(ops):
+    """Stacked layers (BASELINE config C5 'h=256 stacked x2' shape family, here H=128): layer 2 takes
+    the time-batched input-projection path (I = H > 8)."""
+    torch.manual_seed(5)
+    T, N, I, H = 10, 19, 8, 128
+    ref = torch.nn.LSTM(I, H, 2)
+    x = torch.randn(T, N, I)
+    h0, c0 = torch.randn(2, N, H), torch.randn(2, N, H)
+    y_ref, (hn_ref, cn_ref) = ref(x, (h0, c0))
+    d = lambda t: t.detach().to(DEV).contiguous()
+    p = {k: d(v) for k, v in ref.named_parameters()}
+    y1, hn1, cn1, _ = ops.lstm_fwd(d(x.transpose(0, 1)), None, d(h0[0]), d(c0[0]), p["weight_ih_l0"], p["weight_hh_l0"],
+                                   p["bias_ih_l0"], p["bias_hh_l0"])
+    y2, hn2, cn2, _ = ops.lstm_fwd(y1, None, d(h0[1]), d(c0[1]), p["weight_ih_l1"], p["weight_hh_l1"],
+                                   p["bias_ih_l1"], p["bias_hh_l1"])
+    _close(y2.transpose(0, 1), y_ref, 1e-5, 3e-6)
+    _close(hn2, hn_ref[1], 1e-5, 3e-6)
+    _close(cn1, cn_ref[0], 1e-5, 3e-6)

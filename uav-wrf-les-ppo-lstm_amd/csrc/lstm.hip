@@ -1,0 +1,435 @@
+// lstm.hip -- L1: nn.LSTM-semantics sequence kernels (forward with BPTT stash, backward).
+//
+// Reference semantics: torch.nn.LSTM as the reference uses it (PPOV2.0/model.py:206-212,
+// PPOV2.1/model.py:263,284,311,330): gates = x W_ih^T + b_ih + h W_hh^T + b_hh, chunk order
+// i,f,g,o, c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c').
+//
+// MI355X design (persistent over time, MFMA-bound, exact f32):
+//   * one workgroup owns 16 env sequences for ALL T steps; grid = N/16 (256 WGs at N=4096);
+//   * wave w owns hidden units [16w,16w+16) of all four gates, so the i,f,g,o pre-activations of
+//     one (env, unit) land in ONE lane's accumulators (v_mfma_f32_16x16x4_f32, M = 16 envs) and
+//     the gate pointwise + cell state never leave registers;
+//   * that wave's 4 x 16 x H slice of W_hh stays in VGPRs for the whole sequence (128 VGPRs at
+//     H=128): the recurrent weights are read from HBM once per launch, not once per step;
+//   * h_t goes through a double-buffered, padded LDS tile (one barrier per step), read back as
+//     conflict-free ds_read_b128 A-fragments (k is permuted so each lane reads contiguous floats);
+//   * the K=I<=8 input projection rides along as two extra MFMA k-steps (x staged in LDS per
+//     32-step chunk); wider inputs (stacked layers) use a time-batched GEMM into the stash first.
+// Backward mirrors it with W_hh^T slices in VGPRs: dgates of a step are written to LDS (and to
+// HBM for the weight-gradient GEMMs), dh_{t-1} = dgates W_hh comes back in the same lane layout
+// as the pointwise needs, so dh/dc also stay in registers across the time loop.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
+             const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
+             int accumulate, hipStream_t st);
+int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st);
+
+constexpr int MT = 16;      // env rows per workgroup (MFMA M)
+constexpr int TC = 32;      // time steps staged per chunk
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1); exact at +-inf, |err| ~ 1e-7 relative to the f32 result
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+template <int H>
+struct FwdGeom {
+    static constexpr int NW = H / 16;          // waves per workgroup
+    static constexpr int KS = H / 4;           // MFMA k-steps over the hidden dimension
+    static constexpr int SEG = KS + 4;         // padded quarter-row (conflict-free ds_read_b128)
+    static constexpr int S = 4 * SEG + 8;      // padded row stride of the h tile
+    static constexpr size_t LDS = (2 * MT * S + TC * MT * 8 + (TC + 1) * MT) * sizeof(float);
+};
+// position of hidden unit u inside a padded h row
+template <int H>
+__device__ __forceinline__ int hpos(int u) { return (u / (H / 4)) * FwdGeom<H>::SEG + (u % (H / 4)); }
+
+template <int H, bool FUSE_X>
+__global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ keep, const float* __restrict__ h0,
+    const float* __restrict__ c0, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+    const float* __restrict__ b_ih, const float* __restrict__ b_hh, int N, int T, int I,
+    float* __restrict__ y, float* __restrict__ hn, float* __restrict__ cn, float* __restrict__ stash) {
+    using G = FwdGeom<H>;
+    constexpr int KS = G::KS, SEG = G::SEG, S = G::S;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* hbuf = smem;                        // [2][MT][S]
+    float* xbuf = hbuf + 2 * MT * S;           // [TC][MT][8]
+    float* kbuf = xbuf + TC * MT * 8;          // [TC+1][MT]
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int u = 16 * w + j;                  // hidden unit of this lane's accumulator column
+    const int n0 = blockIdx.x * MT;
+
+    // ---- this wave's slice of the weights, resident in VGPRs for the whole sequence
+    float wh[4][KS];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float* src = w_hh + (size_t)(q * H + u) * H + kq * KS;
+#pragma unroll
+        for (int s = 0; s < KS; s += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + s);
+            wh[q][s] = v.x; wh[q][s + 1] = v.y; wh[q][s + 2] = v.z; wh[q][s + 3] = v.w;
+        }
+    }
+    float wx[4][2], bias[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bias[q] = FUSE_X ? (b_ih[q * H + u] + b_hh[q * H + u]) : 0.f;   // non-fused: bias is in `pre`
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 2 * kq + s;
+            wx[q][s] = (FUSE_X && k < I) ? w_ih[(size_t)(q * H + u) * I + k] : 0.f;
+        }
+    }
+
+    // ---- incoming state of this lane's (env row r, unit u) pairs: rows e = 4*kq + r
+    float c_reg[4], hin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = 4 * kq + r;
+        const int n = min(n0 + e, N - 1);
+        const float k0 = keep ? keep[(size_t)n * T] : 1.f;
+        c_reg[r] = c0[(size_t)n * H + u] * k0;
+        hin[r] = h0[(size_t)n * H + u] * k0;
+        hbuf[e * S + hpos<H>(u)] = hin[r];
+    }
+    int cur = 0;
+    float h_last[4] = {0.f, 0.f, 0.f, 0.f};
+
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int tc = min(TC, T - t0);
+        // ---- stage x[n0..n0+15][t0..t0+tc) (zero-padded to 8 features) and keep[..][t0..t0+tc]
+        if (FUSE_X) {
+            for (int idx = threadIdx.x; idx < MT * tc * 8; idx += blockDim.x) {
+                const int e = idx / (tc * 8), rem = idx % (tc * 8), tt = rem >> 3, f = rem & 7;
+                const int n = min(n0 + e, N - 1);
+                xbuf[(tt * MT + e) * 8 + f] = (f < I) ? x[((size_t)n * T + t0 + tt) * I + f] : 0.f;
+            }
+        }
+        for (int idx = threadIdx.x; idx < MT * (tc + 1); idx += blockDim.x) {
+            const int e = idx / (tc + 1), tt = idx % (tc + 1);
+            const int n = min(n0 + e, N - 1);
+            kbuf[tt * MT + e] = (keep && t0 + tt < T) ? keep[(size_t)n * T + t0 + tt] : 1.f;
+        }
+        __syncthreads();
+
+        for (int tt = 0; tt < tc; ++tt) {
+            const int t = t0 + tt;
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (FUSE_X) {
+                    acc[q] = f32x4{bias[q], bias[q], bias[q], bias[q]};
+                } else {
+                    // pre-activations x W_ih^T + b from the time-batched GEMM (gates slot of the stash)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = min(n0 + 4 * kq + r, N - 1);
+                        acc[q][r] = stash[((size_t)n * T + t) * (6 * H) + q * H + u];
+                    }
+                }
+            }
+            if (FUSE_X) {
+                const float2 ax = *reinterpret_cast<const float2*>(&xbuf[(tt * MT + j) * 8 + 2 * kq]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax.x, wx[q][0], acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax.y, wx[q][1], acc[q], 0, 0, 0);
+                }
+            }
+            // recurrent part: A = h_{t-1}[env j][k], k permuted so that lane (j,kq) reads a contiguous run
+            const float* hrow = hbuf + cur * MT * S + j * S + kq * SEG;
+#pragma unroll
+            for (int s = 0; s < KS; s += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(hrow + s);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wh[q][s], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wh[q][s + 1], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wh[q][s + 2], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wh[q][s + 3], acc[q], 0, 0, 0);
+            }
+            // ---- gate pointwise, all in this lane's registers (C/D map: row = 4*kq + r, col = j)
+            float* hnext = hbuf + (cur ^ 1) * MT * S;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * kq + r;
+                const int n = n0 + e;
+                const float gi = sigmoidf_(acc[0][r]), gf = sigmoidf_(acc[1][r]);
+                const float gg = tanhf_(acc[2][r]), go = sigmoidf_(acc[3][r]);
+                const float cp = c_reg[r];
+                const float c = gf * cp + gi * gg;
+                const float h = go * tanhf_(c);
+                const float kn = kbuf[(tt + 1) * MT + e];     // keep of step t+1 (1 past the end)
+                if (n < N) {
+                    const size_t row = (size_t)n * T + t;
+                    y[row * H + u] = h;
+                    if (stash) {
+                        float* sp = stash + row * (6 * H);
+                        sp[u] = gi; sp[H + u] = gf; sp[2 * H + u] = gg; sp[3 * H + u] = go;
+                        sp[4 * H + u] = cp;
+                        sp[5 * H + u] = hin[r];
+                    }
+                }
+                h_last[r] = h;
+                if (t == T - 1) c_reg[r] = c;                 // cn is the unmasked final cell state
+                else c_reg[r] = c * kn;
+                hin[r] = h * kn;
+                hnext[e * S + hpos<H>(u)] = hin[r];
+            }
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * kq + r;
+        if (n < N) {
+            hn[(size_t)n * H + u] = h_last[r];
+            cn[(size_t)n * H + u] = c_reg[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- backward
+template <int H>
+struct BwdGeom {
+    static constexpr int S = 4 * H + 4;        // padded row of the dgates tile (conflict-free b128)
+    static constexpr size_t LDS = (2 * MT * S + TC * MT * 8 + (TC + 1) * MT) * sizeof(float);
+};
+
+// dy source: either dy[N][T][H] or (dheads[N][T][NH], w_head[NH][H]) with dy = dheads . w_head
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
+    const float* __restrict__ keep, const float* __restrict__ stash, const float* __restrict__ w_hh,
+    const float* __restrict__ dy, const float* __restrict__ dheads, const float* __restrict__ w_head, int NH,
+    const float* __restrict__ dhn, const float* __restrict__ dcn, int N, int T, float* __restrict__ dgates,
+    float* __restrict__ dh0, float* __restrict__ dc0) {
+    using G = BwdGeom<H>;
+    constexpr int S = G::S;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dgbuf = smem;                       // [2][MT][S]
+    float* dhbuf = dgbuf + 2 * MT * S;         // [TC][MT][8]   staged dheads
+    float* kbuf = dhbuf + TC * MT * 8;         // [TC+1][MT]    keep[t0 .. t0+tc]
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int u = 16 * w + j;
+    const int n0 = blockIdx.x * MT;
+
+    // W_hh^T slice: B[k][col j] = W_hh[k][u]; lane group kq covers gate kq's rows (k = kq*H + s)
+    float wt[H];
+#pragma unroll
+    for (int s = 0; s < H; ++s) wt[s] = w_hh[(size_t)(kq * H + s) * H + u];
+    float whd[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) whd[a] = (dheads && a < NH) ? w_head[(size_t)a * H + u] : 0.f;
+
+    float dh_rec[4], dc_next[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = min(n0 + 4 * kq + r, N - 1);
+        dh_rec[r] = dhn ? dhn[(size_t)n * H + u] : 0.f;
+        dc_next[r] = dcn ? dcn[(size_t)n * H + u] : 0.f;
+    }
+    int cur = 0;
+    const int nchunk = (T + TC - 1) / TC;
+    for (int ch = nchunk - 1; ch >= 0; --ch) {
+        const int t0 = ch * TC, tc = min(TC, T - t0);
+        if (dheads) {
+            for (int idx = threadIdx.x; idx < MT * tc * 8; idx += blockDim.x) {
+                const int e = idx / (tc * 8), rem = idx % (tc * 8), tt = rem >> 3, f = rem & 7;
+                const int n = min(n0 + e, N - 1);
+                dhbuf[(tt * MT + e) * 8 + f] = (f < NH) ? dheads[((size_t)n * T + t0 + tt) * NH + f] : 0.f;
+            }
+        }
+        for (int idx = threadIdx.x; idx < MT * tc; idx += blockDim.x) {
+            const int e = idx / tc, tt = idx % tc;
+            const int n = min(n0 + e, N - 1);
+            kbuf[tt * MT + e] = keep ? keep[(size_t)n * T + t0 + tt] : 1.f;
+        }
+        __syncthreads();
+        for (int tt = tc - 1; tt >= 0; --tt) {
+            const int t = t0 + tt;
+            float* dgw = dgbuf + cur * MT * S;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * kq + r;
+                const int n = min(n0 + e, N - 1);
+                const size_t row = (size_t)n * T + t;
+                const float* sp = stash + row * (6 * H);
+                const float gi = sp[u], gf = sp[H + u], gg = sp[2 * H + u], go = sp[3 * H + u], cp = sp[4 * H + u];
+                float dyv;
+                if (dheads) {
+                    const float* dr = &dhbuf[(tt * MT + e) * 8];
+                    dyv = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 8; ++a) dyv += dr[a] * whd[a];
+                } else {
+                    dyv = dy[row * H + u];
+                }
+                const float dh = dyv + dh_rec[r];
+                const float c = gf * cp + gi * gg;
+                const float tch = tanhf_(c);
+                const float dc = dh * go * (1.0f - tch * tch) + dc_next[r];
+                const float dgi = dc * gg * gi * (1.0f - gi);
+                const float dgf = dc * cp * gf * (1.0f - gf);
+                const float dgg = dc * gi * (1.0f - gg * gg);
+                const float dgo = dh * tch * go * (1.0f - go);
+                const float kp = kbuf[tt * MT + e];            // keep[t]: the incoming state was masked by it
+                dc_next[r] = dc * gf * kp;
+                dgw[e * S + 0 * H + u] = dgi;
+                dgw[e * S + 1 * H + u] = dgf;
+                dgw[e * S + 2 * H + u] = dgg;
+                dgw[e * S + 3 * H + u] = dgo;
+                if (n0 + e < N) {
+                    float* gp = dgates + row * (4 * H);
+                    gp[u] = dgi; gp[H + u] = dgf; gp[2 * H + u] = dgg; gp[3 * H + u] = dgo;
+                }
+            }
+            __syncthreads();
+            // dh_{t-1}[env][u] = sum_k dgates[env][k] W_hh[k][u]; four independent accumulators
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            const float* drow = dgw + j * S + kq * H;
+#pragma unroll
+            for (int s = 0; s < H; s += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(drow + s);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wt[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wt[s + 1], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wt[s + 2], a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wt[s + 3], a3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float kp = kbuf[tt * MT + 4 * kq + r];
+                dh_rec[r] = ((a0[r] + a1[r]) + (a2[r] + a3[r])) * kp;
+            }
+            cur ^= 1;
+        }
+        __syncthreads();     // kbuf / dhbuf are restaged by the next chunk
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * kq + r;
+        if (n < N) {
+            if (dh0) dh0[(size_t)n * H + u] = dh_rec[r];
+            if (dc0) dc0[(size_t)n * H + u] = dc_next[r];
+        }
+    }
+}
+
+template <int H>
+static int launch_fwd(bool fuse, const float* x, const float* keep, const float* h0, const float* c0,
+                      const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int N, int T, int I,
+                      float* y, float* hn, float* cn, float* stash, hipStream_t st) {
+    const dim3 grid((N + MT - 1) / MT), block(H * 4);
+    const size_t lds = FwdGeom<H>::LDS;
+    if (fuse)
+        hipLaunchKernelGGL((lstm_fwd_kernel<H, true>), grid, block, lds, st, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N,
+                           T, I, y, hn, cn, stash);
+    else
+        hipLaunchKernelGGL((lstm_fwd_kernel<H, false>), grid, block, lds, st, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh,
+                           N, T, I, y, hn, cn, stash);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int H>
+static int launch_bwd(const float* keep, const float* stash, const float* w_hh, const float* dy, const float* dheads,
+                      const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
+                      float* dh0, float* dc0, hipStream_t st) {
+    const dim3 grid((N + MT - 1) / MT), block(H * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdGeom<H>::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_kernel<H>), grid, block, BwdGeom<H>::LDS, st, keep, stash, w_hh, dy, dheads, w_head, NH,
+                       dhn, dcn, N, T, dgates, dh0, dc0);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// b[i] = a0[i] + a1[i]
+__global__ void add2_kernel(const float* a0, const float* a1, float* b, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) b[i] = a0[i] + a1[i];
+}
+
+int lstm_bwd_core(uav_ctx* ctx, const float* x, const float* keep, const float* stash, const float* w_ih,
+                  const float* w_hh, const float* dy, const float* dheads, const float* w_head, int NH,
+                  const float* dhn, const float* dcn, int N, int T, int I, int H, float* dgates, float* dx,
+                  float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, hipStream_t st) {
+    int rc;
+    switch (H) {
+        case 64: rc = launch_bwd<64>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st); break;
+        case 128: rc = launch_bwd<128>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st); break;
+        default: uav_set_error("uav_lstm_bwd: H=%d unsupported (64, 128)", H); return 2;
+    }
+    if (rc) return rc;
+    const int64_t NT = (int64_t)N * T;
+    // weight gradients: time-batched GEMMs over all N*T rows (split-K, deterministic)
+    // dW_hh[4H][H] = dG^T Hprev ; Hprev = stash[..][5H:6H]
+    if ((rc = gemm_f32(ctx, 4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H, nullptr, 0, st))) return rc;
+    if ((rc = gemm_f32(ctx, 4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I, nullptr, 0, st))) return rc;
+    // column sums reuse the tail of the workspace
+    const size_t red_floats = (size_t)1024 * 4 * H;
+    UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_bwd: workspace too small");
+    float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
+    if ((rc = colsum(ctx, dgates, NT, 4 * H, db, red, st))) return rc;
+    if (dx) {
+        if ((rc = gemm_f32(ctx, NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I, nullptr, 0, st))) return rc;
+    }
+    return 0;
+}
+
+extern "C" {
+
+int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* c0, const float* w_ih,
+                 const float* w_hh, const float* b_ih, const float* b_hh, int N, int T, int I, int H, float* y,
+                 float* hn, float* cn, float* stash, uav_stream stream) {
+    UAV_REQUIRE(ctx && x && h0 && c0 && w_ih && w_hh && b_ih && b_hh && y && hn && cn, "uav_lstm_fwd: NULL argument");
+    UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_fwd: N=%d T=%d I=%d", N, T, I);
+    hipStream_t st = as_stream(stream);
+    const bool fuse = I <= 8;
+    if (!fuse) {
+        // time-batched input projection into the gates slot of the stash: pre = x W_ih^T + (b_ih + b_hh)
+        UAV_REQUIRE(stash, "uav_lstm_fwd: stash is required when I > 8");
+        float* bsum = (float*)ctx->ws;   // 4H floats at the head of the workspace... kept clear of GEMM slabs below
+        uav_ctx sub = *ctx;
+        sub.ws = (char*)ctx->ws + 65536;
+        sub.ws_bytes = ctx->ws_bytes - 65536;
+        hipLaunchKernelGGL(add2_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, b_ih, b_hh, bsum, 4 * H);
+        int rc = gemm_f32(&sub, (int64_t)N * T, 4 * H, I, x, I, 1, w_ih, 1, I, stash, 6 * H, bsum, 0, st);
+        if (rc) return rc;
+    }
+    switch (H) {
+        case 64: return launch_fwd<64>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, st);
+        case 128: return launch_fwd<128>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, st);
+    }
+    UAV_REQUIRE(false, "uav_lstm_fwd: H=%d unsupported (64, 128)", H);
+}
+
+int uav_lstm_bwd(uav_ctx* ctx, const float* x, const float* keep, const float* stash, const float* w_ih,
+                 const float* w_hh, const float* dy, const float* dheads, const float* w_head, int n_heads,
+                 const float* dhn, const float* dcn, int N, int T, int I, int H, float* dgates, float* dx,
+                 float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, uav_stream stream) {
+    UAV_REQUIRE(ctx && x && stash && w_ih && w_hh && dgates && dw_ih && dw_hh && db, "uav_lstm_bwd: NULL argument");
+    UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd: give exactly one of dy / dheads");
+    UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd: dheads needs w_head and 1..8 heads");
+    UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_bwd: N=%d T=%d I=%d", N, T, I);
+    return lstm_bwd_core(ctx, x, keep, stash, w_ih, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, I, H, dgates,
+                         dx, dw_ih, dw_hh, db, dh0, dc0, as_stream(stream));
+}
+
+}  // extern "C"

@@ -233,3 +233,46 @@ def env_peek(state, n_env, pos=None, source=None, steps=None, episode=None):
     check(lib().uav_env_peek(_h(state), _p(state, U8, name="env state"), n_env, _p(pos, F32, (n_env, 2), "pos"),
                              _p(source, F64, (n_env, 2), "source"), _p(steps, I32, (n_env,), "steps"),
                              _p(episode, I32, (n_env,), "episode"), _stream()), "uav_env_peek")
+
+
+# ----------------------------------------------------------------------------- L1
+def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=True, y=None):
+    """One nn.LSTM layer over x[N,T,I] (env-major).  Returns y[N,T,H], hn, cn, stash[N,T,6H]."""
+    N, T, I = x.shape
+    H = w_hh.shape[1]
+    dev = x.device
+    y = torch.empty(N, T, H, dtype=F32, device=dev) if y is None else y
+    hn = torch.empty(N, H, dtype=F32, device=dev)
+    cn = torch.empty(N, H, dtype=F32, device=dev)
+    if stash is None and (want_stash or I > 8):
+        stash = torch.empty(N, T, 6 * H, dtype=F32, device=dev)
+    check(lib().uav_lstm_fwd(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"),
+                             _p(h0, F32, (N, H), "h0"), _p(c0, F32, (N, H), "c0"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                             _p(w_hh, F32, (4 * H, H), "w_hh"), _p(b_ih, F32, (4 * H,), "b_ih"),
+                             _p(b_hh, F32, (4 * H,), "b_hh"), N, T, I, H, _p(y, F32, (N, T, H), "y"), _p(hn), _p(cn),
+                             _p(stash, F32, (N, T, 6 * H), "stash"), _stream()), "uav_lstm_fwd")
+    return y, hn, cn, stash
+
+
+def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
+             dgates=None, dw_ih=None, dw_hh=None, db=None, want_dstate=True):
+    N, T, I = x.shape
+    H = w_hh.shape[1]
+    dev = x.device
+    dgates = torch.empty(N, T, 4 * H, dtype=F32, device=dev) if dgates is None else dgates
+    dx = torch.empty(N, T, I, dtype=F32, device=dev) if need_dx else None
+    dw_ih = torch.empty(4 * H, I, dtype=F32, device=dev) if dw_ih is None else dw_ih
+    dw_hh = torch.empty(4 * H, H, dtype=F32, device=dev) if dw_hh is None else dw_hh
+    db = torch.empty(4 * H, dtype=F32, device=dev) if db is None else db
+    dh0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
+    dc0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
+    nh = 0 if dheads is None else dheads.shape[-1]
+    check(lib().uav_lstm_bwd(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"),
+                             _p(stash, F32, (N, T, 6 * H), "stash"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                             _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
+                             _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh,
+                             _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, I, H,
+                             _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dx), _p(dw_ih, F32, (4 * H, I), "dw_ih"),
+                             _p(dw_hh, F32, (4 * H, H), "dw_hh"), _p(db, F32, (4 * H,), "db"), _p(dh0), _p(dc0),
+                             _stream()), "uav_lstm_bwd")
+    return {"dx": dx, "dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dh0": dh0, "dc0": dc0, "dgates": dgates}
