@@ -99,6 +99,9 @@ int uav_gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, 
                  int64_t sa_k, const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc,
                  const float* bias, int accumulate, uav_stream stream);
 
+/* out[c] = sum over rows of x[r][c]  (bias gradients; deterministic two-stage reduction).  cols <= 1024. */
+int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out, uav_stream stream);
+
 /* ---- M2: the reference's MLP policy (model.py:17-53), forward and backward.
  * params: flat f32[36230-like] in the order W1[h1][in] b1 g1 be1 W2[h2][h1] b2 g2 be2
  * Whead[n_act+1][h2] bhead[n_act+1] (actor rows then the critic row).

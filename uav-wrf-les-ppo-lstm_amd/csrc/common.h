@@ -11,6 +11,7 @@ struct uav_ctx {
     int num_cu;
     void* ws;          // scratch for two-stage reductions / split-K slabs
     size_t ws_bytes;
+    double* pow075;    // device table pow(i, 0.75), i = 0..5000 (env_core.h)
 };
 
 void uav_set_error(const char* fmt, ...);

@@ -3,6 +3,7 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+int env_init_tables(uav_ctx* ctx);
 
 void uav_set_error(const char* fmt, ...) {
     va_list ap;
@@ -28,9 +29,15 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     c->ws_bytes = ws_bytes;
+    c->pow075 = nullptr;
     if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
         delete c;
         uav_set_error("uav_create: hipMalloc(%zu) failed", ws_bytes);
+        return 1;
+    }
+    if (env_init_tables(c) != 0) {
+        (void)hipFree(c->ws);
+        delete c;
         return 1;
     }
     *out = c;
@@ -40,6 +47,7 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
 void uav_destroy(uav_ctx* ctx) {
     if (!ctx) return;
     (void)hipFree(ctx->ws);
+    (void)hipFree(ctx->pow075);
     delete ctx;
 }
 

@@ -1,9 +1,20 @@
 // env.hip -- E1-E5 as stand-alone kernels: reset, one vectorised step with auto-reset, peek.
 // One thread per environment; arithmetic in env_core.h.  (The fused rollout kernel in
 // rollout.hip runs the same core inside its time loop.)
+#include <math.h>
+#include <vector>
 #include "env_core.h"
 
-int env_params_from_cfg(const uav_env_cfg* cfg, int n_env, EnvParams& P) {
+// called once from uav_create: the table is the host libm's pow, i.e. the reference's own values
+int env_init_tables(uav_ctx* ctx) {
+    std::vector<double> t(POW_TABLE_N);
+    for (int i = 0; i < POW_TABLE_N; ++i) t[i] = pow((double)i, 0.75);
+    UAV_CHECK_HIP(hipMalloc(&ctx->pow075, sizeof(double) * POW_TABLE_N));
+    UAV_CHECK_HIP(hipMemcpy(ctx->pow075, t.data(), sizeof(double) * POW_TABLE_N, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, EnvParams& P) {
     UAV_REQUIRE(cfg, "env: cfg is NULL");
     UAV_REQUIRE(cfg->variant >= UAV_ENV_V20 && cfg->variant <= UAV_ENV_V11, "env: variant %d", cfg->variant);
     UAV_REQUIRE(cfg->field_mode == UAV_FIELD_PROCEDURAL || cfg->field_mode == UAV_FIELD_MATERIALISED,
@@ -26,6 +37,7 @@ int env_params_from_cfg(const uav_env_cfg* cfg, int n_env, EnvParams& P) {
     P.seed = cfg->seed;
     P.bank = cfg->bank;
     P.bank_src = cfg->bank_src;
+    P.pow075 = ctx->pow075;
     return 0;
 }
 
@@ -91,7 +103,7 @@ size_t uav_env_state_bytes(int n_env) { return n_env > 0 ? env_blob_bytes(n_env)
 int uav_env_reset(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg, float* obs_out, uav_stream stream) {
     UAV_REQUIRE(ctx && state && obs_out && n_env > 0, "uav_env_reset: bad argument");
     EnvParams P;
-    int rc = env_params_from_cfg(cfg, n_env, P);
+    int rc = env_params_from_cfg(ctx, cfg, n_env, P);
     if (rc) return rc;
     hipLaunchKernelGGL(env_reset_kernel, dim3((n_env + 255) / 256), dim3(256), 0, as_stream(stream), P,
                        env_blob_view(state, n_env), n_env, obs_out);
@@ -104,7 +116,7 @@ int uav_env_step(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg, c
                  uav_stream stream) {
     UAV_REQUIRE(ctx && state && act && obs_out && rew && done && flags && n_env > 0, "uav_env_step: bad argument");
     EnvParams P;
-    int rc = env_params_from_cfg(cfg, n_env, P);
+    int rc = env_params_from_cfg(ctx, cfg, n_env, P);
     if (rc) return rc;
     hipLaunchKernelGGL(env_step_kernel, dim3((n_env + 255) / 256), dim3(256), 0, as_stream(stream), P,
                        env_blob_view(state, n_env), n_env, act, noise, obs_out, rew, done, flags, info, term_obs, rew64);

@@ -22,6 +22,7 @@ struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived c
     uint64_t seed;
     const double* bank;       // [F][GRID][GRID][2]
     const double* bank_src;   // [F][2]
+    const double* pow075;     // [POW_TABLE_N] host-libm pow(i, 0.75)
 };
 
 struct EnvState {             // registers of one env
@@ -66,14 +67,20 @@ __device__ __forceinline__ void env_store(const EnvBlob& b, int i, const EnvStat
 
 __device__ __forceinline__ int clipi(int v) { return v < 0 ? 0 : (v > GRID - 1 ? GRID - 1 : v); }
 
-// two standard normals from one Philox block (Box-Muller, f64)
+// pow(vc, 0.75) for vc = 0..5000 (environment.py:133), filled by the HOST's libm at uav_create so it
+// is the very double the reference's `visit_count**0.75` produces; also keeps f64 pow out of the kernels.
+constexpr int POW_TABLE_N = 5001;      // table pointer travels in EnvParams (owned by the uav_ctx)
+
+// two standard normals from one Philox block (Box-Muller).  Counter-RNG noise is validated
+// statistically only (parity runs inject noise), so the transcendental part is f32 fast-math:
+// it keeps the persistent rollout kernel's register footprint small.
 __device__ __forceinline__ void normal2(const Philox4& r, double& z0, double& z1) {
-    const double u1 = u01_open_f64(r.x, r.y), u2 = u01_f64(r.z, r.w);
-    const double rad = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincos(6.283185307179586 * u2, &s, &c);
-    z0 = rad * c;
-    z1 = rad * s;
+    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0,1]
+    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);               // [0,1)
+    const float rad = sqrtf(-2.0f * __logf(u1));
+    const float ang = 6.2831853071795865f * u2;
+    z0 = (double)(rad * __cosf(ang));
+    z1 = (double)(rad * __sinf(ang));
 }
 
 // E3: concentration and 'tke' at integer cell (x, y)
@@ -86,14 +93,16 @@ __device__ __forceinline__ void field_at(const EnvParams& P, int env_global, con
         tke = v.y;
         return;
     }
-    // procedural: |N(0,1)| and U[0,1) of this (env, episode, cell) from the counter RNG
+    // procedural: |N(0,1)| and U[0,1) of this (env, episode, cell) from the counter RNG; f32 fast-math
+    // transcendentals (statistical mode), the combination itself in f64 like the reference
     const Philox4 r = philox4x32_10(P.seed, (uint32_t)(x * GRID + y), (uint32_t)env_global, (uint32_t)s.episode, RNG_FIELD);
-    const double u1 = u01_open_f64(r.x, r.y);
-    const double g = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * ((double)r.z * (1.0 / 4294967296.0)));
+    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float g = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795865f * ((float)(r.y >> 8) * (1.0f / 16777216.0f)));
     const double u = (double)r.w * (1.0 / 4294967296.0);
-    tke = 3.0 * (fabs(g) + 0.3 * sin(0.05 * x) * cos(0.07 * y) + 0.2 * u);          // environment.py:56-60
-    const double dx = x - s.sx, dy = y - s.sy;
-    const double base = 100.0 * exp(-(dx * dx + dy * dy) / P.two_sigma2);            // :53-54
+    const float wave = 0.3f * __sinf(0.05f * (float)x) * __cosf(0.07f * (float)y);
+    tke = 3.0 * ((double)fabsf(g) + (double)wave + 0.2 * u);                        // environment.py:56-60
+    const float dx = (float)x - (float)s.sx, dy = (float)y - (float)s.sy;
+    const double base = 100.0 * (double)__expf(-(dx * dx + dy * dy) / (float)P.two_sigma2);   // :53-54
     const double c = base + tke;
     conc = c < 0.0 ? 0.0 : (c > 100.0 ? 100.0 : c);                                  // :61
 }
@@ -176,7 +185,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
     vis[vi] = (unsigned short)vc;                                     // :129-130
 
     env_obs(P, s, vis, out.obs);                                      // :133,136 (f32-position cell)
-    const double den = pow((double)vc, 0.75) + 1.0;
+    const double den = P.pow075[vc < POW_TABLE_N ? vc : POW_TABLE_N - 1] + 1.0;
     const float conc_r = 2.0f * out.obs[2];                           // f32, :140
     const float tke_p = 0.4f * out.obs[3];                            // f32, :143
     double explore, total;

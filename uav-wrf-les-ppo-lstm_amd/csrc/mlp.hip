@@ -209,6 +209,12 @@ static int ln_bwd_any(uav_ctx* ctx, int C, float* d, const float* xhat, const fl
 
 extern "C" {
 
+int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out, uav_stream stream) {
+    UAV_REQUIRE(ctx && x && out && rows > 0 && cols > 0 && cols <= 1024, "uav_colsum: bad argument");
+    UAV_REQUIRE(ctx->ws_bytes >= (size_t)1024 * 1024 * sizeof(float), "uav_colsum: workspace too small");
+    return colsum(ctx, x, rows, cols, out, (float*)ctx->ws, as_stream(stream));
+}
+
 int64_t uav_mlp_param_count(int in_dim, int h1, int h2, int n_act) { return mlp_layout(in_dim, h1, h2, n_act).total; }
 int64_t uav_mlp_stash_floats(int h1, int h2) { return 2 * (int64_t)h1 + 2 * (int64_t)h2 + 2; }
 

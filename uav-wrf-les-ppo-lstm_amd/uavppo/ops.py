@@ -276,3 +276,28 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=
                              _p(dw_hh, F32, (4 * H, H), "dw_hh"), _p(db, F32, (4 * H,), "db"), _p(dh0), _p(dc0),
                              _stream()), "uav_lstm_bwd")
     return {"dx": dx, "dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dh0": dh0, "dc0": dc0, "dgates": dgates}
+
+
+def colsum(x, out=None):
+    rows, cols = x.shape
+    out = torch.empty(cols, dtype=F32, device=x.device) if out is None else out
+    check(lib().uav_colsum(_h(x), _p(x, F32, (rows, cols), "x"), rows, cols, _p(out, F32, (cols,), "out"), _stream()),
+          "uav_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------- R1
+def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h, c, bufs, last_val=None,
+                 forced_act=None, noise=None, nan_count=None):
+    """Fused persistent rollout (csrc/rollout.hip).  bufs: dict obs[N,T,6] act rew val logp done flags keep."""
+    N, T = n_env, horizon
+    check(lib().uav_rollout(_h(cur_obs), _p(env_state, U8, name="env state"), N, C.byref(cfg), 1,
+                            _p(params, F32, name="params"), int(hidden), T, int(it),
+                            _p(cur_obs, F32, (N, 6), "cur_obs"), _p(h, F32, (N, hidden), "h"), _p(c, F32, (N, hidden), "c"),
+                            _p(bufs["obs"], F32, (N, T, 6), "obs"), _p(bufs["act"], I32, (N, T), "act"),
+                            _p(bufs["rew"], F32, (N, T), "rew"), _p(bufs["val"], F32, (N, T), "val"),
+                            _p(bufs["logp"], F32, (N, T), "logp"), _p(bufs["done"], F32, (N, T), "done"),
+                            _p(bufs["flags"], U8, (N, T), "flags"), _p(bufs["keep"], F32, (N, T), "keep"),
+                            _p(last_val, F32, (N,), "last_val"), _p(forced_act, I32, (N, T), "forced_act"),
+                            _p(noise, F64, (N, T, 2), "noise"), _p(nan_count, I32, (1,), "nan_count"), _stream()),
+          "uav_rollout")

@@ -1,0 +1,196 @@
+"""Actor-critic policies whose parameters live in ONE flat f32 device buffer (what the HIP
+kernels, the fused clip+Adam and the RCCL gradient all-reduce operate on) while exposing the
+reference's / torch's parameter names as views.
+
+  MLPActorCritic   the reference's network, PPOV2.0/model.py:17-53 (state_dict keys feature.{0,1,3,4}.*,
+                   actor.*, critic.*; orthogonal init gains sqrt(2) / 0.01 / 1.0, zero biases)
+  LSTMActorCritic  the LSTM actor-critic BASELINE.json specifies: nn.LSTM(obs, H, L) semantics
+                   (PPOV2.0/model.py:206-212) -> actor Linear(H, A) | critic Linear(H, 1)
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class _FlatPolicy:
+    """flat parameter buffer + named views (no copies)."""
+
+    def _alloc(self, layout, device):
+        self.layout = layout                       # list of (name, shape)
+        total = sum(int(np.prod(s)) for _, s in layout)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.flat)
+        self.views, self.grad_views = {}, {}
+        o = 0
+        for name, shape in layout:
+            n = int(np.prod(shape))
+            self.views[name] = self.flat[o:o + n].view(shape)
+            self.grad_views[name] = self.grad[o:o + n].view(shape)
+            o += n
+
+    @property
+    def device(self):
+        return self.flat.device
+
+    def num_params(self):
+        return self.flat.numel()
+
+
+def _orthogonal(shape, gain, gen):
+    w = torch.empty(shape)
+    torch.nn.init.orthogonal_(w, gain=gain, generator=gen)
+    return w
+
+
+class MLPActorCritic(_FlatPolicy):
+    KEYS = ("feature.0.weight", "feature.0.bias", "feature.1.weight", "feature.1.bias",
+            "feature.3.weight", "feature.3.bias", "feature.4.weight", "feature.4.bias",
+            "actor.weight", "actor.bias", "critic.weight", "critic.bias")
+
+    def __init__(self, input_size=6, output_size=5, h1=256, h2=128, device="cuda", seed=None):
+        self.in_dim, self.n_act, self.h1, self.h2 = input_size, output_size, h1, h2
+        A = output_size
+        # flat order of csrc/mlp.hip (heads contiguous: actor rows then the critic row)
+        self._alloc([("feature.0.weight", (h1, input_size)), ("feature.0.bias", (h1,)),
+                     ("feature.1.weight", (h1,)), ("feature.1.bias", (h1,)),
+                     ("feature.3.weight", (h2, h1)), ("feature.3.bias", (h2,)),
+                     ("feature.4.weight", (h2,)), ("feature.4.bias", (h2,)),
+                     ("head.weight", (A + 1, h2)), ("head.bias", (A + 1,))], device)
+        assert self.flat.numel() == ops.mlp_param_count(input_size, h1, h2, A)
+        gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        sd = {  # model.py:29-40
+            "feature.0.weight": _orthogonal((h1, input_size), math.sqrt(2), gen), "feature.0.bias": torch.zeros(h1),
+            "feature.1.weight": torch.ones(h1), "feature.1.bias": torch.zeros(h1),
+            "feature.3.weight": _orthogonal((h2, h1), math.sqrt(2), gen), "feature.3.bias": torch.zeros(h2),
+            "feature.4.weight": torch.ones(h2), "feature.4.bias": torch.zeros(h2),
+            "actor.weight": _orthogonal((A, h2), 0.01, gen), "actor.bias": torch.zeros(A),
+            "critic.weight": _orthogonal((1, h2), 1.0, gen), "critic.bias": torch.zeros(1),
+        }
+        self.load_state_dict(sd)
+        self._stash = None
+
+    # -- reference-compatible (de)serialisation -------------------------------------------------
+    def _named(self, src):
+        A = self.n_act
+        out = {k: src[k] for k in self.KEYS[:8]}
+        out["actor.weight"], out["critic.weight"] = src["head.weight"][:A], src["head.weight"][A:]
+        out["actor.bias"], out["critic.bias"] = src["head.bias"][:A], src["head.bias"][A:]
+        return out
+
+    def named_views(self):
+        return self._named(self.views)
+
+    def named_grads(self):
+        return self._named(self.grad_views)
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.named_views().items()}
+
+    def load_state_dict(self, sd):
+        nv = self.named_views()
+        for k in self.KEYS:
+            nv[k].copy_(torch.as_tensor(sd[k], dtype=torch.float32).reshape(nv[k].shape))
+
+    # -- compute ----------------------------------------------------------------------------------
+    def heads(self, x, stash=None):
+        """x [B, in] -> heads [B, A+1] (logits | value); keeps the stash for backward()."""
+        heads, self._stash = ops.mlp_fwd(self.flat, x, self.in_dim, self.h1, self.h2, self.n_act, stash=stash)
+        self._x = x
+        return heads
+
+    def backward(self, dheads):
+        """d(loss)/d(heads) -> self.grad (flat, overwritten).  Consumes the stash."""
+        ops.mlp_bwd(self.flat, self._x, self._stash, dheads, self.in_dim, self.h1, self.h2, self.n_act, grad=self.grad)
+        self._stash = None
+        return self.grad
+
+
+class LSTMActorCritic(_FlatPolicy):
+    def __init__(self, obs_dim=6, hidden=128, num_layers=1, n_act=5, device="cuda", seed=0):
+        self.obs_dim, self.hidden, self.num_layers, self.n_act = obs_dim, hidden, num_layers, n_act
+        H, A = hidden, n_act
+        layout = []
+        for l in range(num_layers):
+            i = obs_dim if l == 0 else H
+            layout += [(f"lstm.weight_ih_l{l}", (4 * H, i)), (f"lstm.weight_hh_l{l}", (4 * H, H)),
+                       (f"lstm.bias_ih_l{l}", (4 * H,)), (f"lstm.bias_hh_l{l}", (4 * H,))]
+        layout += [("head.weight", (A + 1, H)), ("head.bias", (A + 1,))]
+        self._alloc(layout, device)
+        gen = torch.Generator().manual_seed(seed)
+        k = 1.0 / math.sqrt(H)
+        for name, shape in layout[:-2]:            # nn.LSTM default init U(-1/sqrt(H), 1/sqrt(H))
+            self.views[name].copy_((torch.rand(shape, generator=gen) * 2 - 1) * k)
+        self.views["head.weight"][:A].copy_(_orthogonal((A, H), 0.01, gen))       # heads as model.py:34-40
+        self.views["head.weight"][A:].copy_(_orthogonal((1, H), 1.0, gen))
+        self.views["head.bias"].zero_()
+        self._saved = None
+
+    def _named(self, src):
+        A = self.n_act
+        out = {k: v for k, v in src.items() if k.startswith("lstm.")}
+        out["actor.weight"], out["critic.weight"] = src["head.weight"][:A], src["head.weight"][A:]
+        out["actor.bias"], out["critic.bias"] = src["head.bias"][:A], src["head.bias"][A:]
+        return out
+
+    def named_views(self):
+        return self._named(self.views)
+
+    def named_grads(self):
+        return self._named(self.grad_views)
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self.named_views().items()}
+
+    def load_state_dict(self, sd):
+        nv = self.named_views()
+        for k, v in nv.items():
+            v.copy_(torch.as_tensor(sd[k], dtype=torch.float32).reshape(v.shape))
+
+    def zero_state(self, n):
+        z = torch.zeros(self.num_layers, n, self.hidden, dtype=torch.float32, device=self.device)
+        return z, z.clone()
+
+    def heads(self, obs, keep, h0, c0, work=None):
+        """obs [N,T,I], keep [N,T] or None, h0,c0 [L,N,H] -> heads [N*T, A+1].  Saves what
+        backward() needs.  `work` may hold preallocated 'stash{l}', 'y{l}' tensors."""
+        N, T, _ = obs.shape
+        v = self.views
+        x = obs
+        saved = []
+        work = work or {}
+        for l in range(self.num_layers):
+            y, hn, cn, stash = ops.lstm_fwd(x, keep, h0[l], c0[l], v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
+                                            v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"],
+                                            stash=work.get(f"stash{l}"), y=work.get(f"y{l}"))
+            saved.append((x, stash))
+            x = y
+        self._saved = (saved, keep, x)
+        return ops.gemm(x.view(N * T, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"],
+                        out=work.get("heads"))
+
+    def backward(self, dheads, work=None):
+        """dheads [N*T, A+1] -> self.grad (flat, overwritten)."""
+        saved, keep, y_last = self._saved
+        N, T, H = y_last.shape
+        v, g = self.views, self.grad_views
+        work = work or {}
+        ops.gemm(dheads, y_last.view(N * T, H), trans_a=True, out=g["head.weight"])
+        ops.colsum(dheads, out=g["head.bias"])
+        dy = None
+        for l in reversed(range(self.num_layers)):
+            x, stash = saved[l]
+            top = (l == self.num_layers - 1)
+            r = ops.lstm_bwd(x, keep, stash, v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
+                             dy=None if top else dy,
+                             dheads=dheads.view(N, T, -1) if top else None, w_head=v["head.weight"] if top else None,
+                             need_dx=(l > 0), dgates=work.get("dgates"), dw_ih=g[f"lstm.weight_ih_l{l}"],
+                             dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"], want_dstate=False)
+            g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
+            dy = r["dx"]
+        self._saved = None
+        return self.grad

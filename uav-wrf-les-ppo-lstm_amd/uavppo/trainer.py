@@ -1,0 +1,220 @@
+"""VecPPOTrainer: the PPOV2.0/2.1 training loop (train_ppo2.0.py:110-261) for N vectorised
+environments -- rollout collection, GAE, whole-buffer advantage normalisation, EPOCHS passes
+of the clipped-PPO update -- every arithmetic step a HIP kernel behind the C ABI.
+
+One process per GPU: environments are sharded by contiguous global index, parameters are
+replicated, and per optimiser step ONE all-reduce (RCCL over xGMI) of the flat gradient buffer
+keeps them identical; 3 doubles are all-reduced for the reference's whole-buffer advantage
+statistics (train_ppo2.0.py:35-39).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .curriculum import Curriculum
+from .policy import LSTMActorCritic, MLPActorCritic
+
+# reference hyper-parameters, PPOV2.0/config.py:12-18 and train_ppo2.0.py:87,114
+DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, ent_beta=0.01, lr=3e-5, epochs=5, max_grad_norm=0.5)
+
+
+class VecPPOTrainer:
+    def __init__(self, num_envs, horizon, policy="lstm", hidden=128, layers=1, variant="v2.0", device="cuda",
+                 seed=1234, gae_mode="reference_exact", num_minibatches=1, bank=None, bank_sources=None,
+                 rank=0, world_size=1, use_curriculum=True, **hp):
+        self.hp = dict(DEFAULTS)
+        self.hp.update(hp)
+        self.N, self.T = int(num_envs), int(horizon)
+        self.rank, self.world = int(rank), int(world_size)
+        self.device = torch.device(device)
+        self.variant, self.seed = variant, int(seed)
+        self.gae_mode = gae_mode
+        self.num_minibatches = int(num_minibatches)
+        if self.N % self.num_minibatches:
+            raise ValueError("num_envs must be divisible by num_minibatches (minibatches are whole env sequences)")
+        self.kind = policy
+        if policy == "lstm":
+            self.policy = LSTMActorCritic(6, hidden, layers, 5, self.device, seed=self.seed)
+        elif policy == "mlp":
+            self.policy = MLPActorCritic(6, 5, device=self.device, seed=self.seed)
+        else:
+            raise ValueError(policy)
+        N, T, d = self.N, self.T, self.device
+        f32 = dict(dtype=torch.float32, device=d)
+        self.buf = {"obs": torch.zeros(N, T, 6, **f32), "act": torch.zeros(N, T, dtype=torch.int32, device=d),
+                    "rew": torch.zeros(N, T, **f32), "val": torch.zeros(N, T, **f32), "logp": torch.zeros(N, T, **f32),
+                    "done": torch.zeros(N, T, **f32), "flags": torch.zeros(N, T, dtype=torch.uint8, device=d),
+                    "keep": torch.ones(N, T, **f32)}
+        self.adv = torch.zeros(N, T, **f32)
+        self.adv_n = torch.zeros(N, T, **f32)
+        self.ret = torch.zeros(N, T, **f32)
+        self.last_val = torch.zeros(N, **f32) if gae_mode == "standard" else None
+        self.stats3 = torch.zeros(3, dtype=torch.float64, device=d)
+        self.loss_sums = torch.zeros(4, dtype=torch.float64, device=d)
+        self.gnorm = torch.zeros(1, **f32)
+        self.nan_count = torch.zeros(1, dtype=torch.int32, device=d)
+        P = self.policy.num_params()
+        self.exp_avg = torch.zeros(P, **f32)
+        self.exp_avg_sq = torch.zeros(P, **f32)
+        self.opt_step = 0
+        self.iteration = 0
+        self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
+        self.log = []
+        # environments of this rank: global indices [rank*N, (rank+1)*N)
+        self.env_state = torch.zeros(ops.env_state_bytes(N), dtype=torch.uint8, device=d)
+        self.cur_obs = torch.zeros(N, 6, **f32)
+        self.bank = None if bank is None else torch.as_tensor(bank, dtype=torch.float64).to(d).contiguous()
+        self.bank_sources = None if bank_sources is None else torch.as_tensor(bank_sources, dtype=torch.float64).to(d).contiguous()
+        self.curriculum = Curriculum() if use_curriculum else None
+        self.radius, self.bonus = 50.0, 0.6
+        if policy == "lstm":
+            L, H = layers, hidden
+            self.h = torch.zeros(L, N, H, **f32)
+            self.c = torch.zeros(L, N, H, **f32)
+            self.h0 = torch.zeros(L, N, H, **f32)     # state at the start of the current rollout (for BPTT)
+            self.c0 = torch.zeros(L, N, H, **f32)
+            nb = N // self.num_minibatches
+            self.work = {"dgates": torch.empty(nb, T, 4 * H, **f32), "heads": torch.empty(nb * T, 6, **f32)}
+            for l in range(L):
+                self.work[f"stash{l}"] = torch.empty(nb, T, 6 * H, **f32)
+                self.work[f"y{l}"] = torch.empty(nb, T, H, **f32)
+        else:
+            nb = N // self.num_minibatches
+            self.work = {"stash": torch.empty(nb * T * (2 * 256 + 2 * 128 + 2), **f32)}
+            self._mlp_tmp = {"rew": torch.zeros(N, **f32), "done": torch.zeros(N, **f32),
+                             "flags": torch.zeros(N, dtype=torch.uint8, device=d), "stash": None}
+        self.dlogits = torch.empty((N // self.num_minibatches) * T, 5, **f32)
+        self.dvalue = torch.empty((N // self.num_minibatches) * T, **f32)
+        self.dheads = torch.empty((N // self.num_minibatches) * T, 6, **f32)
+        self.reset()
+
+    # ------------------------------------------------------------------------------------------
+    def env_cfg(self):
+        return ops.make_env_cfg(self.variant, self.radius, self.bonus, self.seed, self.bank, self.bank_sources,
+                                env_offset=self.rank * self.N, n_env_total=self.world * self.N)
+
+    def reset(self):
+        ops.env_reset(self.env_state, self.N, self.env_cfg(), self.cur_obs)
+        if self.kind == "lstm":
+            self.h.zero_()
+            self.c.zero_()
+
+    # ------------------------------------------------------------------------------------------ R1
+    def collect(self, forced_act=None, noise=None):
+        """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
+        if self.kind == "lstm":
+            if self.policy.num_layers != 1:
+                raise RuntimeError("fused rollout kernel supports a single LSTM layer (stacked: see DESIGN.md)")
+            self.h0.copy_(self.h)
+            self.c0.copy_(self.c)
+            ops.rollout_lstm(self.env_state, self.N, self.env_cfg(), self.policy.flat, self.policy.hidden, self.T,
+                             self.iteration, self.cur_obs, self.h[0], self.c[0], self.buf, last_val=self.last_val,
+                             forced_act=forced_act, noise=noise, nan_count=self.nan_count)
+        else:
+            self._collect_stepwise(forced_act, noise)
+
+    def _collect_stepwise(self, forced_act=None, noise=None):
+        """MLP policy: one policy-forward + sample + env-step launch group per time step
+        (train_ppo2.0.py:157-198 with a batch of N states instead of 1)."""
+        b, tmp = self.buf, self._mlp_tmp
+        cfg = self.env_cfg()
+        for t in range(self.T):
+            heads = self.policy.heads(self.cur_obs, stash=tmp["stash"])
+            tmp["stash"] = self.policy._stash
+            logits = heads[:, :5].contiguous()
+            fa = None if forced_act is None else forced_act[:, t].contiguous()
+            act, logp, _, _ = ops.policy_sample(logits, seed=self.seed + 7919 * self.rank,
+                                                counter=self.iteration * self.T + t, forced_act=fa,
+                                                nan_count=self.nan_count)
+            b["obs"][:, t] = self.cur_obs
+            b["act"][:, t] = act
+            b["val"][:, t] = heads[:, 5]
+            b["logp"][:, t] = logp
+            nz = None if noise is None else noise[:, t].contiguous()
+            ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, tmp["rew"], tmp["done"], tmp["flags"], noise=nz)
+            b["rew"][:, t] = tmp["rew"]
+            b["done"][:, t] = tmp["done"]
+            b["flags"][:, t] = tmp["flags"]
+        if self.last_val is not None:
+            self.last_val.copy_(self.policy.heads(self.cur_obs, stash=tmp["stash"])[:, 5])
+
+    # ------------------------------------------------------------------------------------------ G1, G2
+    def compute_advantages(self):
+        b, hp = self.buf, self.hp
+        ops.gae(b["rew"], b["val"], b["done"], hp["gamma"], hp["lam"], self.gae_mode, last_val=self.last_val, out=self.adv)
+        ops.adv_stats(self.adv, out=self.stats3)
+        if self.world > 1:
+            dist.all_reduce(self.stats3)          # (sum, sumsq, count): whole-buffer statistics over all ranks
+        ops.adv_normalise(self.adv, b["val"], self.stats3, self.adv_n, self.ret)
+
+    # ------------------------------------------------------------------------------------------ U1-U3
+    def update(self):
+        """GAE + EPOCHS x num_minibatches optimiser steps (_update_model, train_ppo2.0.py:15-88)."""
+        self.compute_advantages()
+        b, hp = self.buf, self.hp
+        N, T, M = self.N, self.T, self.num_minibatches
+        nb = N // M
+        inv_n = 1.0 / float(nb * T * self.world)
+        for _ in range(hp["epochs"]):
+            for m in range(M):
+                sl = slice(m * nb, (m + 1) * nb)
+                if self.kind == "lstm":
+                    heads = self.policy.heads(b["obs"][sl], b["keep"][sl], self.h0[:, sl].contiguous() if M > 1 else self.h0,
+                                              self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work)
+                else:
+                    heads = self.policy.heads(b["obs"][sl].reshape(nb * T, 6), stash=self.work["stash"])
+                logits = heads[:, :5].contiguous()
+                value = heads[:, 5].contiguous()
+                ops.ppo_loss(logits, value, b["act"][sl].reshape(-1), b["logp"][sl].reshape(-1),
+                             self.adv_n[sl].reshape(-1), self.ret[sl].reshape(-1), b["val"][sl].reshape(-1),
+                             inv_n, hp["clip"], hp["ent_beta"], self.loss_sums, self.dlogits, self.dvalue)
+                self.dheads[:, :5] = self.dlogits
+                self.dheads[:, 5] = self.dvalue
+                grad = self.policy.backward(self.dheads, self.work) if self.kind == "lstm" else self.policy.backward(self.dheads)
+                if self.world > 1:
+                    dist.all_reduce(grad)         # RCCL sum over ranks; inv_n already holds 1/global count
+                self.opt_step += 1
+                ops.clip_adam(self.policy.flat, grad, self.exp_avg, self.exp_avg_sq, self.opt_step, hp["lr"],
+                              max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm)
+                if self.record:
+                    self.log.append((self.loss_sums.clone(), self.gnorm.clone()))
+        return self.loss_sums
+
+    # ------------------------------------------------------------------------------------------ T1
+    def update_curriculum(self):
+        """Feed this iteration's finished episodes to the curriculum (host scalars).  One small
+        device->host copy of the flags per iteration; ranks see the same global sequence."""
+        if self.curriculum is None:
+            return
+        flags = self.buf["flags"]
+        if self.world > 1:
+            allf = [torch.empty_like(flags) for _ in range(self.world)]
+            dist.all_gather(allf, flags)
+            flags = torch.cat(allf, 0)
+        f = flags.cpu().numpy()
+        ended = (f & 1) > 0
+        self.curriculum.update_many(((f & 2) > 0)[ended])
+        self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
+
+    def train_iteration(self):
+        self.collect()
+        sums = self.update()
+        self.update_curriculum()
+        self.iteration += 1
+        return sums
+
+    def losses(self):
+        """(policy_loss, value_loss, entropy) of the LAST optimiser step; raises on NaN probabilities
+        like the reference (train_ppo2.0.py:58-62)."""
+        s = self.loss_sums.cpu().numpy()
+        if self.world > 1:
+            t = self.loss_sums.clone()
+            dist.all_reduce(t)
+            s = t.cpu().numpy()
+        if s[3] > 0 or int(self.nan_count.item()) > 0:
+            raise RuntimeError("NaN in probs")
+        n = (self.N // self.num_minibatches) * self.T * self.world
+        return s[0] / n, s[1] / n, s[2] / n
