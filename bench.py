@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec (+ PPO updates/sec) of the PPOV2.0 hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training iteration of BASELINE.json's headline config (C3): a fused
+rollout of 4096 envs x 128 steps per GPU over the procedural Gaussian-plume environment with the
+LSTM(h=128) actor-critic, the GAE scan + whole-buffer normalisation, 5 epochs of the clipped-PPO
+update (forward, loss, BPTT, weight gradients, grad all-reduce, clip+Adam) and the curriculum
+update.  Weak scaling: every rank owns 4096 envs; value = all ranks' env-steps / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "uav-wrf-les-ppo-lstm_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {   # BASELINE.json configs (per-GPU env count; SURVEY 8 shorthand)
+    "c2": dict(num_envs=256, horizon=64, hidden=64, layers=1, variant="v2.0"),
+    "c3": dict(num_envs=4096, horizon=128, hidden=128, layers=1, variant="v2.0"),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def lstm_flops_per_env_step(I, H, A=5):
+    """LSTM layer fwd 2*4H*(I+H); training = 3x fwd."""
+    return 2 * 4 * H * (I + H)
+
+
+def cpu_baseline(seconds=12.0):
+    """Reference-faithful CPU loop (variant (i) of BASELINE.md 3): 1 env, batch-1 MLP forward per
+    step, 256-step buffer, GAE + 5 full-batch Adam steps -- the oracle ('port'), rank 0 only."""
+    import numpy as np
+    from oracle import ppo_oracle as po
+    from oracle.env_oracle import OracleEnv
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(0)
+    p = {}
+    shapes = {"feature.0.weight": (256, 6), "feature.0.bias": (256,), "feature.1.weight": (256,), "feature.1.bias": (256,),
+              "feature.3.weight": (128, 256), "feature.3.bias": (128,), "feature.4.weight": (128,), "feature.4.bias": (128,),
+              "actor.weight": (5, 128), "actor.bias": (5,), "critic.weight": (1, 128), "critic.bias": (1,)}
+    for k, s in shapes.items():
+        if k.endswith("weight") and len(s) == 2:
+            w = torch.empty(s)
+            torch.nn.init.orthogonal_(w, gain=0.01 if k.startswith("actor") else (1.0 if k.startswith("critic") else 2 ** 0.5),
+                                      generator=gen)
+            p[k] = w
+        else:
+            p[k] = torch.ones(s) if k in ("feature.1.weight", "feature.4.weight") else torch.zeros(s)
+    adam = po.AdamState(p)
+    env = OracleEnv("v2.0", seed=0)
+    state = env.obs()
+    buf = {k: [] for k in "sarvld"}
+    steps = updates = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        with torch.no_grad():
+            probs, value, _ = po.mlp_forward(p, torch.from_numpy(state)[None])
+            a = int(torch.multinomial(probs[0], 1, generator=gen))
+            lp = float(po.categorical_logp(probs, torch.tensor([a])))
+        o, r, d, s, _ = env.step(a)
+        for k, x in zip("sarvld", (state, a, r, float(value), lp, float(d))):
+            buf[k].append(x)
+        steps += 1
+        if len(buf["s"]) >= 256:
+            po.update_model(p, adam, np.stack(buf["s"]), np.array(buf["a"]), np.array(buf["r"], np.float32),
+                            np.array(buf["v"], np.float32), np.array(buf["l"], np.float32), np.array(buf["d"], np.float32))
+            buf = {k: [] for k in buf}
+            updates += 1
+        state = env.reset() if d else o
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} env steps of 1 env + {updates} _update_model calls (256-sample buffer, MLP policy, "
+                      f"{dt:.1f} s) -- reference-faithful CPU loop of oracle/",
+            "updates_per_s": updates / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    cfg = CONFIGS[args.config]
+    N, T, H = cfg["num_envs"], cfg["horizon"], cfg["hidden"]
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, layers=cfg["layers"], variant=cfg["variant"], device=dev,
+                       seed=1234, rank=rank, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_iteration()
+    # ---- timed region: exactly K iterations, barrier + synchronize on both sides
+    ops.KERNEL_TIMER.enable(("lstm_bwd", "lstm_fwd", "lstm_wgrad", "rollout"))
+    ev_roll = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev_roll[k][0].record()
+        tr.collect()
+        ev_roll[k][1].record()
+        tr.update()
+        tr.update_curriculum()
+        tr.iteration += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    timers = ops.KERNEL_TIMER.summary()
+    ops.KERNEL_TIMER.disable()
+    tr.losses()     # raises if any NaN probability was seen (reference convention)
+
+    roll_ms = sum(a.elapsed_time(b) for a, b in ev_roll) / args.steps
+    env_steps = N * T * world * args.steps
+    value = env_steps / dt
+    opt_steps = tr.hp["epochs"] * tr.num_minibatches
+    # roofline of the dominant kernel (BPTT sequence kernel): algorithmic flops of the dh = dgates W_hh
+    # product per launch (N*T*2*4H*H; SURVEY 8d's per-env-step LSTM figure restricted to this kernel)
+    fl_bwd = N * T * 2 * 4 * H * H
+    bwd = timers.get("lstm_bwd")
+    roofline = None
+    if bwd:
+        ach = fl_bwd / (bwd["avg_ms"] * 1e-3) / 1e12
+        roofline = {"kernel": "lstm_bwd_kernel<%d>" % H, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_ms": bwd["avg_ms"], "launches": bwd["n"]}
+    out = {
+        "metric": "env-steps/sec (rollout + GAE + 5-epoch PPO update), 4096 envs x 128 T per GPU, LSTM h=128",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
+        "config": {"workload": f"BASELINE configs[2] ({args.config}): PPOV2.0, {N} envs/GPU x T={T}, LSTM h={H}, obs 6, "
+                               f"5 actions, reference_exact GAE, {tr.hp['epochs']} epochs x {tr.num_minibatches} minibatch "
+                               f"of {N * T} samples/GPU", "num_envs_per_gpu": N, "horizon": T, "hidden": H,
+                   "minibatch_samples": N * T // tr.num_minibatches, "parallelism": f"dp{world} (env shards, RCCL grad all-reduce)"},
+        "rollout_env_steps_per_s": N * T * world / (roll_ms * 1e-3),
+        "ppo_iterations_per_s": args.steps / dt, "optimizer_steps_per_s": args.steps * opt_steps / dt,
+        "rollout_ms": roll_ms, "kernel_ms": {k: v["avg_ms"] for k, v in timers.items()},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

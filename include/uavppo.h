@@ -126,17 +126,20 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
                  const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  int N, int T, int I, int H, float* y, float* hn, float* cn, float* stash,
                  uav_stream stream);
-/* Gradient of y comes either as dy [N][T][H], or -- for the actor-critic heads, fused --
- * as dheads [N][T][n_heads] with w_head [n_heads][H] (dy = dheads . w_head is formed in
- * registers, never written to HBM); exactly one of dy / dheads is non-NULL.  dhn,dcn [N][H]
- * or NULL.  Writes dx [N][T][I] (or NULL to skip), dw_ih [4H][I], dw_hh [4H][H], db [4H]
- * (= db_ih = db_hh), dh0, dc0 [N][H] (or NULL).  dgates: scratch f32 [N][T][4H] from the
- * caller (the per-step gate gradients; input of the time-batched weight-gradient GEMMs). */
-int uav_lstm_bwd(uav_ctx* ctx, const float* x, const float* keep, const float* stash,
-                 const float* w_ih, const float* w_hh, const float* dy, const float* dheads,
-                 const float* w_head, int n_heads, const float* dhn, const float* dcn, int N, int T,
-                 int I, int H, float* dgates, float* dx, float* dw_ih, float* dw_hh, float* db,
-                 float* dh0, float* dc0, uav_stream stream);
+/* BPTT sequence kernel.  Gradient of y comes either as dy [N][T][H], or -- for the actor-critic
+ * heads, fused -- as dheads [N][T][n_heads] with w_head [n_heads][H] (dy = dheads . w_head is
+ * formed in registers, never written to HBM); exactly one of dy / dheads is non-NULL.  dhn,dcn
+ * [N][H] or NULL.  Writes dgates f32 [N][T][4H] (per-step gate gradients, the input of
+ * uav_lstm_wgrad) and dh0, dc0 [N][H] (or NULL). */
+int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh,
+                 const float* dy, const float* dheads, const float* w_head, int n_heads,
+                 const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0,
+                 float* dc0, uav_stream stream);
+/* Time-batched weight gradients from dgates: dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev
+ * (Hprev from the stash), db [4H] (= db_ih = db_hh), and dx [N][T][I] = dG W_ih (or NULL). */
+int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* stash, const float* dgates,
+                   const float* w_ih, int N, int T, int I, int H, float* dw_ih, float* dw_hh,
+                   float* db, float* dx, uav_stream stream);
 
 /* ---- E1-E5: vectorised plume environment (environment.py:19-169).  State lives in one
  * caller-owned device blob of uav_env_state_bytes(n_env) bytes. */

@@ -366,31 +366,15 @@ __global__ void add2_kernel(const float* a0, const float* a1, float* b, int n) {
     if (i < n) b[i] = a0[i] + a1[i];
 }
 
-int lstm_bwd_core(uav_ctx* ctx, const float* x, const float* keep, const float* stash, const float* w_ih,
-                  const float* w_hh, const float* dy, const float* dheads, const float* w_head, int NH,
-                  const float* dhn, const float* dcn, int N, int T, int I, int H, float* dgates, float* dx,
-                  float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, hipStream_t st) {
-    int rc;
+static int lstm_bwd_seq(const float* keep, const float* stash, const float* w_hh, const float* dy,
+                        const float* dheads, const float* w_head, int NH, const float* dhn, const float* dcn, int N,
+                        int T, int H, float* dgates, float* dh0, float* dc0, hipStream_t st) {
     switch (H) {
-        case 64: rc = launch_bwd<64>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st); break;
-        case 128: rc = launch_bwd<128>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st); break;
-        default: uav_set_error("uav_lstm_bwd: H=%d unsupported (64, 128)", H); return 2;
+        case 64: return launch_bwd<64>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+        case 128: return launch_bwd<128>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
     }
-    if (rc) return rc;
-    const int64_t NT = (int64_t)N * T;
-    // weight gradients: time-batched GEMMs over all N*T rows (split-K, deterministic)
-    // dW_hh[4H][H] = dG^T Hprev ; Hprev = stash[..][5H:6H]
-    if ((rc = gemm_f32(ctx, 4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H, nullptr, 0, st))) return rc;
-    if ((rc = gemm_f32(ctx, 4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I, nullptr, 0, st))) return rc;
-    // column sums reuse the tail of the workspace
-    const size_t red_floats = (size_t)1024 * 4 * H;
-    UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_bwd: workspace too small");
-    float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
-    if ((rc = colsum(ctx, dgates, NT, 4 * H, db, red, st))) return rc;
-    if (dx) {
-        if ((rc = gemm_f32(ctx, NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I, nullptr, 0, st))) return rc;
-    }
-    return 0;
+    uav_set_error("uav_lstm_bwd: H=%d unsupported (64, 128)", H);
+    return 2;
 }
 
 extern "C" {
@@ -420,16 +404,37 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
     UAV_REQUIRE(false, "uav_lstm_fwd: H=%d unsupported (64, 128)", H);
 }
 
-int uav_lstm_bwd(uav_ctx* ctx, const float* x, const float* keep, const float* stash, const float* w_ih,
-                 const float* w_hh, const float* dy, const float* dheads, const float* w_head, int n_heads,
-                 const float* dhn, const float* dcn, int N, int T, int I, int H, float* dgates, float* dx,
-                 float* dw_ih, float* dw_hh, float* db, float* dh0, float* dc0, uav_stream stream) {
-    UAV_REQUIRE(ctx && x && stash && w_ih && w_hh && dgates && dw_ih && dw_hh && db, "uav_lstm_bwd: NULL argument");
+int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
+                 const float* dheads, const float* w_head, int n_heads, const float* dhn, const float* dcn, int N,
+                 int T, int H, float* dgates, float* dh0, float* dc0, uav_stream stream) {
+    UAV_REQUIRE(ctx && stash && w_hh && dgates, "uav_lstm_bwd: NULL argument");
     UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd: give exactly one of dy / dheads");
     UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd: dheads needs w_head and 1..8 heads");
-    UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_bwd: N=%d T=%d I=%d", N, T, I);
-    return lstm_bwd_core(ctx, x, keep, stash, w_ih, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, I, H, dgates,
-                         dx, dw_ih, dw_hh, db, dh0, dc0, as_stream(stream));
+    UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd: N=%d T=%d", N, T);
+    return lstm_bwd_seq(keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, H, dgates, dh0, dc0,
+                        as_stream(stream));
+}
+
+int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* stash, const float* dgates, const float* w_ih, int N,
+                   int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* dx, uav_stream stream) {
+    UAV_REQUIRE(ctx && x && stash && dgates && w_ih && dw_ih && dw_hh && db, "uav_lstm_wgrad: NULL argument");
+    UAV_REQUIRE(N > 0 && T > 0 && I > 0 && H > 0, "uav_lstm_wgrad: N=%d T=%d I=%d H=%d", N, T, I, H);
+    hipStream_t st = as_stream(stream);
+    const int64_t NT = (int64_t)N * T;
+    // column sums use the tail of the workspace, the split-K slabs everything in front of it
+    const size_t red_floats = (size_t)1024 * 4 * H;
+    UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_wgrad: workspace too small");
+    float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
+    uav_ctx sub = *ctx;
+    sub.ws_bytes = ctx->ws_bytes - red_floats * sizeof(float);
+    int rc;
+    // time-batched GEMMs over all N*T rows (split-K, deterministic):
+    // dW_hh[4H][H] = dG^T Hprev, Hprev = stash[..][5H:6H];  dW_ih[4H][I] = dG^T X;  db = colsum(dG)
+    if ((rc = gemm_f32(&sub, 4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H, nullptr, 0, st))) return rc;
+    if ((rc = gemm_f32(&sub, 4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I, nullptr, 0, st))) return rc;
+    if ((rc = colsum(&sub, dgates, NT, 4 * H, db, red, st))) return rc;
+    if (dx) return gemm_f32(&sub, NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I, nullptr, 0, st);
+    return 0;
 }
 
 }  // extern "C"

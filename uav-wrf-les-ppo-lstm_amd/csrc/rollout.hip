@@ -51,7 +51,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                                                                         uint64_t iter, const float* __restrict__ params,
                                                                         RolloutBufs B) {
     using G = RGeom<H>;
-    constexpr int NW = G::NW, KS = G::KS, SEG = G::SEG, S = G::S, I = 6, NH = NA + 1;
+    constexpr int KS = G::KS, SEG = G::SEG, S = G::S, I = 6, NH = NA + 1;
     __shared__ __attribute__((aligned(16))) float hbuf[RMT * S];
     __shared__ __attribute__((aligned(16))) float xbuf[RMT * 8];
     __shared__ float kbuf[RMT];

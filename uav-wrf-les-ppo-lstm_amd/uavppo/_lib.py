@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- FIRST: torch's bundled HIP runtime must be the one libuavppo.so binds to
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuavppo.so")
 
@@ -42,7 +44,8 @@ SIGNATURES = {
     "uav_mlp_fwd": (I32, [P, P, P, I64, I32, I32, I32, I32, P, P, P]),
     "uav_mlp_bwd": (I32, [P, P, P, P, P, I64, I32, I32, I32, I32, P, P]),
     "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
-    "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, I32, P, P, P, P, P, P, P, P]),
+    "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, P, P]),
+    "uav_lstm_wgrad": (I32, [P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),
     "uav_env_reset": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P]),
     "uav_env_step": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P, P, P, P, P, P, P, P, P]),

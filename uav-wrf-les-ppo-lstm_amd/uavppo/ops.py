@@ -63,6 +63,40 @@ def _p(t, dtype=None, shape=None, name="tensor"):
 F32, F64, I32, U8 = torch.float32, torch.float64, torch.int32, torch.uint8
 
 
+class _KernelTimer:
+    """Optional HIP-event bracket around named launches on torch's current stream (bench.py uses it
+    to time the dominant kernel live inside the timed region).  Disabled = zero overhead."""
+
+    def __init__(self):
+        self.names, self.events = (), {}
+
+    def enable(self, names):
+        self.names, self.events = tuple(names), {n: [] for n in names}
+
+    def disable(self):
+        self.names, self.events = (), {}
+
+    def bracket(self, name):
+        if name not in self.names:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events[name].append((a, b))
+        a.record()
+        return b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for n, ev in self.events.items():
+            if ev:
+                ms = [a.elapsed_time(b) for a, b in ev]
+                out[n] = {"avg_ms": sum(ms) / len(ms), "n": len(ms)}
+        return out
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
 # ----------------------------------------------------------------------------- G1 / G2
 def gae(rew, val, done, gamma, lam, mode="reference_exact", last_val=None, out=None):
     n, T = rew.shape
@@ -246,11 +280,14 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
     cn = torch.empty(N, H, dtype=F32, device=dev)
     if stash is None and (want_stash or I > 8):
         stash = torch.empty(N, T, 6 * H, dtype=F32, device=dev)
+    _t = KERNEL_TIMER.bracket("lstm_fwd")
     check(lib().uav_lstm_fwd(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"),
                              _p(h0, F32, (N, H), "h0"), _p(c0, F32, (N, H), "c0"), _p(w_ih, F32, (4 * H, I), "w_ih"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(b_ih, F32, (4 * H,), "b_ih"),
                              _p(b_hh, F32, (4 * H,), "b_hh"), N, T, I, H, _p(y, F32, (N, T, H), "y"), _p(hn), _p(cn),
                              _p(stash, F32, (N, T, 6 * H), "stash"), _stream()), "uav_lstm_fwd")
+    if _t is not None:
+        _t.record()
     return y, hn, cn, stash
 
 
@@ -267,14 +304,21 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=
     dh0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
     dc0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
     nh = 0 if dheads is None else dheads.shape[-1]
-    check(lib().uav_lstm_bwd(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"),
-                             _p(stash, F32, (N, T, 6 * H), "stash"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+    _t = KERNEL_TIMER.bracket("lstm_bwd")
+    check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
                              _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh,
-                             _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, I, H,
-                             _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dx), _p(dw_ih, F32, (4 * H, I), "dw_ih"),
-                             _p(dw_hh, F32, (4 * H, H), "dw_hh"), _p(db, F32, (4 * H,), "db"), _p(dh0), _p(dc0),
-                             _stream()), "uav_lstm_bwd")
+                             _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, H,
+                             _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dh0), _p(dc0), _stream()), "uav_lstm_bwd")
+    if _t is not None:
+        _t.record()
+    _t = KERNEL_TIMER.bracket("lstm_wgrad")
+    check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(stash, F32, (N, T, 6 * H), "stash"),
+                               _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"), N, T, I, H,
+                               _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
+                               _p(db, F32, (4 * H,), "db"), _p(dx), _stream()), "uav_lstm_wgrad")
+    if _t is not None:
+        _t.record()
     return {"dx": dx, "dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dh0": dh0, "dc0": dc0, "dgates": dgates}
 
 
@@ -291,6 +335,7 @@ def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h,
                  forced_act=None, noise=None, nan_count=None):
     """Fused persistent rollout (csrc/rollout.hip).  bufs: dict obs[N,T,6] act rew val logp done flags keep."""
     N, T = n_env, horizon
+    _t = KERNEL_TIMER.bracket("rollout")
     check(lib().uav_rollout(_h(cur_obs), _p(env_state, U8, name="env state"), N, C.byref(cfg), 1,
                             _p(params, F32, name="params"), int(hidden), T, int(it),
                             _p(cur_obs, F32, (N, 6), "cur_obs"), _p(h, F32, (N, hidden), "h"), _p(c, F32, (N, hidden), "c"),
@@ -301,3 +346,5 @@ def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h,
                             _p(last_val, F32, (N,), "last_val"), _p(forced_act, I32, (N, T), "forced_act"),
                             _p(noise, F64, (N, T, 2), "noise"), _p(nan_count, I32, (1,), "nan_count"), _stream()),
           "uav_rollout")
+    if _t is not None:
+        _t.record()
