@@ -173,6 +173,11 @@ int uav_env_step(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg /*
 int uav_env_peek(uav_ctx* ctx, const void* state, int n_env, float* pos, double* source,
                  int32_t* steps, int32_t* episode, uav_stream stream);
 
+/* the 500x500 (conc, tke) f64 tables of env `env_index`'s CURRENT episode, i.e. what the reference
+ * holds in env.conc_field / env.tke_field (environment.py:61-62); field_out f64 [500][500][2] */
+int uav_env_materialise(uav_ctx* ctx, const void* state, int n_env, const uav_env_cfg* cfg /*host*/,
+                        int env_index, double* field_out, uav_stream stream);
+
 /* ---- R1: fused persistent rollout (train_ppo2.0.py:157-198 for n_env environments):
  * policy step + sample + env step + store, T steps in one launch; one workgroup owns a tile
  * of envs and keeps h/c in LDS/registers across the time loop.

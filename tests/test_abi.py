@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library loads here (no GPU needed) and exports exactly what include/uavppo.h
+declares; the ctypes table mirrors the header.  No compute call is made."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "uavppo.h")
+
+
+def declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uav_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from uavppo import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: make -C uav-wrf-les-ppo-lstm_amd/csrc"
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (uav_[a-z0-9_]+)", out))
+    names = declared()
+    assert len(names) >= 25
+    missing = [n for n in names if n not in exported]
+    assert not missing, f"declared in uavppo.h but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    from uavppo import _lib
+    names = declared()
+    assert sorted(_lib.SIGNATURES) == names
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n_decl = 0 if params in ("", "void") else len(params.split(","))
+        assert n_decl == len(args), (name, n_decl, len(args))
+
+
+def test_loads_and_reports_version_without_gpu():
+    from uavppo import _lib
+    lib = _lib.lib()
+    assert lib.uav_abi_version() == 1
+    assert lib.uav_mlp_param_count(6, 256, 128, 5) == 36230      # 36,230 parameters
+    assert lib.uav_mlp_stash_floats(256, 128) == 2 * 256 + 2 * 128 + 2
+    assert lib.uav_env_state_bytes(4096) > 4096 * 200
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: on a GPU-less host the first op raises instead of computing something else."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from uavppo import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.Context.get(torch.device("cuda", 0))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "uav-wrf-les-ppo-lstm_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)

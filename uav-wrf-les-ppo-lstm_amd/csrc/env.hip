@@ -96,7 +96,31 @@ __global__ __launch_bounds__(256) void env_peek_kernel(EnvBlob b, int n, float* 
     if (episode) episode[i] = b.episode[i];
 }
 
+// the whole 500x500 field of ONE env's current episode, as the reference keeps it in
+// env.conc_field / env.tke_field (environment.py:61-62): out[x][y] = (conc, tke)
+__global__ __launch_bounds__(256) void env_materialise_kernel(EnvParams P, EnvBlob b, int env, double* __restrict__ out) {
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= GRID * GRID) return;
+    EnvState s = env_load(b, env);
+    double c, t;
+    field_at(P, P.env_offset + env, s, cell / GRID, cell % GRID, c, t);
+    out[2 * (size_t)cell] = c;
+    out[2 * (size_t)cell + 1] = t;
+}
+
 extern "C" {
+
+int uav_env_materialise(uav_ctx* ctx, const void* state, int n_env, const uav_env_cfg* cfg, int env_index,
+                        double* field_out, uav_stream stream) {
+    UAV_REQUIRE(ctx && state && field_out && env_index >= 0 && env_index < n_env, "uav_env_materialise: bad argument");
+    EnvParams P;
+    int rc = env_params_from_cfg(ctx, cfg, n_env, P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(env_materialise_kernel, dim3((GRID * GRID + 255) / 256), dim3(256), 0, as_stream(stream), P,
+                       env_blob_view(const_cast<void*>(state), n_env), env_index, field_out);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
 
 size_t uav_env_state_bytes(int n_env) { return n_env > 0 ? env_blob_bytes(n_env) : 0; }
 

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void ln_relu_fwd_kernel(float* __restrict__ z,
         for (int j = 0; j < VPT; ++j) {
             const float xh = v[j] * rstd;
             z[row * C + j * 64 + lane] = xh;
-            a[row * C + j * 64 + lane] = fmaxf(xh * gg[j] + bb[j], 0.f);
+            const float pre = xh * gg[j] + bb[j];
+            a[row * C + j * 64 + lane] = pre < 0.f ? 0.f : pre;      // NaN propagates like torch.relu (model.py:47-49 relies on it)
         }
         if (lane == 0) rstd_out[row] = rstd;
     }

@@ -322,6 +322,13 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=
     return {"dx": dx, "dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dh0": dh0, "dc0": dc0, "dgates": dgates}
 
 
+def env_materialise(state, n_env, cfg, env_index, out=None):
+    out = torch.empty(500, 500, 2, dtype=F64, device=state.device) if out is None else out
+    check(lib().uav_env_materialise(_h(state), _p(state, U8, name="env state"), n_env, C.byref(cfg), int(env_index),
+                                    _p(out, F64, (500, 500, 2), "field_out"), _stream()), "uav_env_materialise")
+    return out
+
+
 def colsum(x, out=None):
     rows, cols = x.shape
     out = torch.empty(cols, dtype=F32, device=x.device) if out is None else out

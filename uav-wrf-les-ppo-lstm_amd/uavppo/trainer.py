@@ -11,9 +11,9 @@ from __future__ import annotations
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from . import ops
+from .dist_utils import allreduce_adv_stats, allreduce_grad, env_shard, gather_episode_flags
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
 
@@ -94,7 +94,7 @@ class VecPPOTrainer:
     # ------------------------------------------------------------------------------------------
     def env_cfg(self):
         return ops.make_env_cfg(self.variant, self.radius, self.bonus, self.seed, self.bank, self.bank_sources,
-                                env_offset=self.rank * self.N, n_env_total=self.world * self.N)
+                                env_offset=env_shard(self.rank, self.N)[0], n_env_total=self.world * self.N)
 
     def reset(self):
         ops.env_reset(self.env_state, self.N, self.env_cfg(), self.cur_obs)
@@ -146,8 +146,7 @@ class VecPPOTrainer:
         b, hp = self.buf, self.hp
         ops.gae(b["rew"], b["val"], b["done"], hp["gamma"], hp["lam"], self.gae_mode, last_val=self.last_val, out=self.adv)
         ops.adv_stats(self.adv, out=self.stats3)
-        if self.world > 1:
-            dist.all_reduce(self.stats3)          # (sum, sumsq, count): whole-buffer statistics over all ranks
+        allreduce_adv_stats(self.stats3)          # (sum, sumsq, count): whole-buffer statistics over all ranks
         ops.adv_normalise(self.adv, b["val"], self.stats3, self.adv_n, self.ret)
 
     # ------------------------------------------------------------------------------------------ U1-U3
@@ -174,8 +173,7 @@ class VecPPOTrainer:
                 self.dheads[:, :5] = self.dlogits
                 self.dheads[:, 5] = self.dvalue
                 grad = self.policy.backward(self.dheads, self.work) if self.kind == "lstm" else self.policy.backward(self.dheads)
-                if self.world > 1:
-                    dist.all_reduce(grad)         # RCCL sum over ranks; inv_n already holds 1/global count
+                allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
                 self.opt_step += 1
                 ops.clip_adam(self.policy.flat, grad, self.exp_avg, self.exp_avg_sq, self.opt_step, hp["lr"],
                               max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm)
@@ -189,12 +187,7 @@ class VecPPOTrainer:
         device->host copy of the flags per iteration; ranks see the same global sequence."""
         if self.curriculum is None:
             return
-        flags = self.buf["flags"]
-        if self.world > 1:
-            allf = [torch.empty_like(flags) for _ in range(self.world)]
-            dist.all_gather(allf, flags)
-            flags = torch.cat(allf, 0)
-        f = flags.cpu().numpy()
+        f = gather_episode_flags(self.buf["flags"]).cpu().numpy()
         ended = (f & 1) > 0
         self.curriculum.update_many(((f & 2) > 0)[ended])
         self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
@@ -211,6 +204,7 @@ class VecPPOTrainer:
         like the reference (train_ppo2.0.py:58-62)."""
         s = self.loss_sums.cpu().numpy()
         if self.world > 1:
+            import torch.distributed as dist
             t = self.loss_sums.clone()
             dist.all_reduce(t)
             s = t.cpu().numpy()
