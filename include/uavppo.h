@@ -70,11 +70,13 @@ int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t 
  * logits f32 [n][n_act] (pre-softmax), value f32 [n], act i32 [n]; inv_n = 1/(global sample
  * count).  loss_sums (f64 [4], device): {sum -min(s1,s2), sum 0.5*max(.), sum entropy,
  * count of NaN probabilities}.  dlogits [n][n_act], dvalue [n] are d(total)/d(.) where
- * total = policy + value - ent_beta*entropy, each a mean over 1/inv_n samples. */
+ * total = policy + value - ent_beta*entropy, each a mean over 1/inv_n samples.  dhead_bias
+ * (f32 [n_act+1], or NULL): column sums of (dlogits | dvalue) = gradient of the head biases. */
 int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const int32_t* act,
                  const float* logp_old, const float* adv, const float* ret, const float* val_old,
                  int64_t n, int n_act, float inv_n, float clip, float ent_beta,
-                 double* loss_sums, float* dlogits, float* dvalue, uav_stream stream);
+                 double* loss_sums, float* dlogits, float* dvalue, float* dhead_bias,
+                 uav_stream stream);
 
 /* ---- K3 (sampling part): softmax + Categorical sample + log_prob + NaN check
  * (train_ppo2.0.py:161-163,189; torch Categorical(probs) semantics).  u: uniforms in [0,1)
@@ -135,11 +137,15 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
                  const float* dy, const float* dheads, const float* w_head, int n_heads,
                  const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0,
                  float* dc0, uav_stream stream);
-/* Time-batched weight gradients from dgates: dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev
- * (Hprev from the stash), db [4H] (= db_ih = db_hh), and dx [N][T][I] = dG W_ih (or NULL). */
-int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* stash, const float* dgates,
-                   const float* w_ih, int N, int T, int I, int H, float* dw_ih, float* dw_hh,
-                   float* db, float* dx, uav_stream stream);
+/* Time-batched weight gradients from dgates in ONE fused pass (csrc/wgrad.hip):
+ * dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev with Hprev[n][t] = y[n][t-1]*keep[n][t]
+ * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh) and -- when dheads != NULL (top layer) --
+ * dw_head [n_heads][H] = dheads^T y.  dx [N][T][I] = dG W_ih when non-NULL.  y [N][T][H] is this
+ * layer's forward output.  I > 6 (stacked layers) takes generic split-K GEMMs and needs `stash`. */
+int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* y,
+                   const float* stash, const float* dgates, const float* w_ih, const float* dheads,
+                   int n_heads, int N, int T, int I, int H, float* dw_ih, float* dw_hh, float* db,
+                   float* dw_head, float* dx, uav_stream stream);
 
 /* ---- E1-E5: vectorised plume environment (environment.py:19-169).  State lives in one
  * caller-owned device blob of uav_env_state_bytes(n_env) bytes. */

@@ -23,7 +23,7 @@ def _close(a, b, rtol=2e-4, atol=2e-5):
     assert err <= atol * max(scale, 1.0) + rtol * scale, (err, scale)
 
 
-@pytest.mark.parametrize("T,N,I,H", [(8, 4, 6, 64), (16, 8, 6, 128), (70, 37, 6, 128), (5, 16, 8, 64),
+@pytest.mark.parametrize("T,N,I,H", [(8, 4, 6, 64), (16, 8, 6, 128), (70, 37, 6, 128), (5, 16, 8, 64), (33, 300, 4, 64),
                                      (12, 20, 64, 64), (9, 17, 128, 128), (1, 1, 6, 128)])
 @pytest.mark.parametrize("use_keep", [False, True])
 def test_lstm_layer_fwd_bwd(ops, T, N, I, H, use_keep):
@@ -51,7 +51,8 @@ def test_lstm_layer_fwd_bwd(ops, T, N, I, H, use_keep):
     _close(yg.transpose(0, 1), y, 1e-5, 2e-6)
     _close(hng, hn, 1e-5, 2e-6)
     _close(cng, cn, 1e-5, 2e-6)
-    g = ops.lstm_bwd(xg, kg, stash, d(w_ih), d(w_hh), dy=d(dy.transpose(0, 1)), dhn=d(dhn), dcn=d(dcn), need_dx=True)
+    g = ops.lstm_bwd(xg, kg, stash, d(w_ih), d(w_hh), yg, d(h0), dy=d(dy.transpose(0, 1)), dhn=d(dhn), dcn=d(dcn),
+                     need_dx=True)
     _close(g["dx"].transpose(0, 1), x.grad)
     _close(g["dw_ih"], w_ih.grad)
     _close(g["dw_hh"], w_hh.grad)
@@ -74,10 +75,13 @@ def test_lstm_bwd_fused_heads_equals_explicit_dy(ops):
     dheads = torch.randn(N, T, 6, device=dev)
     w_head = torch.randn(6, H, device=dev)
     dy = (dheads.reshape(-1, 6).cpu().double() @ w_head.cpu().double()).float().reshape(N, T, H).to(dev)
-    g1 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, dy=dy)
-    g2 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, dheads=dheads, w_head=w_head)
+    g1 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=dy)
+    g2 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dheads=dheads, w_head=w_head)
     for k in ("dw_ih", "dw_hh", "db", "dh0", "dc0"):
         _close(g2[k], g1[k], 1e-4, 1e-5)
+    # fused head-weight gradient dW_head = dheads^T y
+    want = dheads.reshape(-1, 6).cpu().double().T @ y.reshape(-1, H).cpu().double()
+    _close(g2["dw_head"], want.float(), 1e-4, 1e-5)
 
 
 def test_lstm_two_layer_stack_matches_torch(ops):

@@ -25,6 +25,7 @@ __device__ __forceinline__ void softmax_row(const float* z, float* p) {
 }
 
 constexpr int LOSS_BLOCKS = 1024;
+constexpr int LOSS_PSTRIDE = 16;   // doubles per block partial: 4 loss sums + up to 9 head-bias sums
 
 template <int A>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(
@@ -34,6 +35,9 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
     double* __restrict__ partial, float* __restrict__ dlogits, float* __restrict__ dvalue) {
     __shared__ double sm[4];
     double s_pl = 0.0, s_vl = 0.0, s_en = 0.0, s_nan = 0.0;
+    float s_db[A + 1];                       // column sums of (dlogits | dvalue) = gradient of the head biases
+#pragma unroll
+    for (int k = 0; k <= A; ++k) s_db[k] = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float z[A], p[A];
 #pragma unroll
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
         const float d2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - R) : 0.f;
         const float gV = (e1 > e2) ? d1 : ((e1 < e2) ? d2 : 0.5f * (d1 + d2));
         dvalue[i] = 0.5f * inv_n * gV;
+        s_db[A] += 0.5f * inv_n * gV;
 
         // entropy, train_ppo2.0.py:81 :  H = -sum p log(p + 1e-8)
         float Hs = 0.f, hk[A], ph = 0.f;
@@ -101,29 +106,35 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
             const float dpol = g_logp * ((k == a ? 1.0f : 0.0f) - q[k]);
             const float dent = -beta * inv_n * p[k] * (hk[k] - ph);
             dlogits[i * A + k] = dpol + dent;
+            s_db[k] += dpol + dent;
         }
     }
     s_pl = block256_sum(s_pl, sm);
     s_vl = block256_sum(s_vl, sm);
     s_en = block256_sum(s_en, sm);
     s_nan = block256_sum(s_nan, sm);
+    double dbs[A + 1];
+#pragma unroll
+    for (int k = 0; k <= A; ++k) dbs[k] = block256_sum((double)s_db[k], sm);
     if (threadIdx.x == 0) {
-        partial[4 * blockIdx.x + 0] = s_pl;
-        partial[4 * blockIdx.x + 1] = s_vl;
-        partial[4 * blockIdx.x + 2] = s_en;
-        partial[4 * blockIdx.x + 3] = s_nan;
+        double* pp = partial + (size_t)LOSS_PSTRIDE * blockIdx.x;
+        pp[0] = s_pl; pp[1] = s_vl; pp[2] = s_en; pp[3] = s_nan;
+#pragma unroll
+        for (int k = 0; k <= A; ++k) pp[4 + k] = dbs[k];
     }
 }
 
-__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nb,
-                                                         double* __restrict__ out4) {
+__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nb, int n_heads,
+                                                         double* __restrict__ out4, float* __restrict__ dbias) {
     __shared__ double sm[4];
-    double s[4] = {0, 0, 0, 0};
-    for (int i = threadIdx.x; i < nb; i += 256)
-        for (int k = 0; k < 4; ++k) s[k] += partial[4 * i + k];
-    for (int k = 0; k < 4; ++k) {
-        const double r = block256_sum(s[k], sm);
-        if (threadIdx.x == 0) out4[k] = r;
+    for (int k = 0; k < 4 + n_heads; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nb; i += 256) s += partial[(size_t)LOSS_PSTRIDE * i + k];
+        const double r = block256_sum(s, sm);
+        if (threadIdx.x == 0) {
+            if (k < 4) out4[k] = r;
+            else if (dbias) dbias[k - 4] = (float)r;
+        }
     }
 }
 
@@ -182,7 +193,7 @@ extern "C" {
 int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const int32_t* act,
                  const float* logp_old, const float* adv, const float* ret, const float* val_old,
                  int64_t n, int n_act, float inv_n, float clip, float ent_beta, double* loss_sums,
-                 float* dlogits, float* dvalue, uav_stream stream) {
+                 float* dlogits, float* dvalue, float* dhead_bias, uav_stream stream) {
     UAV_REQUIRE(ctx && logits && value && act && logp_old && adv && ret && val_old && loss_sums && dlogits && dvalue,
                 "uav_ppo_loss: NULL argument");
     UAV_REQUIRE(n > 0, "uav_ppo_loss: n=%lld", (long long)n);
@@ -202,7 +213,8 @@ int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const in
         default: UAV_REQUIRE(false, "uav_ppo_loss: n_act=%d unsupported", n_act);
     }
 #undef LAUNCH_LOSS
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, loss_sums);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
+                       dhead_bias);
     UAV_LAUNCH_CHECK();
     return 0;
 }

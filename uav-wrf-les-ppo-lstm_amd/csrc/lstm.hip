@@ -26,6 +26,9 @@ int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int6
              const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
              int accumulate, hipStream_t st);
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st);
+int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
+                     const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
+                     float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 constexpr int TC = 32;      // time steps staged per chunk
@@ -415,25 +418,33 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
                         as_stream(stream));
 }
 
-int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* stash, const float* dgates, const float* w_ih, int N,
-                   int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* dx, uav_stream stream) {
-    UAV_REQUIRE(ctx && x && stash && dgates && w_ih && dw_ih && dw_hh && db, "uav_lstm_wgrad: NULL argument");
+int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* y,
+                   const float* stash, const float* dgates, const float* w_ih, const float* dheads, int n_heads, int N,
+                   int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* dw_head, float* dx,
+                   uav_stream stream) {
+    UAV_REQUIRE(ctx && x && h0 && y && dgates && w_ih && dw_ih && dw_hh && db, "uav_lstm_wgrad: NULL argument");
     UAV_REQUIRE(N > 0 && T > 0 && I > 0 && H > 0, "uav_lstm_wgrad: N=%d T=%d I=%d H=%d", N, T, I, H);
+    UAV_REQUIRE(!dheads || (dw_head && n_heads > 0 && n_heads <= 8), "uav_lstm_wgrad: dheads needs dw_head, 1..8 heads");
     hipStream_t st = as_stream(stream);
     const int64_t NT = (int64_t)N * T;
-    // column sums use the tail of the workspace, the split-K slabs everything in front of it
-    const size_t red_floats = (size_t)1024 * 4 * H;
-    UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_wgrad: workspace too small");
-    float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
-    uav_ctx sub = *ctx;
-    sub.ws_bytes = ctx->ws_bytes - red_floats * sizeof(float);
     int rc;
-    // time-batched GEMMs over all N*T rows (split-K, deterministic):
-    // dW_hh[4H][H] = dG^T Hprev, Hprev = stash[..][5H:6H];  dW_ih[4H][I] = dG^T X;  db = colsum(dG)
-    if ((rc = gemm_f32(&sub, 4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H, nullptr, 0, st))) return rc;
-    if ((rc = gemm_f32(&sub, 4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I, nullptr, 0, st))) return rc;
-    if ((rc = colsum(&sub, dgates, NT, 4 * H, db, red, st))) return rc;
-    if (dx) return gemm_f32(&sub, NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I, nullptr, 0, st);
+    if (I <= 6 && (H == 64 || H == 128)) {
+        if ((rc = lstm_wgrad_fused(ctx, dgates, y, keep, h0, x, I, dheads ? y : nullptr, dheads, n_heads, N, T, H, dw_ih,
+                                   dw_hh, db, dw_head, st))) return rc;
+    } else {
+        // generic path: column sums use the tail of the workspace, the split-K slabs everything in front of it
+        UAV_REQUIRE(stash, "uav_lstm_wgrad: stash is required when I > 6");
+        const size_t red_floats = (size_t)1024 * 4 * H;
+        UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_wgrad: workspace too small");
+        float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
+        uav_ctx sub = *ctx;
+        sub.ws_bytes = ctx->ws_bytes - red_floats * sizeof(float);
+        if ((rc = gemm_f32(&sub, 4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H, nullptr, 0, st))) return rc;
+        if ((rc = gemm_f32(&sub, 4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I, nullptr, 0, st))) return rc;
+        if ((rc = colsum(&sub, dgates, NT, 4 * H, db, red, st))) return rc;
+        if (dheads && (rc = gemm_f32(&sub, n_heads, H, NT, dheads, 1, n_heads, y, H, 1, dw_head, H, nullptr, 0, st))) return rc;
+    }
+    if (dx) return gemm_f32(ctx, NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I, nullptr, 0, st);
     return 0;
 }
 

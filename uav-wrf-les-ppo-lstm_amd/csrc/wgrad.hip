@@ -1,0 +1,221 @@
+// wgrad.hip -- fused LSTM weight-gradient kernel (the time-batched "dW = dG^T [Hprev | X | 1]" GEMM).
+//
+// One pass over the per-step gate gradients dgates[N*T][4H] (written by lstm_bwd_kernel) produces
+//   dW_hh[4H][H] = dG^T Hprev,  dW_ih[4H][I] = dG^T X,  db[4H] = dG^T 1        (I <= 6, ones column)
+// and, for the top layer, dW_head[NH][H] = dheads^T Y -- instead of four generic split-K GEMMs and a
+// column-sum that each re-read dgates.  MFMA-bound (exact f32, v_mfma_f32_16x16x4_f32):
+// 2*4H*(H+16) + 2*16*H flop per (n,t) row; HBM: 4H + 2H + 8 floats read per row, once.
+//
+// Decomposition: K (= the N*T rows) is split over the grid, one contiguous row range per
+// workgroup; wave w owns gate rows [64w, 64w+64) x all H+16 columns (4 x (H/16+1) accumulator
+// tiles) plus one 16 x 16 tile of dW_head.  Row chunks of 16 are register-staged and written to a
+// double-buffered LDS image whose row strides are = 16 (mod 32) floats so both "transposed"
+// fragment reads (lane (i, kq) reads element i of row 4s+kq) are conflict-free ds_read_b32.
+// Each workgroup writes its partial slab to the context workspace; a second kernel sums the slabs
+// in a fixed order (deterministic, no float atomics).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KC = 16;          // rows per staged chunk (4 MFMA k-steps)
+
+template <int H>
+struct WG {
+    static constexpr int NW = H / 16;                 // waves (each owns 64 gate rows)
+    static constexpr int NT_ = H / 16 + 1;            // 16-column tiles of [Hprev | X,1,pad]
+    static constexpr int NC = H + 16;                 // columns of the B image
+    static constexpr int SG = 4 * H + 16;             // LDS row strides, all = 16 (mod 32)
+    static constexpr int SB = H + 16;
+    static constexpr int SY = H + 16;
+    static constexpr int SD = 48;
+    static constexpr int BUF = KC * (SG + SB + SY + SD);          // floats per LDS buffer
+    static constexpr size_t LDS = 2 * BUF * sizeof(float);
+    static constexpr size_t SLAB = (size_t)4 * H * NC + 16 * H;   // floats per workgroup partial
+};
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_wgrad_kernel(
+    const float* __restrict__ dgates, const float* __restrict__ y_prev_src, const float* __restrict__ keep,
+    const float* __restrict__ h0, const float* __restrict__ x, int I, const float* __restrict__ ytop,
+    const float* __restrict__ dheads, int NH, int N, int T, int64_t rows_per_block, float* __restrict__ slabs) {
+    using G = WG<H>;
+    constexpr int NT_ = G::NT_, SG = G::SG, SB = G::SB, SY = G::SY, SD = G::SD, BUF = G::BUF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int64_t NTr = (int64_t)N * T;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = (r_begin + rows_per_block < NTr) ? r_begin + rows_per_block : NTr;
+    const int nchunk = (r_end > r_begin) ? (int)((r_end - r_begin + KC - 1) / KC) : 0;
+
+    f32x4 acc[4][NT_];
+    f32x4 acch = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- register staging of one chunk --------------------------------------------------------
+    constexpr int GV = KC * H / (H * 4);          // float4 of dgates per thread per chunk: KC*4H/4 / (4H threads) = KC/4
+    float4 sg[GV];
+    float4 sh, sy;
+    float sx, sd;
+    // per-thread fixed coordinates inside a chunk
+    const int g_col4 = tid % H;                   // float4 column of dgates (4H/4 = H float4 per row)
+    const int g_row0 = tid / H;                   // 0..3 ; rows g_row0 + 4*i
+    const int h_row = tid / (H / 4), h_col4 = tid % (H / 4);     // KC*H/4 = 4H float4 -> exactly one per thread
+    const int s_row = tid >> 3, s_f = tid & 7;    // first 128 threads: x / dheads element (row, feature)
+
+    auto load_chunk = [&](int c) {
+        const int64_t base = r_begin + (int64_t)c * KC;
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            const int64_t r = base + g_row0 + 4 * i;
+            sg[i] = (r < r_end) ? *reinterpret_cast<const float4*>(dgates + r * (4 * H) + 4 * g_col4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        {
+            const int64_t r = base + h_row;
+            sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            sy = sh;
+            if (r < r_end) {
+                // h_prev of row (n,t): y[n][t-1] * keep[n][t], or h0[n] * keep[n][0] at t = 0
+                const int64_t n = r / T;
+                const int t = (int)(r - n * T);
+                const float kp = keep ? keep[r] : 1.f;
+                const float* src = (t == 0) ? (h0 + n * H) : (y_prev_src + (r - 1) * H);
+                const float4 v = *reinterpret_cast<const float4*>(src + 4 * h_col4);
+                sh = make_float4(v.x * kp, v.y * kp, v.z * kp, v.w * kp);
+                if (ytop) sy = *reinterpret_cast<const float4*>(ytop + r * H + 4 * h_col4);
+            }
+        }
+        sx = 0.f;
+        sd = 0.f;
+        if (tid < KC * 8) {
+            const int64_t r = base + s_row;
+            if (r < r_end) {
+                sx = (s_f < I) ? x[r * I + s_f] : (s_f == 6 ? 1.f : 0.f);      // column 6 = ones -> db
+                if (dheads && s_f < NH) sd = dheads[r * NH + s_f];
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* lg = smem + buf * BUF;
+        float* lb = lg + KC * SG;
+        float* ly = lb + KC * SB;
+        float* ld = ly + KC * SY;
+#pragma unroll
+        for (int i = 0; i < GV; ++i)
+            *reinterpret_cast<float4*>(lg + (g_row0 + 4 * i) * SG + 4 * g_col4) = sg[i];
+        *reinterpret_cast<float4*>(lb + h_row * SB + 4 * h_col4) = sh;
+        *reinterpret_cast<float4*>(ly + h_row * SY + 4 * h_col4) = sy;
+        if (tid < KC * 8) {
+            lb[s_row * SB + H + s_f] = sx;
+            lb[s_row * SB + H + 8 + s_f] = 0.f;
+            ld[s_row * SD + s_f] = sd;
+            ld[s_row * SD + 8 + s_f] = 0.f;
+        }
+    };
+
+    if (nchunk > 0) load_chunk(0);
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        store_chunk(buf);
+        __syncthreads();
+        if (c + 1 < nchunk) load_chunk(c + 1);          // global loads fly under the MFMAs below
+        const float* lg = smem + buf * BUF;
+        const float* lb = lg + KC * SG;
+        const float* ly = lb + KC * SB;
+        const float* ld = ly + KC * SY;
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            const int kr = 4 * s + kq;                   // chunk row this lane supplies
+            float a[4], b[NT_];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = lg[kr * SG + 64 * w + 16 * mi + j];
+#pragma unroll
+            for (int ni = 0; ni < NT_; ++ni) b[ni] = lb[kr * SB + 16 * ni + j];
+            const float ah = ld[kr * SD + j];
+            const float bh = ly[kr * SY + 16 * w + j];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT_; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            acch = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bh, acch, 0, 0, 0);
+        }
+    }
+    // ---- partial slab: [4H][NC] then [16][H]; C/D map row = 4*kq + r, col = j
+    float* slab = slabs + (size_t)blockIdx.x * G::SLAB;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(size_t)(64 * w + 16 * mi + 4 * kq + r) * G::NC + 16 * ni + j] = acc[mi][ni][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
+}
+
+// sum the slabs in block order and scatter into dW_hh / dW_ih / db / dW_head
+template <int H>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nb, int I, int NH,
+                                                           float* __restrict__ dw_ih, float* __restrict__ dw_hh,
+                                                           float* __restrict__ db, float* __restrict__ dw_head) {
+    using G = WG<H>;
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= G::SLAB) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += slabs[(size_t)b * G::SLAB + o];
+    const size_t gsz = (size_t)4 * H * G::NC;
+    if (o < gsz) {
+        const int m = (int)(o / G::NC), c = (int)(o % G::NC);
+        if (c < H) dw_hh[(size_t)m * H + c] = s;
+        else if (c - H < I) dw_ih[(size_t)m * I + (c - H)] = s;
+        else if (c - H == 6) db[m] = s;
+    } else if (dw_head) {
+        const int a = (int)((o - gsz) / H), uu = (int)((o - gsz) % H);
+        if (a < NH) dw_head[(size_t)a * H + uu] = s;
+    }
+}
+
+template <int H>
+static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
+                        const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T,
+                        float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st) {
+    using G = WG<H>;
+    const int64_t NTr = (int64_t)N * T;
+    int nb = ctx->num_cu;
+    const int64_t max_nb = (int64_t)(ctx->ws_bytes / (G::SLAB * sizeof(float)));
+    if (nb > max_nb) nb = (int)max_nb;
+    UAV_REQUIRE(nb >= 1, "uav_lstm_wgrad: workspace too small for one slab");
+    int64_t rpb = (NTr + nb - 1) / nb;
+    rpb = (rpb + KC - 1) / KC * KC;
+    nb = (int)((NTr + rpb - 1) / rpb);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_kernel<H>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        attr_set = true;
+    }
+    float* slabs = (float*)ctx->ws;
+    hipLaunchKernelGGL((lstm_wgrad_kernel<H>), dim3(nb), dim3(H * 4), G::LDS, st, dgates, y_prev_src, keep, h0, x, I, ytop,
+                       dheads, NH, N, T, rpb, slabs);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<H>), dim3((unsigned)((G::SLAB + 255) / 256)), dim3(256), 0, st, slabs, nb, I,
+                       NH, dw_ih, dw_hh, db, dw_head);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// fast path entry used by uav_lstm_wgrad (lstm.hip) when I <= 6 and H in {64,128}
+int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
+                     const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
+                     float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st) {
+    switch (H) {
+        case 64: return launch_wgrad<64>(ctx, dgates, y_prev_src, keep, h0, x, I, ytop, dheads, NH, N, T, dw_ih, dw_hh, db, dw_head, st);
+        case 128: return launch_wgrad<128>(ctx, dgates, y_prev_src, keep, h0, x, I, ytop, dheads, NH, N, T, dw_ih, dw_hh, db, dw_head, st);
+    }
+    uav_set_error("lstm_wgrad_fused: H=%d unsupported", H);
+    return 2;
+}

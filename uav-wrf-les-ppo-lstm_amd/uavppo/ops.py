@@ -128,7 +128,7 @@ def adv_normalise(adv, val, stats3, adv_out=None, ret_out=None):
 
 # ----------------------------------------------------------------------------- U2 / K3
 def ppo_loss(logits, value, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta,
-             loss_sums=None, dlogits=None, dvalue=None):
+             loss_sums=None, dlogits=None, dvalue=None, dhead_bias=None):
     n, A = logits.shape
     loss_sums = torch.empty(4, dtype=F64, device=logits.device) if loss_sums is None else loss_sums
     dlogits = torch.empty_like(logits) if dlogits is None else dlogits
@@ -137,7 +137,8 @@ def ppo_loss(logits, value, act, logp_old, adv, ret, val_old, inv_n, clip, ent_b
                              _p(act, I32, (n,), "act"), _p(logp_old, F32, (n,), "logp_old"),
                              _p(adv, F32, (n,), "adv"), _p(ret, F32, (n,), "ret"), _p(val_old, F32, (n,), "val_old"),
                              n, A, float(inv_n), float(clip), float(ent_beta), _p(loss_sums, F64, (4,), "loss_sums"),
-                             _p(dlogits, F32, (n, A), "dlogits"), _p(dvalue, F32, (n,), "dvalue"), _stream()),
+                             _p(dlogits, F32, (n, A), "dlogits"), _p(dvalue, F32, (n,), "dvalue"),
+                             _p(dhead_bias, F32, (A + 1,), "dhead_bias"), _stream()),
           "uav_ppo_loss")
     return loss_sums, dlogits, dvalue
 
@@ -291,8 +292,10 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
     return y, hn, cn, stash
 
 
-def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
-             dgates=None, dw_ih=None, dw_hh=None, db=None, want_dstate=True):
+def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
+             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True):
+    """BPTT sequence kernel + fused weight-gradient pass of one layer.  y, h0: the layer's forward
+    output and initial hidden state (h_prev of the weight gradient is y shifted by one step)."""
     N, T, I = x.shape
     H = w_hh.shape[1]
     dev = x.device
@@ -304,6 +307,8 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=
     dh0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
     dc0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
     nh = 0 if dheads is None else dheads.shape[-1]
+    if dheads is not None and dw_head is None:
+        dw_head = torch.empty(nh, H, dtype=F32, device=dev)
     _t = KERNEL_TIMER.bracket("lstm_bwd")
     check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
@@ -313,13 +318,17 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, dy=None, dheads=None, w_head=None, dhn=
     if _t is not None:
         _t.record()
     _t = KERNEL_TIMER.bracket("lstm_wgrad")
-    check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(stash, F32, (N, T, 6 * H), "stash"),
-                               _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"), N, T, I, H,
+    check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"), _p(h0, F32, (N, H), "h0"),
+                               _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"),
+                               _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                               _p(dheads, F32, (N, T, nh), "dheads"), nh, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
-                               _p(db, F32, (4 * H,), "db"), _p(dx), _stream()), "uav_lstm_wgrad")
+                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nh, H), "dw_head"), _p(dx), _stream()),
+          "uav_lstm_wgrad")
     if _t is not None:
         _t.record()
-    return {"dx": dx, "dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dh0": dh0, "dc0": dc0, "dgates": dgates}
+    return {"dx": dx, "dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dh0": dh0, "dc0": dc0, "dgates": dgates,
+            "dw_head": dw_head}
 
 
 def env_materialise(state, n_env, cfg, env_index, out=None):

@@ -167,29 +167,33 @@ class LSTMActorCritic(_FlatPolicy):
             y, hn, cn, stash = ops.lstm_fwd(x, keep, h0[l], c0[l], v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
                                             v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"],
                                             stash=work.get(f"stash{l}"), y=work.get(f"y{l}"))
-            saved.append((x, stash))
+            saved.append((x, stash, y, h0[l]))
             x = y
         self._saved = (saved, keep, x)
         return ops.gemm(x.view(N * T, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"],
                         out=work.get("heads"))
 
-    def backward(self, dheads, work=None):
-        """dheads [N*T, A+1] -> self.grad (flat, overwritten)."""
+    def backward(self, dheads, work=None, dhead_bias=None):
+        """dheads [N*T, A+1] -> self.grad (flat, overwritten).  dhead_bias: the column sums of dheads
+        when the loss kernel already produced them (uav_ppo_loss), else computed here."""
         saved, keep, y_last = self._saved
         N, T, H = y_last.shape
         v, g = self.views, self.grad_views
         work = work or {}
-        ops.gemm(dheads, y_last.view(N * T, H), trans_a=True, out=g["head.weight"])
-        ops.colsum(dheads, out=g["head.bias"])
+        if dhead_bias is not None:
+            g["head.bias"].copy_(dhead_bias)
+        else:
+            ops.colsum(dheads, out=g["head.bias"])
         dy = None
         for l in reversed(range(self.num_layers)):
-            x, stash = saved[l]
+            x, stash, y, h0 = saved[l]
             top = (l == self.num_layers - 1)
-            r = ops.lstm_bwd(x, keep, stash, v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
+            r = ops.lstm_bwd(x, keep, stash, v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"], y, h0,
                              dy=None if top else dy,
                              dheads=dheads.view(N, T, -1) if top else None, w_head=v["head.weight"] if top else None,
                              need_dx=(l > 0), dgates=work.get("dgates"), dw_ih=g[f"lstm.weight_ih_l{l}"],
-                             dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"], want_dstate=False)
+                             dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"],
+                             dw_head=g["head.weight"] if top else None, want_dstate=False)
             g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
             dy = r["dx"]
         self._saved = None

@@ -55,6 +55,7 @@ class VecPPOTrainer:
         self.stats3 = torch.zeros(3, dtype=torch.float64, device=d)
         self.loss_sums = torch.zeros(4, dtype=torch.float64, device=d)
         self.gnorm = torch.zeros(1, **f32)
+        self.dhead_bias = torch.zeros(6, **f32)
         self.nan_count = torch.zeros(1, dtype=torch.int32, device=d)
         P = self.policy.num_params()
         self.exp_avg = torch.zeros(P, **f32)
@@ -169,10 +170,12 @@ class VecPPOTrainer:
                 value = heads[:, 5].contiguous()
                 ops.ppo_loss(logits, value, b["act"][sl].reshape(-1), b["logp"][sl].reshape(-1),
                              self.adv_n[sl].reshape(-1), self.ret[sl].reshape(-1), b["val"][sl].reshape(-1),
-                             inv_n, hp["clip"], hp["ent_beta"], self.loss_sums, self.dlogits, self.dvalue)
+                             inv_n, hp["clip"], hp["ent_beta"], self.loss_sums, self.dlogits, self.dvalue,
+                             self.dhead_bias)
                 self.dheads[:, :5] = self.dlogits
                 self.dheads[:, 5] = self.dvalue
-                grad = self.policy.backward(self.dheads, self.work) if self.kind == "lstm" else self.policy.backward(self.dheads)
+                grad = (self.policy.backward(self.dheads, self.work, self.dhead_bias) if self.kind == "lstm"
+                        else self.policy.backward(self.dheads))
                 allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
                 self.opt_step += 1
                 ops.clip_adam(self.policy.flat, grad, self.exp_avg, self.exp_avg_sq, self.opt_step, hp["lr"],
