@@ -71,7 +71,9 @@ int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t 
  * count).  loss_sums (f64 [4], device): {sum -min(s1,s2), sum 0.5*max(.), sum entropy,
  * count of NaN probabilities}.  dlogits [n][n_act], dvalue [n] are d(total)/d(.) where
  * total = policy + value - ent_beta*entropy, each a mean over 1/inv_n samples.  dhead_bias
- * (f32 [n_act+1], or NULL): column sums of (dlogits | dvalue) = gradient of the head biases. */
+ * (f32 [n_act+1], or NULL): column sums of (dlogits | dvalue) = gradient of the head biases.
+ * Packed form: value == NULL and dvalue == NULL -> `logits` is the heads buffer [n][n_act+1]
+ * (logits | value) and `dlogits` receives d(total)/d(heads) in the same [n][n_act+1] layout. */
 int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const int32_t* act,
                  const float* logp_old, const float* adv, const float* ret, const float* val_old,
                  int64_t n, int n_act, float inv_n, float clip, float ent_beta,

@@ -39,6 +39,23 @@ static inline hipStream_t as_stream(uav_stream s) { return reinterpret_cast<hipS
 
 constexpr int WAVE = 64;
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() also waits vmcnt(0): in the
+// persistent kernels that drained the software-prefetched global loads and every outstanding
+// store at each time step (lstm_bwd: 0.84 -> 0.6 ms).  Waves of one workgroup never exchange data
+// through global memory inside these kernels, so LDS ordering is all the barrier has to give.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// LSTM gate activations: v_exp_f32 + v_rcp_f32 (1 ulp each).  A plain `1.0f / x` compiles to the
+// ~10-instruction IEEE division sequence; with 20 activations per lane per step that sequence,
+// not the MFMAs, paced the persistent kernels (tools/mfma_probe.hip).
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2/(exp(2x)+1): exact limits at +-inf, abs error ~1e-7
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+
 // ---- wave / block reductions (deterministic: fixed tree, no atomics) -------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

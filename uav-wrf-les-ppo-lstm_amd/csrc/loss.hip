@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
     const float* __restrict__ logits, const float* __restrict__ value, const int32_t* __restrict__ act,
     const float* __restrict__ logp_old, const float* __restrict__ adv, const float* __restrict__ ret,
     const float* __restrict__ val_old, int64_t n, float inv_n, float clip, float beta,
-    double* __restrict__ partial, float* __restrict__ dlogits, float* __restrict__ dvalue) {
+    double* __restrict__ partial, float* __restrict__ dlogits, float* __restrict__ dvalue, int ldl, int ldv) {
     __shared__ double sm[4];
     double s_pl = 0.0, s_vl = 0.0, s_en = 0.0, s_nan = 0.0;
     float s_db[A + 1];                       // column sums of (dlogits | dvalue) = gradient of the head biases
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float z[A], p[A];
 #pragma unroll
-        for (int k = 0; k < A; ++k) z[k] = logits[i * A + k];
+        for (int k = 0; k < A; ++k) z[k] = logits[i * ldl + k];
         softmax_row<A>(z, p);
         const int a = act[i];
         float psum = 0.f;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
         const float g_logp = clamp_open ? (-inv_n * g_ratio * ratio) : 0.f;   // dL/dlogp
 
         // value loss, train_ppo2.0.py:74-78
-        const float V = value[i], R = ret[i], vo = val_old[i];
+        const float V = value[i * ldv], R = ret[i], vo = val_old[i];
         const float dv = V - vo;
         const float vc = vo + fminf(fmaxf(dv, -clip), clip);
         const float e1 = (V - R) * (V - R), e2 = (vc - R) * (vc - R);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
         const float d1 = 2.0f * (V - R);
         const float d2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - R) : 0.f;
         const float gV = (e1 > e2) ? d1 : ((e1 < e2) ? d2 : 0.5f * (d1 + d2));
-        dvalue[i] = 0.5f * inv_n * gV;
+        dvalue[i * ldv] = 0.5f * inv_n * gV;
         s_db[A] += 0.5f * inv_n * gV;
 
         // entropy, train_ppo2.0.py:81 :  H = -sum p log(p + 1e-8)
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
         for (int k = 0; k < A; ++k) {
             const float dpol = g_logp * ((k == a ? 1.0f : 0.0f) - q[k]);
             const float dent = -beta * inv_n * p[k] * (hk[k] - ph);
-            dlogits[i * A + k] = dpol + dent;
+            dlogits[i * ldl + k] = dpol + dent;
             s_db[k] += dpol + dent;
         }
     }
@@ -194,15 +194,19 @@ int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const in
                  const float* logp_old, const float* adv, const float* ret, const float* val_old,
                  int64_t n, int n_act, float inv_n, float clip, float ent_beta, double* loss_sums,
                  float* dlogits, float* dvalue, float* dhead_bias, uav_stream stream) {
-    UAV_REQUIRE(ctx && logits && value && act && logp_old && adv && ret && val_old && loss_sums && dlogits && dvalue,
+    UAV_REQUIRE(ctx && logits && act && logp_old && adv && ret && val_old && loss_sums && dlogits,
                 "uav_ppo_loss: NULL argument");
+    // value == NULL: packed heads -- logits is [n][n_act+1] (logits | value) and dlogits the same shape
+    UAV_REQUIRE((value == nullptr) == (dvalue == nullptr), "uav_ppo_loss: value and dvalue must both be NULL (packed) or both given");
+    const int ldl = value ? n_act : n_act + 1, ldv = value ? 1 : n_act + 1;
+    if (!value) { value = logits + n_act; dvalue = dlogits + n_act; }
     UAV_REQUIRE(n > 0, "uav_ppo_loss: n=%lld", (long long)n);
     int nb = (int)((n + 255) / 256);
     if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
     double* partial = (double*)ctx->ws;
 #define LAUNCH_LOSS(A_)                                                                                  \
     hipLaunchKernelGGL(ppo_loss_kernel<A_>, dim3(nb), dim3(256), 0, as_stream(stream), logits, value,   \
-                       act, logp_old, adv, ret, val_old, n, inv_n, clip, ent_beta, partial, dlogits, dvalue)
+                       act, logp_old, adv, ret, val_old, n, inv_n, clip, ent_beta, partial, dlogits, dvalue, ldl, ldv)
     switch (n_act) {
         case 2: LAUNCH_LOSS(2); break;
         case 3: LAUNCH_LOSS(3); break;

@@ -13,6 +13,9 @@
 //     H=128): the recurrent weights are read from HBM once per launch, not once per step;
 //   * h_t goes through a double-buffered, padded LDS tile (one barrier per step), read back as
 //     conflict-free ds_read_b128 A-fragments (k is permuted so each lane reads contiguous floats);
+//   (A half-step stagger of waves 4-7 against 0-3 -- MI355X_MICROARCH "two waves per SIMD" item 9 -- was
+//    built and measured: no gain here, tools/stagger_probe.hip; what paced the step was the IEEE
+//    division sequence inside the activations, now v_rcp_f32.)
 //   * the K=I<=8 input projection rides along as two extra MFMA k-steps (x staged in LDS per
 //     32-step chunk); wider inputs (stacked layers) use a time-batched GEMM into the stash first.
 // Backward mirrors it with W_hh^T slices in VGPRs: dgates of a step are written to LDS (and to
@@ -33,12 +36,8 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 constexpr int TC = 32;      // time steps staged per chunk
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) {
-    // tanh(x) = 1 - 2/(exp(2x)+1); exact at +-inf, |err| ~ 1e-7 relative to the f32 result
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
-}
+#define sigmoidf_ fast_sigmoid
+#define tanhf_ fast_tanh
 
 template <int H>
 struct FwdGeom {
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(
             const int n = min(n0 + e, N - 1);
             kbuf[tt * MT + e] = (keep && t0 + tt < T) ? keep[(size_t)n * T + t0 + tt] : 1.f;
         }
-        __syncthreads();
+        lds_barrier();
 
         for (int tt = 0; tt < tc; ++tt) {
             const int t = t0 + tt;
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(
                         float* sp = stash + row * (6 * H);
                         sp[u] = gi; sp[H + u] = gf; sp[2 * H + u] = gg; sp[3 * H + u] = go;
                         sp[4 * H + u] = cp;
-                        sp[5 * H + u] = hin[r];
+                        if (I > 6) sp[5 * H + u] = hin[r];   // h_prev: only the generic wgrad path (I > 6) reads it
                     }
                 }
                 h_last[r] = h;
@@ -190,7 +189,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(
                 hnext[e * S + hpos<H>(u)] = hin[r];
             }
             cur ^= 1;
-            __syncthreads();
+            lds_barrier();
         }
     }
 #pragma unroll
@@ -233,17 +232,34 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
     float wt[H];
 #pragma unroll
     for (int s = 0; s < H; ++s) wt[s] = w_hh[(size_t)(kq * H + s) * H + u];
-    float whd[8];
+    // head weights as MFMA B-fragments (k = head index): dy = dheads . W_head is two MFMA k-steps whose
+    // result lands in the accumulator layout the pointwise needs (row = env, col = unit)
+    float whb[2];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) whd[a] = (dheads && a < NH) ? w_head[(size_t)a * H + u] : 0.f;
+    for (int a = 0; a < 2; ++a) whb[a] = (dheads && 4 * a + kq < NH) ? w_head[(size_t)(4 * a + kq) * H + u] : 0.f;
 
     float dh_rec[4], dc_next[4];
+    size_t srow[4];                            // stash row base of this lane's 4 env rows at t = 0
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = min(n0 + 4 * kq + r, N - 1);
         dh_rec[r] = dhn ? dhn[(size_t)n * H + u] : 0.f;
         dc_next[r] = dcn ? dcn[(size_t)n * H + u] : 0.f;
+        srow[r] = (size_t)n * T;
     }
+    // software prefetch: the stash values (and dy) of step t-1 are loaded while step t's MFMAs run,
+    // so the HBM latency never sits between two steps of the recurrence
+    float pf[4][5], pdy[4];
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* sp = stash + (srow[r] + t) * (6 * H);
+            pf[r][0] = sp[u]; pf[r][1] = sp[H + u]; pf[r][2] = sp[2 * H + u]; pf[r][3] = sp[3 * H + u];
+            pf[r][4] = sp[4 * H + u];
+            pdy[r] = dy ? dy[(srow[r] + t) * H + u] : 0.f;
+        }
+    };
+    prefetch(T - 1);
     int cur = 0;
     const int nchunk = (T + TC - 1) / TC;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
@@ -260,26 +276,21 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
             const int n = min(n0 + e, N - 1);
             kbuf[tt * MT + e] = keep ? keep[(size_t)n * T + t0 + tt] : 1.f;
         }
-        __syncthreads();
+        lds_barrier();
         for (int tt = tc - 1; tt >= 0; --tt) {
             const int t = t0 + tt;
             float* dgw = dgbuf + cur * MT * S;
+            f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
+            if (dheads) {
+                const float* dr = &dhbuf[(tt * MT + j) * 8];       // A-fragment: dheads[env j][head kq / 4+kq]
+                dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[kq], whb[0], dyacc, 0, 0, 0);
+                dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[4 + kq], whb[1], dyacc, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int e = 4 * kq + r;
-                const int n = min(n0 + e, N - 1);
-                const size_t row = (size_t)n * T + t;
-                const float* sp = stash + row * (6 * H);
-                const float gi = sp[u], gf = sp[H + u], gg = sp[2 * H + u], go = sp[3 * H + u], cp = sp[4 * H + u];
-                float dyv;
-                if (dheads) {
-                    const float* dr = &dhbuf[(tt * MT + e) * 8];
-                    dyv = 0.f;
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) dyv += dr[a] * whd[a];
-                } else {
-                    dyv = dy[row * H + u];
-                }
+                const float gi = pf[r][0], gf = pf[r][1], gg = pf[r][2], go = pf[r][3], cp = pf[r][4];
+                const float dyv = dheads ? dyacc[r] : pdy[r];
                 const float dh = dyv + dh_rec[r];
                 const float c = gf * cp + gi * gg;
                 const float tch = tanhf_(c);
@@ -295,11 +306,12 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
                 dgw[e * S + 2 * H + u] = dgg;
                 dgw[e * S + 3 * H + u] = dgo;
                 if (n0 + e < N) {
-                    float* gp = dgates + row * (4 * H);
+                    float* gp = dgates + (srow[r] + t) * (4 * H);
                     gp[u] = dgi; gp[H + u] = dgf; gp[2 * H + u] = dgg; gp[3 * H + u] = dgo;
                 }
             }
-            __syncthreads();
+            if (t > 0) prefetch(t - 1);
+            lds_barrier();
             // dh_{t-1}[env][u] = sum_k dgates[env][k] W_hh[k][u]; four independent accumulators
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
             const float* drow = dgw + j * S + kq * H;
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
             }
             cur ^= 1;
         }
-        __syncthreads();     // kbuf / dhbuf are restaged by the next chunk
+        lds_barrier();     // kbuf / dhbuf are restaged by the next chunk
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -24,11 +24,8 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
 constexpr int RMT = 16;
 constexpr float R_F32_EPS = 1.1920928955078125e-07f;
 
-__device__ __forceinline__ float r_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float r_tanh(float x) {
-    const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
-}
+#define r_sigmoid fast_sigmoid
+#define r_tanh fast_tanh
 
 template <int H>
 struct RGeom {
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
             kbuf[lane] = 1.f;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // acc = bias + h_{t-1} W_hh^T of the step about to run (gate waves)
     f32x4 acc[4];
@@ -142,7 +139,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
         }
     };
     recurrent();
-    __syncthreads();     // every wave has read h_{-1} before step 0 overwrites hbuf
+    lds_barrier();     // every wave has read h_{-1} before step 0 overwrites hbuf
 
     const int steps = T + (B.last_val ? 1 : 0);   // one extra value-only pass for V(s_T)
     for (int t = 0; t < steps; ++t) {
@@ -166,7 +163,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                 if (!value_only) { c_reg[r] = c; h_keep[r] = h; }
             }
         }
-        __syncthreads();                       // barrier 1: h_t visible
+        lds_barrier();                       // barrier 1: h_t visible
         // ---------------------------------------------------------------- phase 2 (overlapped roles)
         if (is_env_wave) {
             // heads of h_t: one MFMA chain, D[row = env][col = head]
@@ -259,7 +256,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
             }
         }
         if (!value_only && t + 1 < steps) recurrent();              // bias + h_t W_hh^T for step t+1
-        __syncthreads();                       // barrier 2: x_{t+1}, keep_{t+1} visible; recurrent reads of h_t done
+        lds_barrier();                       // barrier 2: x_{t+1}, keep_{t+1} visible; recurrent reads of h_t done
         if (!value_only) {
             // episode ended at step t: the recurrent state restarts from zero (acc rows fall back to the bias)
 #pragma unroll

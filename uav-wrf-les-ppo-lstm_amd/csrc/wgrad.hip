@@ -121,7 +121,7 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_kernel(
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
         store_chunk(buf);
-        __syncthreads();
+        lds_barrier();
         if (c + 1 < nchunk) load_chunk(c + 1);          // global loads fly under the MFMAs below
         const float* lg = smem + buf * BUF;
         const float* lb = lg + KC * SG;

@@ -157,6 +157,17 @@ def policy_sample(logits, u=None, seed=0, counter=0, forced_act=None, want_probs
     return act, logp, probs, nan_count
 
 
+def ppo_loss_heads(heads, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta, loss_sums, dheads, dhead_bias=None):
+    """Packed form of ppo_loss: heads [n, A+1] (logits | value) in, dheads [n, A+1] out -- no split/concat copies."""
+    n, A1 = heads.shape
+    check(lib().uav_ppo_loss(_h(heads), _p(heads, F32, (n, A1), "heads"), None, _p(act, I32, (n,), "act"),
+                             _p(logp_old, F32, (n,), "logp_old"), _p(adv, F32, (n,), "adv"), _p(ret, F32, (n,), "ret"),
+                             _p(val_old, F32, (n,), "val_old"), n, A1 - 1, float(inv_n), float(clip), float(ent_beta),
+                             _p(loss_sums, F64, (4,), "loss_sums"), _p(dheads, F32, (n, A1), "dheads"), None,
+                             _p(dhead_bias, F32, (A1,), "dhead_bias"), _stream()), "uav_ppo_loss")
+    return loss_sums, dheads
+
+
 # ----------------------------------------------------------------------------- U3
 def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.5,
               gnorm_out=None):

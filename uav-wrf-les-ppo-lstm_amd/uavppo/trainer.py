@@ -87,8 +87,6 @@ class VecPPOTrainer:
             self.work = {"stash": torch.empty(nb * T * (2 * 256 + 2 * 128 + 2), **f32)}
             self._mlp_tmp = {"rew": torch.zeros(N, **f32), "done": torch.zeros(N, **f32),
                              "flags": torch.zeros(N, dtype=torch.uint8, device=d), "stash": None}
-        self.dlogits = torch.empty((N // self.num_minibatches) * T, 5, **f32)
-        self.dvalue = torch.empty((N // self.num_minibatches) * T, **f32)
         self.dheads = torch.empty((N // self.num_minibatches) * T, 6, **f32)
         self.reset()
 
@@ -166,14 +164,9 @@ class VecPPOTrainer:
                                               self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work)
                 else:
                     heads = self.policy.heads(b["obs"][sl].reshape(nb * T, 6), stash=self.work["stash"])
-                logits = heads[:, :5].contiguous()
-                value = heads[:, 5].contiguous()
-                ops.ppo_loss(logits, value, b["act"][sl].reshape(-1), b["logp"][sl].reshape(-1),
-                             self.adv_n[sl].reshape(-1), self.ret[sl].reshape(-1), b["val"][sl].reshape(-1),
-                             inv_n, hp["clip"], hp["ent_beta"], self.loss_sums, self.dlogits, self.dvalue,
-                             self.dhead_bias)
-                self.dheads[:, :5] = self.dlogits
-                self.dheads[:, 5] = self.dvalue
+                ops.ppo_loss_heads(heads, b["act"][sl].reshape(-1), b["logp"][sl].reshape(-1),
+                                   self.adv_n[sl].reshape(-1), self.ret[sl].reshape(-1), b["val"][sl].reshape(-1),
+                                   inv_n, hp["clip"], hp["ent_beta"], self.loss_sums, self.dheads, self.dhead_bias)
                 grad = (self.policy.backward(self.dheads, self.work, self.dhead_bias) if self.kind == "lstm"
                         else self.policy.backward(self.dheads))
                 allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
