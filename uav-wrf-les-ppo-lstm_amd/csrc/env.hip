@@ -30,6 +30,7 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
     P.env_offset = cfg->env_offset;
     P.max_steps = (cfg->variant == UAV_ENV_V11) ? 5000 : 1000;           // config.py:7
     P.radius = cfg->radius;
+    P.reach_bonus = fmin(500.0, 150.0 * (50.0 / cfg->radius));
     P.bonus = cfg->bonus;
     P.clip_hi = (cfg->variant == UAV_ENV_V11) ? (500.0 - 1e-6) : 499.0;  // environment.py:105
     const double sigma = (cfg->variant == UAV_ENV_V21) ? 15.0 : (500.0 / 16.0);

@@ -19,6 +19,7 @@ struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived c
     int variant, field_mode, n_fields, bonus_is_f64;
     int n_env_total, env_offset, max_steps, pad_;
     double radius, bonus, clip_hi, two_sigma2;
+    double reach_bonus;       // min(500, 150*(50/radius)), environment.py:151 -- a per-launch constant
     uint64_t seed;
     const double* bank;       // [F][GRID][GRID][2]
     const double* bank_src;   // [F][2]
@@ -29,7 +30,7 @@ struct EnvState {             // registers of one env
     float px, py;             // agent_pos (f32 after the first step; (0,0) at reset)
     double sx, sy;            // source_pos
     int steps, episode;
-    double conc, tke;         // field at the cell of the f32 position (what _get_obs / prev_conc read)
+    double conc, tke;         // conc = field/100 (the value obs[2] and prev_conc both use), tke = raw field
 };
 
 // SoA view of the caller-owned state blob
@@ -107,17 +108,18 @@ __device__ __forceinline__ void field_at(const EnvParams& P, int env_global, con
     conc = c < 0.0 ? 0.0 : (c > 100.0 ? 100.0 : c);                                  // :61
 }
 
-// E5 with the field values of the f32 cell already in s.conc / s.tke
+// E5 with the field values of the f32 cell already in s.conc (= conc/100) and s.tke
 __device__ __forceinline__ void env_obs(const EnvParams& P, const EnvState& s, const unsigned short* vis, float* o) {
     const int x = clipi((int)s.px), y = clipi((int)s.py);
     const int vc = vis[(x / CELL) * CELLS + (y / CELL)];
-    const double lvl = fmin((double)vc / 5.0, 1.0);
+    // min(vc/5.0, 1.0) rounded to f32: the six possible values are constants
+    const float lvl = vc >= 5 ? 1.0f : (vc == 4 ? 0.8f : (vc == 3 ? 0.6f : (vc == 2 ? 0.4f : (vc == 1 ? 0.2f : 0.0f))));
     o[0] = s.px / 500.0f;                           // f32 / weak int (environment.py:74)
     o[1] = s.py / 500.0f;
-    o[2] = (float)(s.conc / 100.0);
+    o[2] = (float)s.conc;
     o[3] = (float)(s.tke / 9.0);
     o[4] = (float)((double)s.steps / (double)P.max_steps);
-    o[5] = (float)lvl;
+    o[5] = lvl;
 }
 
 // E2: start episode s.episode of env `env_global`
@@ -135,7 +137,9 @@ __device__ __forceinline__ void env_begin_episode(const EnvParams& P, int env_gl
     s.py = 0.f;
     s.steps = 0;
     for (int k = 0; k < NVIS; ++k) vis[k] = 0;
-    field_at(P, env_global, s, 0, 0, s.conc, s.tke);
+    double c;
+    field_at(P, env_global, s, 0, 0, c, s.tke);
+    s.conc = c / 100.0;
 }
 
 struct StepOut {
@@ -149,12 +153,12 @@ struct StepOut {
 __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global, EnvState& s, unsigned short* vis,
                                               int action, double z0, double z1, StepOut& out) {
     s.steps += 1;
-    const double prev_conc = s.conc / 100.0;                          // :86-88 (cell of the f32 position)
+    const double prev_conc = s.conc;                                  // :86-88 (cell of the f32 position), already /100
     constexpr double MOVE = GRID * 0.05;                              // :91
     double dx = 0.0, dy = 0.0;
     if (action == 1) dy = MOVE; else if (action == 2) dy = -MOVE; else if (action == 3) dx = MOVE; else if (action == 4) dx = -MOVE;
     const double norm_d = (action == 0) ? 0.0 : MOVE;
-    const double move_pen = -0.15 * (1.0 - norm_d / MOVE);            // :94-95
+    const double move_pen = (action == 0) ? -0.15 : -0.0;            // -0.15*(1 - |d|/25), :94-95
     const double k = (MOVE * 0.2);
     const double tx = k * (z0 * s.tke / 9.0), ty = k * (z1 * s.tke / 9.0);   // :100-101
     double nx = ((double)s.px + dx) + tx, ny = ((double)s.py + dy) + ty;    // :104
@@ -166,20 +170,27 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
     // field at the new f32 cell (obs, next prev_conc) and at the f64 cell (gradient) -- they differ
     // only when the f32 rounding crosses an integer
     const int fx = clipi((int)s.px), fy = clipi((int)s.py);
-    field_at(P, env_global, s, fx, fy, s.conc, s.tke);
+    double craw;
+    field_at(P, env_global, s, fx, fy, craw, s.tke);
+    s.conc = craw / 100.0;
     const int cx = clipi((int)nx), cy = clipi((int)ny);
-    double cur = s.conc, dummy;
-    if (cx != fx || cy != fy) field_at(P, env_global, s, cx, cy, cur, dummy);
-    const double grad = (cur / 100.0 - prev_conc) / (norm_d + 1e-6);  // :109-112
-    const double bdist = fmin(fmin(nx / 500.0, (500.0 - nx) / 500.0), fmin(ny / 500.0, (500.0 - ny) / 500.0));
+    double cur = s.conc;
+    if (cx != fx || cy != fy) {
+        double dummy;
+        field_at(P, env_global, s, cx, cy, craw, dummy);
+        cur = craw / 100.0;
+    }
+    const double grad = (cur - prev_conc) / (norm_d + 1e-6);          // :109-112
+    // min(nx/500, (500-nx)/500, ny/500, (500-ny)/500): a correctly rounded division by a positive constant is
+    // monotonic, so dividing the minimum gives the identical double (:114-119)
+    const double bdist = fmin(fmin(nx, 500.0 - nx), fmin(ny, 500.0 - ny)) / 500.0;
     double bpen = 0.0;
     if (bdist < 0.15 && grad < -0.01) {
         const double t = 0.15 - bdist;
         bpen = -0.1 * (t * t);                                        // :121-124
     }
-    int gx = (int)floor(nx / (double)CELL), gy = (int)floor(ny / (double)CELL);   // :127-128 (f64 position, `//`)
-    if ((double)gx * CELL > nx) gx -= 1;      // exact floor even when the quotient rounds up to an integer
-    if ((double)gy * CELL > ny) gy -= 1;
+    // int(nx // 50) for 0 <= nx < 500: floor(nx/50) == floor(floor(nx)/50), integer arithmetic (:127-128)
+    const int gx = (int)nx / CELL, gy = (int)ny / CELL;
     const int vi = gx * CELLS + gy;
     const int vc = (int)vis[vi] + 1;
     vis[vi] = (unsigned short)vc;                                     // :129-130
@@ -203,7 +214,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
     const double ddx = (double)s.px - s.sx, ddy = (double)s.py - s.sy;
     const double dist = sqrt(ddx * ddx + ddy * ddy);                  // :148
     out.reached = dist <= P.radius;
-    if (out.reached) total = total + fmin(500.0, 150.0 * (50.0 / P.radius));   // :150-151
+    if (out.reached) total = total + P.reach_bonus;                   // :150-151
     out.done = (s.steps >= P.max_steps) || out.reached;              // :153
     out.reward = total;
     out.info[0] = (double)conc_r;

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     __shared__ float hd[RMT * 16];
     __shared__ __attribute__((aligned(16))) float wbuf[16 * S];   // head weights, row = head, padded like an h row
     __shared__ unsigned short vis[RMT * NVIS];
-    __shared__ EnvState es_s[RMT];                                // env registers parked in LDS between steps
+    __shared__ EnvState es_s[RMT];
+    __shared__ float trs[2 * RMT * 8];                            // parked transitions (see the env block)                                // env registers parked in LDS between steps
 
     const float* w_ih = params;
     const float* w_hh = w_ih + 4 * H * I;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
         // ---------------------------------------------------------------- phase 2 (overlapped roles)
         if (is_env_wave) {
             // heads of h_t: one MFMA chain, D[row = env][col = head]
-            f32x4 ha = {0.f, 0.f, 0.f, 0.f};
+            // four independent accumulation chains (a 16x16x4 f32 MFMA has a 40-cycle dependent latency)
+            f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb2 = ha, hc2 = ha, hd2 = ha;
             const float* hrow = hbuf + j * S + kq * SEG;
             const float* wrow = wbuf + j * S + kq * SEG;
 #pragma unroll
@@ -175,10 +177,11 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                 const float4 a = *reinterpret_cast<const float4*>(hrow + s);
                 const float4 b = *reinterpret_cast<const float4*>(wrow + s);
                 ha = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, ha, 0, 0, 0);
-                ha = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, ha, 0, 0, 0);
-                ha = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, ha, 0, 0, 0);
-                ha = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, ha, 0, 0, 0);
+                hb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, hb2, 0, 0, 0);
+                hc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, hc2, 0, 0, 0);
+                hd2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, hd2, 0, 0, 0);
             }
+            ha = (ha + hb2) + (hc2 + hd2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) hd[(4 * kq + r) * 16 + j] = ha[r];
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the hd tile is written (single wave)
@@ -232,17 +235,21 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     else env_step_noise(P, eg, es, z0, z1);
                     StepOut so;
                     env_step_core(P, eg, es, myvis, a_sel, z0, z1, so);
-                    if (env_lane) {
+                    // park the transition in LDS; the global stores are issued at the very end of the env block so
+                    // that no later scratch reload / load wait (vmcnt counts stores too) stalls on their HBM acks
+                    float* tr = trs + lane * 8;
+                    tr[0] = __int_as_float(a_sel);
+                    tr[1] = (float)so.reward;
+                    tr[2] = V;
+                    tr[3] = lp;
+                    tr[4] = so.done ? 1.f : 0.f;
+                    tr[5] = __int_as_float((so.done ? 1 : 0) | (so.reached ? 2 : 0));
+                    tr[6] = kbuf[lane];
+                    float ob_old[6];
 #pragma unroll
-                        for (int f = 0; f < 6; ++f) B.obs[row * 6 + f] = xbuf[lane * 8 + f];
-                        B.act[row] = a_sel;
-                        B.rew[row] = (float)so.reward;
-                        B.val[row] = V;
-                        B.logp[row] = lp;
-                        B.done[row] = so.done ? 1.f : 0.f;
-                        B.flags[row] = (uint8_t)((so.done ? 1 : 0) | (so.reached ? 2 : 0));
-                        B.keep[row] = kbuf[lane];
-                    }
+                    for (int f = 0; f < 6; ++f) ob_old[f] = xbuf[lane * 8 + f];
+#pragma unroll
+                    for (int f = 0; f < 6; ++f) trs[RMT * 8 + lane * 8 + f] = ob_old[f];
                     if (so.done) {
                         es.episode += 1;
                         env_begin_episode(P, eg, es, myvis);
@@ -252,6 +259,18 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     for (int f = 0; f < 6; ++f) xbuf[lane * 8 + f] = so.obs[f];
                     es_s[lane] = es;
                     kbuf[lane] = so.done ? 0.f : 1.f;
+                    if (env_lane) {
+                        const float* tq = trs + lane * 8;
+#pragma unroll
+                        for (int f = 0; f < 6; ++f) B.obs[row * 6 + f] = trs[RMT * 8 + lane * 8 + f];
+                        B.act[row] = __float_as_int(tq[0]);
+                        B.rew[row] = tq[1];
+                        B.val[row] = tq[2];
+                        B.logp[row] = tq[3];
+                        B.done[row] = tq[4];
+                        B.flags[row] = (uint8_t)__float_as_int(tq[5]);
+                        B.keep[row] = tq[6];
+                    }
                 }
             }
         }
