@@ -152,16 +152,24 @@ def main():
     env_steps = N * T * world * args.steps
     value = env_steps / dt
     opt_steps = tr.hp["epochs"] * tr.num_minibatches
-    # roofline of the dominant kernel (BPTT sequence kernel): algorithmic flops of the dh = dgates W_hh
-    # product per launch (N*T*2*4H*H; SURVEY 8d's per-env-step LSTM figure restricted to this kernel)
+    # roofline of the dominant kernel (the BPTT sequence kernel): algorithmic flops of its dh = dgates W_hh
+    # product per launch (N*T*2*4H*H; SURVEY 8d's per-env-step LSTM figure restricted to this kernel) over
+    # its average duration, timed live with HIP events on the launch stream.  `traffic` = HBM bytes per
+    # launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), measured at
+    # this very shape and stored under profiles/ (a profiler cannot run inside the timed region).
     fl_bwd = N * T * 2 * 4 * H * H
     bwd = timers.get("lstm_bwd")
     roofline = None
     if bwd:
         ach = fl_bwd / (bwd["avg_ms"] * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+        if args.config == "c3" and os.path.exists(tf):
+            traffic = json.load(open(tf)).get("lstm_bwd_kernel<128>", {}).get("hbm_total_bytes")
         roofline = {"kernel": "lstm_bwd_kernel<%d>" % H, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                    "avg_ms": bwd["avg_ms"], "launches": bwd["n"]}
+                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                    "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
+                    "hbm_GBps_of_traffic": (traffic / (bwd["avg_ms"] * 1e-3) / 1e9) if traffic else None}
     out = {
         "metric": f"env-steps/sec (rollout + GAE + {tr.hp['epochs']}-epoch PPO update), {N} envs x {T} T per GPU, LSTM h={H}",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

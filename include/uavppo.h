@@ -80,6 +80,15 @@ int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const in
                  double* loss_sums, float* dlogits, float* dvalue, float* dhead_bias,
                  uav_stream stream);
 
+/* U2 with the actor/critic heads fused in: heads = y W_head^T + b_head is formed by MFMA straight
+ * from the policy trunk's output y [n][hidden] (the LSTM's y), never written to HBM; outputs as the
+ * packed form above (dheads [n][n_act+1]).  w_head [n_act+1][hidden], b_head [n_act+1]. */
+int uav_ppo_loss_from_y(uav_ctx* ctx, const float* y, const float* w_head, const float* b_head,
+                        const int32_t* act, const float* logp_old, const float* adv, const float* ret,
+                        const float* val_old, int64_t n, int hidden, int n_act, float inv_n, float clip,
+                        float ent_beta, double* loss_sums, float* dheads, float* dhead_bias,
+                        uav_stream stream);
+
 /* ---- K3 (sampling part): softmax + Categorical sample + log_prob + NaN check
  * (train_ppo2.0.py:161-163,189; torch Categorical(probs) semantics).  u: uniforms in [0,1)
  * [n] or NULL to use the counter RNG (seed, counter).  forced_act: i32 [n] or NULL; when

@@ -251,3 +251,26 @@ def test_mlp_forward_golden(ops, golden):
     probs = torch.softmax(heads[:, :5], -1).cpu().numpy()
     assert np.allclose(probs, g["fwd_probs"], atol=1e-6)
     assert np.allclose(heads[:, 5:].cpu().numpy(), g["fwd_value"], atol=5e-6)
+
+
+@pytest.mark.parametrize("n,H", [(64, 64), (300, 128), (5000, 128), (1000, 256)])
+def test_ppo_loss_fused_heads_equals_unfused(ops, n, H):
+    """uav_ppo_loss_from_y (heads by MFMA inside the loss kernel) == heads GEMM + uav_ppo_loss."""
+    rng = np.random.RandomState(n + H)
+    y = rng.randn(n, H).astype(np.float32)
+    w = (rng.randn(6, H) * 0.2).astype(np.float32)
+    b = (rng.randn(6) * 0.1).astype(np.float32)
+    _, value, act, lpo, adv, ret, vo = _loss_inputs(n, n)
+    heads = (y.astype(np.float64) @ w.T.astype(np.float64) + b).astype(np.float32)
+    s1 = torch.empty(4, dtype=torch.float64, device=DEV)
+    d1 = torch.empty(n, 6, device=DEV)
+    db1 = torch.empty(6, device=DEV)
+    ops.ppo_loss_heads(dev(heads), dev(act), dev(lpo), dev(adv), dev(ret), dev(vo), 1.0 / n, 0.2, 0.01, s1, d1, db1)
+    s2 = torch.empty(4, dtype=torch.float64, device=DEV)
+    d2 = torch.empty(n, 6, device=DEV)
+    db2 = torch.empty(6, device=DEV)
+    ops.ppo_loss_from_y(dev(y), dev(w), dev(b), dev(act), dev(lpo), dev(adv), dev(ret), dev(vo), 1.0 / n, 0.2, 0.01, s2, d2, db2)
+    assert np.allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    assert np.allclose(d2.cpu().numpy(), d1.cpu().numpy(), rtol=2e-4, atol=1e-6 / n)
+    assert np.allclose(db2.cpu().numpy(), db1.cpu().numpy(), rtol=1e-3, atol=1e-6)
+    assert np.allclose(db2.cpu().numpy(), d2.cpu().numpy().sum(0), rtol=1e-3, atol=1e-6)

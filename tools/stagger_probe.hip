@@ -45,10 +45,10 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ w, float*
     auto pw = [&](float* hnext) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float gi = 1.f / (1.f + __expf(-acc[0][r])), gf = 1.f / (1.f + __expf(-acc[1][r]));
-            const float gg = 1.f - 2.f / (__expf(2.f * acc[2][r]) + 1.f), go = 1.f / (1.f + __expf(-acc[3][r]));
+            const float gi = __builtin_amdgcn_rcpf(1.f + __expf(-acc[0][r])), gf = __builtin_amdgcn_rcpf(1.f + __expf(-acc[1][r]));
+            const float gg = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * acc[2][r]) + 1.f), go = __builtin_amdgcn_rcpf(1.f + __expf(-acc[3][r]));
             c[r] = gf * c[r] + gi * gg;
-            const float h = go * (1.f - 2.f / (__expf(2.f * c[r]) + 1.f));
+            const float h = go * (1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * c[r]) + 1.f));
             hnext[(4 * kq + r) * S + (u / 16) * SEG + (u % 16)] = h;
         }
     };

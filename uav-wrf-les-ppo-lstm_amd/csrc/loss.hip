@@ -27,92 +27,80 @@ __device__ __forceinline__ void softmax_row(const float* z, float* p) {
 constexpr int LOSS_BLOCKS = 1024;
 constexpr int LOSS_PSTRIDE = 16;   // doubles per block partial: 4 loss sums + up to 9 head-bias sums
 
+struct LossAcc { double pl, vl, en, nan; };
+
+// one sample: loss terms into `acc`, d(total)/d(logits) into dz[A], d(total)/dV returned
 template <int A>
-__global__ __launch_bounds__(256) void ppo_loss_kernel(
-    const float* __restrict__ logits, const float* __restrict__ value, const int32_t* __restrict__ act,
-    const float* __restrict__ logp_old, const float* __restrict__ adv, const float* __restrict__ ret,
-    const float* __restrict__ val_old, int64_t n, float inv_n, float clip, float beta,
-    double* __restrict__ partial, float* __restrict__ dlogits, float* __restrict__ dvalue, int ldl, int ldv) {
-    __shared__ double sm[4];
-    double s_pl = 0.0, s_vl = 0.0, s_en = 0.0, s_nan = 0.0;
-    float s_db[A + 1];                       // column sums of (dlogits | dvalue) = gradient of the head biases
+__device__ __forceinline__ float ppo_sample(const float* z, float V, int a, float lpo, float Ad, float R, float vo,
+                                            float inv_n, float clip, float beta, LossAcc& acc, float* dz) {
+    float p[A];
+    softmax_row<A>(z, p);
+    float psum = 0.f;
+    bool bad = false;
 #pragma unroll
-    for (int k = 0; k <= A; ++k) s_db[k] = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float z[A], p[A];
-#pragma unroll
-        for (int k = 0; k < A; ++k) z[k] = logits[i * ldl + k];
-        softmax_row<A>(z, p);
-        const int a = act[i];
-        float psum = 0.f;
-        bool bad = false;
-#pragma unroll
-        for (int k = 0; k < A; ++k) {
-            psum += p[k];
-            bad |= (p[k] != p[k]);
-        }
-        if (bad) s_nan += 1.0;
-        // Categorical(probs): q = p / sum p, clamped to [eps, 1-eps]
-        float q[A];
-        float qa = 0.f, pa = 0.f;
-#pragma unroll
-        for (int k = 0; k < A; ++k) {
-            q[k] = p[k] / psum;
-            if (k == a) { qa = q[k]; pa = p[k]; }
-        }
-        (void)pa;
-        const bool clamp_open = (qa >= F32_EPS) && (qa <= 1.0f - F32_EPS);
-        const float qc = fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS);
-        const float logp = logf(qc);
-        const float ratio = expf(logp - logp_old[i]);
-        const float Ad = adv[i];
-        const float lo = 1.0f - clip, hi = 1.0f + clip;
-        const float rc = fminf(fmaxf(ratio, lo), hi);
-        const float s1 = ratio * Ad, s2 = rc * Ad;
-        s_pl += (double)(-fminf(s1, s2));
-        const bool in_rng = (ratio >= lo) && (ratio <= hi);
-        // torch.min backward: ties split 1/2 - 1/2; clamp backward passes inside [lo,hi]
-        float g_ratio;
-        if (s1 < s2) g_ratio = Ad;
-        else if (s1 == s2) g_ratio = 0.5f * Ad + (in_rng ? 0.5f * Ad : 0.f);
-        else g_ratio = in_rng ? Ad : 0.f;
-        const float g_logp = clamp_open ? (-inv_n * g_ratio * ratio) : 0.f;   // dL/dlogp
-
-        // value loss, train_ppo2.0.py:74-78
-        const float V = value[i * ldv], R = ret[i], vo = val_old[i];
-        const float dv = V - vo;
-        const float vc = vo + fminf(fmaxf(dv, -clip), clip);
-        const float e1 = (V - R) * (V - R), e2 = (vc - R) * (vc - R);
-        s_vl += (double)(0.5f * fmaxf(e1, e2));
-        const float d1 = 2.0f * (V - R);
-        const float d2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - R) : 0.f;
-        const float gV = (e1 > e2) ? d1 : ((e1 < e2) ? d2 : 0.5f * (d1 + d2));
-        dvalue[i * ldv] = 0.5f * inv_n * gV;
-        s_db[A] += 0.5f * inv_n * gV;
-
-        // entropy, train_ppo2.0.py:81 :  H = -sum p log(p + 1e-8)
-        float Hs = 0.f, hk[A], ph = 0.f;
-#pragma unroll
-        for (int k = 0; k < A; ++k) {
-            const float lg = logf(p[k] + 1e-8f);
-            Hs -= p[k] * lg;
-            hk[k] = -lg - p[k] / (p[k] + 1e-8f);      // dH/dp_k
-            ph += p[k] * hk[k];
-        }
-        s_en += (double)Hs;
-        // through the softmax: d/dz_k = p_k (g_k - sum_j p_j g_j)
-#pragma unroll
-        for (int k = 0; k < A; ++k) {
-            const float dpol = g_logp * ((k == a ? 1.0f : 0.0f) - q[k]);
-            const float dent = -beta * inv_n * p[k] * (hk[k] - ph);
-            dlogits[i * ldl + k] = dpol + dent;
-            s_db[k] += dpol + dent;
-        }
+    for (int k = 0; k < A; ++k) {
+        psum += p[k];
+        bad |= (p[k] != p[k]);
     }
-    s_pl = block256_sum(s_pl, sm);
-    s_vl = block256_sum(s_vl, sm);
-    s_en = block256_sum(s_en, sm);
-    s_nan = block256_sum(s_nan, sm);
+    if (bad) acc.nan += 1.0;
+    // Categorical(probs): q = p / sum p, clamped to [eps, 1-eps]
+    float q[A];
+    float qa = 0.f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        q[k] = p[k] / psum;
+        if (k == a) qa = q[k];
+    }
+    const bool clamp_open = (qa >= F32_EPS) && (qa <= 1.0f - F32_EPS);
+    const float qc = fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS);
+    const float logp = logf(qc);
+    const float ratio = expf(logp - lpo);
+    const float lo = 1.0f - clip, hi = 1.0f + clip;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = ratio * Ad, s2 = rc * Ad;
+    acc.pl += (double)(-fminf(s1, s2));
+    const bool in_rng = (ratio >= lo) && (ratio <= hi);
+    // torch.min backward: ties split 1/2 - 1/2; clamp backward passes inside [lo,hi]
+    float g_ratio;
+    if (s1 < s2) g_ratio = Ad;
+    else if (s1 == s2) g_ratio = 0.5f * Ad + (in_rng ? 0.5f * Ad : 0.f);
+    else g_ratio = in_rng ? Ad : 0.f;
+    const float g_logp = clamp_open ? (-inv_n * g_ratio * ratio) : 0.f;   // dL/dlogp
+
+    // value loss, train_ppo2.0.py:74-78
+    const float dv = V - vo;
+    const float vc = vo + fminf(fmaxf(dv, -clip), clip);
+    const float e1 = (V - R) * (V - R), e2 = (vc - R) * (vc - R);
+    acc.vl += (double)(0.5f * fmaxf(e1, e2));
+    const float d1 = 2.0f * (V - R);
+    const float d2 = (dv >= -clip && dv <= clip) ? 2.0f * (vc - R) : 0.f;
+    const float gV = (e1 > e2) ? d1 : ((e1 < e2) ? d2 : 0.5f * (d1 + d2));
+
+    // entropy, train_ppo2.0.py:81 :  H = -sum p log(p + 1e-8)
+    float Hs = 0.f, hk[A], ph = 0.f;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        const float lg = logf(p[k] + 1e-8f);
+        Hs -= p[k] * lg;
+        hk[k] = -lg - p[k] / (p[k] + 1e-8f);      // dH/dp_k
+        ph += p[k] * hk[k];
+    }
+    acc.en += (double)Hs;
+    // through the softmax: d/dz_k = p_k (g_k - sum_j p_j g_j)
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        const float dpol = g_logp * ((k == a ? 1.0f : 0.0f) - q[k]);
+        const float dent = -beta * inv_n * p[k] * (hk[k] - ph);
+        dz[k] = dpol + dent;
+    }
+    return 0.5f * inv_n * gV;
+}
+
+template <int A>
+__device__ __forceinline__ void loss_block_epilogue(const LossAcc& a, const float* s_db, double* partial) {
+    __shared__ double sm[4];
+    const double s_pl = block256_sum(a.pl, sm), s_vl = block256_sum(a.vl, sm);
+    const double s_en = block256_sum(a.en, sm), s_nan = block256_sum(a.nan, sm);
     double dbs[A + 1];
 #pragma unroll
     for (int k = 0; k <= A; ++k) dbs[k] = block256_sum((double)s_db[k], sm);
@@ -122,6 +110,124 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(
 #pragma unroll
         for (int k = 0; k <= A; ++k) pp[4 + k] = dbs[k];
     }
+}
+
+template <int A>
+__global__ __launch_bounds__(256) void ppo_loss_kernel(
+    const float* __restrict__ logits, const float* __restrict__ value, const int32_t* __restrict__ act,
+    const float* __restrict__ logp_old, const float* __restrict__ adv, const float* __restrict__ ret,
+    const float* __restrict__ val_old, int64_t n, float inv_n, float clip, float beta,
+    double* __restrict__ partial, float* __restrict__ dlogits, float* __restrict__ dvalue, int ldl, int ldv) {
+    LossAcc acc{0.0, 0.0, 0.0, 0.0};
+    float s_db[A + 1];                       // column sums of (dlogits | dvalue) = gradient of the head biases
+#pragma unroll
+    for (int k = 0; k <= A; ++k) s_db[k] = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float z[A], dz[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k) z[k] = logits[i * ldl + k];
+        const float dV = ppo_sample<A>(z, value[i * ldv], act[i], logp_old[i], adv[i], ret[i], val_old[i], inv_n, clip,
+                                       beta, acc, dz);
+        dvalue[i * ldv] = dV;
+        s_db[A] += dV;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            dlogits[i * ldl + k] = dz[k];
+            s_db[k] += dz[k];
+        }
+    }
+    loss_block_epilogue<A>(acc, s_db, partial);
+}
+
+// ---- heads fused into the loss: heads = y W_head^T + b_head by MFMA straight from the LSTM output ----
+// One wave = 64 samples (4 m-tiles of 16).  Each 16-row tile of y is loaded with fully coalesced
+// float4 reads into a padded per-wave LDS tile (fragment-shaped loads straight from global touch 64
+// cache lines per instruction and thrash L1: 241 us vs the HBM-bound ~60 us), A-fragments are then
+// conflict-free ds_read_b128 (k permuted as in lstm.hip), B-fragments of W_head come from LDS too; the
+// 16x16 result tiles are transposed through LDS so that lane l owns sample l, then the same per-sample
+// loss math runs.  `heads` is never written to HBM and the separate heads GEMM disappears.
+typedef float f32x4_l __attribute__((ext_vector_type(4)));
+template <int A, int H>
+__global__ __launch_bounds__(256) void ppo_loss_from_y_kernel(
+    const float* __restrict__ y, const float* __restrict__ w_head, const float* __restrict__ b_head,
+    const int32_t* __restrict__ act, const float* __restrict__ logp_old, const float* __restrict__ adv,
+    const float* __restrict__ ret, const float* __restrict__ val_old, int64_t n, float inv_n, float clip, float beta,
+    double* __restrict__ partial, float* __restrict__ dheads) {
+    constexpr int KS = H / 4, SEG = KS + 4, S = 4 * SEG + 8, NH = A + 1;
+    __shared__ __attribute__((aligned(16))) float wbuf[16 * S];
+    __shared__ __attribute__((aligned(16))) float ybuf[4][16 * S];   // per wave: one 16-row tile of y
+    __shared__ float hd[4][64 * 9];                 // per wave: 64 samples x 8 heads (row padded to 9)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+    for (int idx = threadIdx.x; idx < 16 * H; idx += 256) {
+        const int hdx = idx / H, uu = idx % H;
+        wbuf[hdx * S + (uu / KS) * SEG + (uu % KS)] = (hdx < NH) ? w_head[(size_t)hdx * H + uu] : 0.f;
+    }
+    __syncthreads();
+    LossAcc acc{0.0, 0.0, 0.0, 0.0};
+    float s_db[A + 1];
+#pragma unroll
+    for (int k = 0; k <= A; ++k) s_db[k] = 0.f;
+    float bh[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) bh[k] = b_head[k];
+    const int64_t ntile = (n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t row0 = tile * 256 + w * 64;
+        f32x4_l c4[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            // coalesced tile load: 16 rows x H floats = 16*H/4 float4, 64 lanes -> H/16 float4 per lane
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < H / 16; ++i) {
+                const int idx = i * 64 + lane, row = idx / (H / 4), c = idx % (H / 4);
+                const int64_t r = row0 + 16 * mi + row;
+                const float4 v = *reinterpret_cast<const float4*>(y + (r < n ? r : n - 1) * H + 4 * c);
+                *reinterpret_cast<float4*>(&ybuf[w][row * S + ((4 * c) / KS) * SEG + (4 * c) % KS]) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): tile written (single wave, LDS in order)
+            __builtin_amdgcn_wave_barrier();
+            const float* yr = &ybuf[w][j * S + kq * SEG];
+            f32x4_l a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+            const float* wr = wbuf + j * S + kq * SEG;
+#pragma unroll
+            for (int s = 0; s < KS; s += 4) {
+                const float4 av = *reinterpret_cast<const float4*>(yr + s);
+                const float4 bv = *reinterpret_cast<const float4*>(wr + s);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, a1, 0, 0, 0);
+            }
+            c4[mi] = a0 + a1;
+        }
+        // transpose: D[row = 4*kq + r][col = j]  ->  hd[sample][head]
+        if (j < 8) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hd[w][(16 * mi + 4 * kq + r) * 9 + j] = c4[mi][r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0); single-wave exchange, LDS is in order
+        __builtin_amdgcn_wave_barrier();
+        const int64_t i = row0 + lane;
+        if (i < n) {
+            float z[A], dz[A];
+#pragma unroll
+            for (int k = 0; k < A; ++k) z[k] = hd[w][lane * 9 + k] + bh[k];
+            const float V = hd[w][lane * 9 + A] + bh[A];
+            const float dV = ppo_sample<A>(z, V, act[i], logp_old[i], adv[i], ret[i], val_old[i], inv_n, clip, beta, acc, dz);
+            s_db[A] += dV;
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                dheads[i * NH + k] = dz[k];
+                s_db[k] += dz[k];
+            }
+            dheads[i * NH + A] = dV;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    loss_block_epilogue<A>(acc, s_db, partial);
 }
 
 __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nb, int n_heads,
@@ -217,6 +323,32 @@ int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const in
         default: UAV_REQUIRE(false, "uav_ppo_loss: n_act=%d unsupported", n_act);
     }
 #undef LAUNCH_LOSS
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
+                       dhead_bias);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_ppo_loss_from_y(uav_ctx* ctx, const float* y, const float* w_head, const float* b_head, const int32_t* act,
+                         const float* logp_old, const float* adv, const float* ret, const float* val_old, int64_t n,
+                         int hidden, int n_act, float inv_n, float clip, float ent_beta, double* loss_sums, float* dheads,
+                         float* dhead_bias, uav_stream stream) {
+    UAV_REQUIRE(ctx && y && w_head && b_head && act && logp_old && adv && ret && val_old && loss_sums && dheads,
+                "uav_ppo_loss_from_y: NULL argument");
+    UAV_REQUIRE(n > 0 && n_act == 5, "uav_ppo_loss_from_y: n=%lld n_act=%d (5 actions supported)", (long long)n, n_act);
+    int nb = (int)((n + 255) / 256);
+    if (nb > LOSS_BLOCKS) nb = LOSS_BLOCKS;
+    double* partial = (double*)ctx->ws;
+#define LAUNCH_LY(H_)                                                                                             \
+    hipLaunchKernelGGL((ppo_loss_from_y_kernel<5, H_>), dim3(nb), dim3(256), 0, as_stream(stream), y, w_head, b_head, \
+                       act, logp_old, adv, ret, val_old, n, inv_n, clip, ent_beta, partial, dheads)
+    switch (hidden) {
+        case 64: LAUNCH_LY(64); break;
+        case 128: LAUNCH_LY(128); break;
+        case 256: LAUNCH_LY(256); break;
+        default: UAV_REQUIRE(false, "uav_ppo_loss_from_y: hidden=%d unsupported (64/128/256)", hidden);
+    }
+#undef LAUNCH_LY
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
                        dhead_bias);
     UAV_LAUNCH_CHECK();

@@ -66,27 +66,30 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_kernel(
     const int h_row = tid / (H / 4), h_col4 = tid % (H / 4);     // KC*H/4 = 4H float4 -> exactly one per thread
     const int s_row = tid >> 3, s_f = tid & 7;    // first 128 threads: x / dheads element (row, feature)
 
+    // branch-free chunk load: rows past the end are clamped to a valid row and multiplied by 0
     auto load_chunk = [&](int c) {
         const int64_t base = r_begin + (int64_t)c * KC;
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int64_t r = base + g_row0 + 4 * i;
-            sg[i] = (r < r_end) ? *reinterpret_cast<const float4*>(dgates + r * (4 * H) + 4 * g_col4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float m = (r < r_end) ? 1.f : 0.f;
+            const float4 v = *reinterpret_cast<const float4*>(dgates + (r < NTr ? r : NTr - 1) * (4 * H) + 4 * g_col4);
+            sg[i] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
         }
         {
-            const int64_t r = base + h_row;
-            sh = make_float4(0.f, 0.f, 0.f, 0.f);
-            sy = sh;
-            if (r < r_end) {
-                // h_prev of row (n,t): y[n][t-1] * keep[n][t], or h0[n] * keep[n][0] at t = 0
-                const int64_t n = r / T;
-                const int t = (int)(r - n * T);
-                const float kp = keep ? keep[r] : 1.f;
-                const float* src = (t == 0) ? (h0 + n * H) : (y_prev_src + (r - 1) * H);
-                const float4 v = *reinterpret_cast<const float4*>(src + 4 * h_col4);
-                sh = make_float4(v.x * kp, v.y * kp, v.z * kp, v.w * kp);
-                if (ytop) sy = *reinterpret_cast<const float4*>(ytop + r * H + 4 * h_col4);
+            const int64_t r = base + h_row, rc = (r < NTr ? r : NTr - 1);
+            // h_prev of row (n,t): y[n][t-1] * keep[n][t], or h0[n] * keep[n][0] at t = 0
+            const int64_t n = rc / T;
+            const int t = (int)(rc - n * T);
+            const float m = (r < r_end) ? 1.f : 0.f;
+            const float kp = (keep ? keep[rc] : 1.f) * m;
+            const float* src = (t == 0) ? (h0 + n * H) : (y_prev_src + (rc - 1) * H);
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * h_col4);
+            sh = make_float4(v.x * kp, v.y * kp, v.z * kp, v.w * kp);
+            sy = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ytop) {
+                const float4 u4 = *reinterpret_cast<const float4*>(ytop + rc * H + 4 * h_col4);
+                sy = make_float4(u4.x * m, u4.y * m, u4.z * m, u4.w * m);
             }
         }
         sx = 0.f;
@@ -166,8 +169,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     using G = WG<H>;
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= G::SLAB) return;
-    float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += slabs[(size_t)b * G::SLAB + o];
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nb; b += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p8[k] += slabs[(size_t)(b + k) * G::SLAB + o];
+    for (; b < nb; ++b) p8[0] += slabs[(size_t)b * G::SLAB + o];
+    const float s = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     const size_t gsz = (size_t)4 * H * G::NC;
     if (o < gsz) {
         const int m = (int)(o / G::NC), c = (int)(o % G::NC);

@@ -168,6 +168,21 @@ def ppo_loss_heads(heads, act, logp_old, adv, ret, val_old, inv_n, clip, ent_bet
     return loss_sums, dheads
 
 
+def ppo_loss_from_y(y, w_head, b_head, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta, loss_sums, dheads,
+                    dhead_bias=None):
+    """Heads + loss fused (csrc/loss.hip: ppo_loss_from_y_kernel): y [n, H] -> dheads [n, A+1]."""
+    n, H = y.shape
+    A1 = w_head.shape[0]
+    check(lib().uav_ppo_loss_from_y(_h(y), _p(y, F32, (n, H), "y"), _p(w_head, F32, (A1, H), "w_head"),
+                                    _p(b_head, F32, (A1,), "b_head"), _p(act, I32, (n,), "act"),
+                                    _p(logp_old, F32, (n,), "logp_old"), _p(adv, F32, (n,), "adv"),
+                                    _p(ret, F32, (n,), "ret"), _p(val_old, F32, (n,), "val_old"), n, H, A1 - 1,
+                                    float(inv_n), float(clip), float(ent_beta), _p(loss_sums, F64, (4,), "loss_sums"),
+                                    _p(dheads, F32, (n, A1), "dheads"), _p(dhead_bias, F32, (A1,), "dhead_bias"),
+                                    _stream()), "uav_ppo_loss_from_y")
+    return loss_sums, dheads
+
+
 # ----------------------------------------------------------------------------- U3
 def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.5,
               gnorm_out=None):

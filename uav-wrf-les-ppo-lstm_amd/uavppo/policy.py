@@ -155,7 +155,7 @@ class LSTMActorCritic(_FlatPolicy):
         z = torch.zeros(self.num_layers, n, self.hidden, dtype=torch.float32, device=self.device)
         return z, z.clone()
 
-    def heads(self, obs, keep, h0, c0, work=None):
+    def heads(self, obs, keep, h0, c0, work=None, want_heads=True):
         """obs [N,T,I], keep [N,T] or None, h0,c0 [L,N,H] -> heads [N*T, A+1].  Saves what
         backward() needs.  `work` may hold preallocated 'stash{l}', 'y{l}' tensors."""
         N, T, _ = obs.shape
@@ -170,6 +170,8 @@ class LSTMActorCritic(_FlatPolicy):
             saved.append((x, stash, y, h0[l]))
             x = y
         self._saved = (saved, keep, x)
+        if not want_heads:
+            return x.view(N * T, self.hidden)          # trunk output; the loss kernel applies the heads
         return ops.gemm(x.view(N * T, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"],
                         out=work.get("heads"))
 

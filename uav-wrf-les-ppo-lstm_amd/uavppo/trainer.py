@@ -159,14 +159,16 @@ class VecPPOTrainer:
         for _ in range(hp["epochs"]):
             for m in range(M):
                 sl = slice(m * nb, (m + 1) * nb)
+                args = (b["act"][sl].reshape(-1), b["logp"][sl].reshape(-1), self.adv_n[sl].reshape(-1),
+                        self.ret[sl].reshape(-1), b["val"][sl].reshape(-1), inv_n, hp["clip"], hp["ent_beta"],
+                        self.loss_sums, self.dheads, self.dhead_bias)
                 if self.kind == "lstm":
-                    heads = self.policy.heads(b["obs"][sl], b["keep"][sl], self.h0[:, sl].contiguous() if M > 1 else self.h0,
-                                              self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work)
+                    y = self.policy.heads(b["obs"][sl], b["keep"][sl], self.h0[:, sl].contiguous() if M > 1 else self.h0,
+                                          self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work, want_heads=False)
+                    ops.ppo_loss_from_y(y, self.policy.views["head.weight"], self.policy.views["head.bias"], *args)
                 else:
                     heads = self.policy.heads(b["obs"][sl].reshape(nb * T, 6), stash=self.work["stash"])
-                ops.ppo_loss_heads(heads, b["act"][sl].reshape(-1), b["logp"][sl].reshape(-1),
-                                   self.adv_n[sl].reshape(-1), self.ret[sl].reshape(-1), b["val"][sl].reshape(-1),
-                                   inv_n, hp["clip"], hp["ent_beta"], self.loss_sums, self.dheads, self.dhead_bias)
+                    ops.ppo_loss_heads(heads, *args)
                 grad = (self.policy.backward(self.dheads, self.work, self.dhead_bias) if self.kind == "lstm"
                         else self.policy.backward(self.dheads))
                 allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
