@@ -102,3 +102,28 @@ def test_lstm_two_layer_stack_matches_torch(ops):
     _close(y2.transpose(0, 1), y_ref, 1e-5, 3e-6)
     _close(hn2, hn_ref[1], 1e-5, 3e-6)
     _close(cn1, cn_ref[0], 1e-5, 3e-6)
+
+
+@pytest.mark.parametrize("T,N,I,H", [(6, 5, 6, 256), (9, 33, 256, 256), (4, 3, 6, 32)])
+def test_lstm_generic_hidden_sizes(ops, T, N, I, H):
+    """Hidden sizes without a persistent kernel (BASELINE C5: h=256) run the per-step GEMM + pointwise
+    path behind the same entry points; same parity bar against torch.nn.LSTM semantics."""
+    torch.manual_seed(H + T)
+    ref = torch.nn.LSTM(I, H, 1)
+    w_ih, w_hh, b_ih, b_hh = [p.detach().clone().requires_grad_(True) for p in ref.parameters()]
+    x = torch.randn(T, N, I, requires_grad=True)
+    h0 = torch.randn(N, H, requires_grad=True)
+    c0 = torch.randn(N, H, requires_grad=True)
+    keep = (torch.rand(T, N) > 0.25).float()
+    y, hn, cn = po.lstm_layer_forward(x, h0, c0, w_ih, w_hh, b_ih, b_hh, keep)
+    dy, dhn, dcn = torch.randn(T, N, H), torch.randn(N, H), torch.randn(N, H)
+    ((y * dy).sum() + (hn * dhn).sum() + (cn * dcn).sum()).backward()
+    d = lambda t: t.detach().to(DEV).contiguous()
+    xg, kg = d(x.transpose(0, 1)), d(keep.transpose(0, 1))
+    yg, hng, cng, stash = ops.lstm_fwd(xg, kg, d(h0), d(c0), d(w_ih), d(w_hh), d(b_ih), d(b_hh))
+    _close(yg.transpose(0, 1), y, 1e-5, 3e-6)
+    _close(cng, cn, 1e-5, 3e-6)
+    g = ops.lstm_bwd(xg, kg, stash, d(w_ih), d(w_hh), yg, d(h0), dy=d(dy.transpose(0, 1)), dhn=d(dhn), dcn=d(dcn), need_dx=True)
+    for k, want in (("dx", x.grad.transpose(0, 1)), ("dw_ih", w_ih.grad), ("dw_hh", w_hh.grad), ("db", b_ih.grad),
+                    ("dh0", h0.grad), ("dc0", c0.grad)):
+        _close(g[k], want)

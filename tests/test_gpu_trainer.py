@@ -129,7 +129,7 @@ def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, ep
 
 
 @pytest.mark.parametrize("H,L,N,T,mode", [(64, 1, 6, 24, "reference_exact"), (128, 1, 18, 40, "standard"),
-                                          (128, 2, 9, 17, "reference_exact")])
+                                          (128, 2, 9, 17, "reference_exact"), (256, 2, 7, 11, "standard")])
 def test_lstm_ppo_update_matches_oracle(H, L, N, T, mode):
     from uavppo.trainer import VecPPOTrainer
     tr = VecPPOTrainer(N, T, "lstm", hidden=H, layers=L, device=DEV, seed=3, gae_mode=mode, use_curriculum=False, epochs=3)
@@ -240,3 +240,40 @@ def test_end_to_end_reference_loss_curve(golden):
         # a parameter with a near-zero gradient can differ by ~one Adam step (lr = 3e-5) after 120 steps
         assert np.isclose(sd[k].double().sum().item(), g["post_sum/" + k], rtol=1e-4, atol=1e-4), k
     assert tr.curriculum.current_radius == 50.0 and len(tr.curriculum.success_history) == len(g["curriculum"])
+
+
+def test_stepwise_lstm_rollout_matches_fused_kernel():
+    """The step-wise rollout (stacked / wide policies) and the fused persistent kernel are two schedules of
+    the same computation: identical buffers for a single-layer h=128 policy on the same injected inputs."""
+    from uavppo.trainer import VecPPOTrainer
+    N, T, H = 21, 30, 128
+    bank = FieldBank.from_seed(2 * N, "v2.0", seed=41)
+    mk = lambda: VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=8, bank=bank.interleaved(),
+                               bank_sources=bank.sources, gae_mode="standard", use_curriculum=False)
+    a, b = mk(), mk()
+    a.radius = b.radius = 60.0
+    a.reset(); b.reset()
+    rng = np.random.RandomState(1)
+    fa = torch.from_numpy(rng.randint(1, 5, (N, T)).astype(np.int32)).to(DEV)
+    nz = torch.from_numpy(rng.randn(N, T, 2)).to(DEV)
+    a.collect(forced_act=fa, noise=nz)
+    b.h0.copy_(b.h); b.c0.copy_(b.c)
+    b._collect_stepwise_lstm(fa, nz)
+    for k in ("obs", "act", "done", "keep", "flags"):
+        assert torch.equal(a.buf[k], b.buf[k]), k
+    for k in ("rew", "val", "logp"):
+        assert torch.allclose(a.buf[k], b.buf[k], atol=2e-5, rtol=1e-4), k
+    assert torch.allclose(a.h, b.h, atol=2e-5) and torch.allclose(a.c, b.c, atol=2e-5)
+    assert torch.allclose(a.last_val, b.last_val, atol=2e-5)
+
+
+def test_c5_shaped_policy_trains():
+    """BASELINE config C5 family (stacked x2, h=256) end to end at a small size: step-wise rollout, generic
+    LSTM forward/backward, fused loss; finite losses and parameters that move."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(48, 16, "lstm", hidden=256, layers=2, device=DEV, seed=2, use_curriculum=False, epochs=2)
+    p0 = tr.policy.flat.clone()
+    tr.train_iteration()
+    pl, vl, ent = tr.losses()
+    assert np.isfinite([pl, vl, ent]).all() and 1.5 < ent < 1.61
+    assert torch.isfinite(tr.policy.flat).all() and (tr.policy.flat - p0).abs().max() > 1e-6

@@ -29,6 +29,11 @@ int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int6
              const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
              int accumulate, hipStream_t st);
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st);
+int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T,
+                     int H, float* y, float* hn, float* cn, float* stash, hipStream_t st);
+int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
+                     const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0, float* dc0,
+                     hipStream_t st);
 int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
                      const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
                      float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
@@ -400,10 +405,11 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
     UAV_REQUIRE(ctx && x && h0 && c0 && w_ih && w_hh && b_ih && b_hh && y && hn && cn, "uav_lstm_fwd: NULL argument");
     UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_fwd: N=%d T=%d I=%d", N, T, I);
     hipStream_t st = as_stream(stream);
-    const bool fuse = I <= 8;
+    const bool persistent = (H == 64 || H == 128);
+    const bool fuse = I <= 8 && persistent;
     if (!fuse) {
         // time-batched input projection into the gates slot of the stash: pre = x W_ih^T + (b_ih + b_hh)
-        UAV_REQUIRE(stash, "uav_lstm_fwd: stash is required when I > 8");
+        UAV_REQUIRE(stash, "uav_lstm_fwd: stash is required when I > 8 or H is not 64/128");
         float* bsum = (float*)ctx->ws;   // 4H floats at the head of the workspace... kept clear of GEMM slabs below
         uav_ctx sub = *ctx;
         sub.ws = (char*)ctx->ws + 65536;
@@ -416,7 +422,8 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
         case 64: return launch_fwd<64>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, st);
         case 128: return launch_fwd<128>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, st);
     }
-    UAV_REQUIRE(false, "uav_lstm_fwd: H=%d unsupported (64, 128)", H);
+    // any other hidden size: per-step GEMM + pointwise (lstm_generic.hip)
+    return lstm_generic_fwd(ctx, keep, h0, c0, w_hh, N, T, H, y, hn, cn, stash, st);
 }
 
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
@@ -426,6 +433,10 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
     UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd: give exactly one of dy / dheads");
     UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd: dheads needs w_head and 1..8 heads");
     UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd: N=%d T=%d", N, T);
+    if (H != 64 && H != 128) {
+        UAV_REQUIRE(dy, "uav_lstm_bwd: hidden sizes other than 64/128 take dy (form dheads . w_head with uav_gemm_f32)");
+        return lstm_generic_bwd(ctx, keep, stash, w_hh, dy, dhn, dcn, N, T, H, dgates, dh0, dc0, as_stream(stream));
+    }
     return lstm_bwd_seq(keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, H, dgates, dh0, dc0,
                         as_stream(stream));
 }

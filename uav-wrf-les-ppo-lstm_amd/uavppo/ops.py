@@ -319,7 +319,7 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
 
 
 def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
-             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True):
+             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None):
     """BPTT sequence kernel + fused weight-gradient pass of one layer.  y, h0: the layer's forward
     output and initial hidden state (h_prev of the weight gradient is y shifted by one step)."""
     N, T, I = x.shape
@@ -333,8 +333,11 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     dh0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
     dc0 = torch.empty(N, H, dtype=F32, device=dev) if want_dstate else None
     nh = 0 if dheads is None else dheads.shape[-1]
-    if dheads is not None and dw_head is None:
-        dw_head = torch.empty(nh, H, dtype=F32, device=dev)
+    if wgrad_dheads is None:
+        wgrad_dheads = dheads          # head-weight gradient wanted whenever dheads drives the backward
+    nhw = 0 if wgrad_dheads is None else wgrad_dheads.shape[-1]
+    if wgrad_dheads is not None and dw_head is None:
+        dw_head = torch.empty(nhw, H, dtype=F32, device=dev)
     _t = KERNEL_TIMER.bracket("lstm_bwd")
     check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
@@ -347,9 +350,9 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"), _p(h0, F32, (N, H), "h0"),
                                _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"),
                                _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
-                               _p(dheads, F32, (N, T, nh), "dheads"), nh, N, T, I, H,
+                               _p(wgrad_dheads, F32, (N, T, nhw), "dheads"), nhw, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
-                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nh, H), "dw_head"), _p(dx), _stream()),
+                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nhw, H), "dw_head"), _p(dx), _stream()),
           "uav_lstm_wgrad")
     if _t is not None:
         _t.record()

@@ -175,6 +175,26 @@ class LSTMActorCritic(_FlatPolicy):
         return ops.gemm(x.view(N * T, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"],
                         out=work.get("heads"))
 
+    def step(self, obs, h, c, keep=None, work=None):
+        """One time step for N envs (step-wise rollout of configurations the fused rollout kernel does
+        not cover: stacked layers, h = 256).  obs [N, I]; h, c [L, N, H] updated in place; keep [N] or None.
+        Returns heads [N, A+1]."""
+        N = obs.shape[0]
+        x = obs.view(N, 1, -1)
+        k = None if keep is None else keep.view(N, 1)
+        work = work if work is not None else {}
+        v = self.views
+        for l in range(self.num_layers):
+            st = work.get(f"step_stash{l}")
+            if st is None:
+                st = work[f"step_stash{l}"] = torch.empty(N, 1, 6 * self.hidden, dtype=torch.float32, device=obs.device)
+            y, hn, cn, _ = ops.lstm_fwd(x, k, h[l], c[l], v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
+                                        v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"], stash=st)
+            h[l].copy_(hn)
+            c[l].copy_(cn)
+            x = y
+        return ops.gemm(x.view(N, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"])
+
     def backward(self, dheads, work=None, dhead_bias=None):
         """dheads [N*T, A+1] -> self.grad (flat, overwritten).  dhead_bias: the column sums of dheads
         when the loss kernel already produced them (uav_ppo_loss), else computed here."""
@@ -187,12 +207,18 @@ class LSTMActorCritic(_FlatPolicy):
         else:
             ops.colsum(dheads, out=g["head.bias"])
         dy = None
+        fused_heads = self.hidden in (64, 128)        # lstm_bwd_kernel forms dy = dheads . W_head in registers
+        if not fused_heads:
+            dy = ops.gemm(dheads, v["head.weight"], out=work.get("dy")).view(N, T, H)
         for l in reversed(range(self.num_layers)):
             x, stash, y, h0 = saved[l]
             top = (l == self.num_layers - 1)
+            use_dheads = top and fused_heads
             r = ops.lstm_bwd(x, keep, stash, v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"], y, h0,
-                             dy=None if top else dy,
-                             dheads=dheads.view(N, T, -1) if top else None, w_head=v["head.weight"] if top else None,
+                             dy=None if use_dheads else dy,
+                             dheads=dheads.view(N, T, -1) if use_dheads else None,
+                             w_head=v["head.weight"] if use_dheads else None,
+                             wgrad_dheads=dheads.view(N, T, -1) if top else None,
                              need_dx=(l > 0), dgates=work.get("dgates"), dw_ih=g[f"lstm.weight_ih_l{l}"],
                              dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"],
                              dw_head=g["head.weight"] if top else None, want_dstate=False)

@@ -82,6 +82,8 @@ class VecPPOTrainer:
             for l in range(L):
                 self.work[f"stash{l}"] = torch.empty(nb, T, 6 * H, **f32)
                 self.work[f"y{l}"] = torch.empty(nb, T, H, **f32)
+            if H not in (64, 128):
+                self.work["dy"] = torch.empty(nb * T, H, **f32)
         else:
             nb = N // self.num_minibatches
             self.work = {"stash": torch.empty(nb * T * (2 * 256 + 2 * 128 + 2), **f32)}
@@ -104,9 +106,11 @@ class VecPPOTrainer:
     # ------------------------------------------------------------------------------------------ R1
     def collect(self, forced_act=None, noise=None):
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
-        if self.kind == "lstm":
-            if self.policy.num_layers != 1:
-                raise RuntimeError("fused rollout kernel supports a single LSTM layer (stacked: see DESIGN.md)")
+        if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128)):
+            self.h0.copy_(self.h)
+            self.c0.copy_(self.c)
+            self._collect_stepwise_lstm(forced_act, noise)
+        elif self.kind == "lstm":
             self.h0.copy_(self.h)
             self.c0.copy_(self.c)
             ops.rollout_lstm(self.env_state, self.N, self.env_cfg(), self.policy.flat, self.policy.hidden, self.T,
@@ -114,6 +118,42 @@ class VecPPOTrainer:
                              forced_act=forced_act, noise=noise, nan_count=self.nan_count)
         else:
             self._collect_stepwise(forced_act, noise)
+
+    def _collect_stepwise_lstm(self, forced_act=None, noise=None):
+        """Stacked / wide LSTM policies (BASELINE C5: h=256 x2): one cell step per layer + heads GEMM +
+        sample + env step per time step.  Same buffers and keep semantics as the fused rollout kernel."""
+        b = self.buf
+        if not hasattr(self, "_st"):
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._st = {"rew": torch.zeros(self.N, **f32), "done": torch.zeros(self.N, **f32),
+                        "flags": torch.zeros(self.N, dtype=torch.uint8, device=self.device),
+                        "keep": torch.ones(self.N, **f32), "work": {}}
+        st = self._st
+        cfg = self.env_cfg()
+        st["keep"].fill_(1.0)
+        for t in range(self.T):
+            heads = self.policy.step(self.cur_obs, self.h, self.c, st["keep"], st["work"])
+            fa = None if forced_act is None else forced_act[:, t].contiguous()
+            act, logp, _, _ = ops.policy_sample(heads[:, :5].contiguous(), seed=self.seed + 7919 * self.rank,
+                                                counter=self.iteration * self.T + t, forced_act=fa,
+                                                nan_count=self.nan_count)
+            b["obs"][:, t] = self.cur_obs
+            b["act"][:, t] = act
+            b["val"][:, t] = heads[:, 5]
+            b["logp"][:, t] = logp
+            b["keep"][:, t] = st["keep"]
+            nz = None if noise is None else noise[:, t].contiguous()
+            ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, st["rew"], st["done"], st["flags"], noise=nz)
+            b["rew"][:, t] = st["rew"]
+            b["done"][:, t] = st["done"]
+            b["flags"][:, t] = st["flags"]
+            torch.sub(1.0, st["done"], out=st["keep"])          # the recurrent state restarts where an episode ended
+        # hand the state to the next rollout already masked (its keep[:, 0] is 1), like the fused kernel
+        self.h.mul_(st["keep"][None, :, None])
+        self.c.mul_(st["keep"][None, :, None])
+        if self.last_val is not None:
+            hh, cc = self.h.clone(), self.c.clone()
+            self.last_val.copy_(self.policy.step(self.cur_obs, hh, cc, None, st["work"])[:, 5])
 
     def _collect_stepwise(self, forced_act=None, noise=None):
         """MLP policy: one policy-forward + sample + env-step launch group per time step
