@@ -277,3 +277,24 @@ def test_c5_shaped_policy_trains():
     pl, vl, ent = tr.losses()
     assert np.isfinite([pl, vl, ent]).all() and 1.5 < ent < 1.61
     assert torch.isfinite(tr.policy.flat).all() and (tr.policy.flat - p0).abs().max() > 1e-6
+
+
+def test_epoch0_reuses_rollout_forward():
+    """The fused rollout kernel's stash/y == what lstm_fwd recomputes with the same parameters, and an
+    update that adopts it lands on the same parameters as one that recomputes the forward pass."""
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    mk = lambda reuse: VecPPOTrainer(40, 24, "lstm", hidden=128, device=DEV, seed=4, use_curriculum=False, epochs=2)
+    a, b = mk(True), mk(False)
+    b.reuse_rollout_forward = False
+    a.collect(); b.collect()
+    assert torch.equal(a.buf["obs"], b.buf["obs"]) and a._rollout_forward_valid and not b._rollout_forward_valid
+    v = a.policy.views
+    y, hn, cn, stash = ops.lstm_fwd(a.buf["obs"], a.buf["keep"], a.h0[0], a.c0[0], v["lstm.weight_ih_l0"],
+                                    v["lstm.weight_hh_l0"], v["lstm.bias_ih_l0"], v["lstm.bias_hh_l0"])
+    H = 128
+    assert torch.allclose(a.work["y0"], y, atol=2e-6)
+    assert torch.allclose(a.work["stash0"][..., :5 * H], stash[..., :5 * H], atol=2e-6)
+    a.update(); b.update()
+    assert torch.allclose(a.policy.flat, b.policy.flat, atol=2e-6)
+    assert torch.allclose(a.loss_sums, b.loss_sums, rtol=1e-5)

@@ -41,6 +41,7 @@ struct RolloutBufs {
     float* cur_obs; float* h; float* c;
     float* obs; int32_t* act; float* rew; float* val; float* logp; float* done; uint8_t* flags; float* keep;
     float* last_val; const int32_t* forced_act; const double* noise; int32_t* nan_count;
+    float* stash; float* y;     // optional: BPTT stash [N][T][6H] + y [N][T][H], so PPO epoch 0 skips its forward pass
 };
 
 template <int H, int NA>
@@ -161,6 +162,14 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                 const float c = gf * c_reg[r] + gi * gg;
                 const float h = go * r_tanh(c);
                 hbuf[e * S + rpos<H>(u)] = h;
+                if (B.stash && !value_only && n0 + e < N) {
+                    // the update's first epoch uses these parameters: its forward pass IS this rollout
+                    const size_t row = (size_t)(n0 + e) * T + t;
+                    float* sp = B.stash + row * (6 * H);
+                    sp[u] = gi; sp[H + u] = gf; sp[2 * H + u] = gg; sp[3 * H + u] = go;
+                    sp[4 * H + u] = c_reg[r];
+                    B.y[row * H + u] = h;
+                }
                 if (!value_only) { c_reg[r] = c; h_keep[r] = h; }
             }
         }
@@ -320,7 +329,7 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
                            const float* params, int hidden, int horizon, uint64_t iter, float* cur_obs, float* h,
                            float* c, float* obs, int32_t* act, float* rew, float* val, float* logp, float* done,
                            uint8_t* flags, float* keep, float* last_val, const int32_t* forced_act,
-                           const double* noise, int32_t* nan_count, uav_stream stream) {
+                           const double* noise, int32_t* nan_count, float* stash, float* y_out, uav_stream stream) {
     UAV_REQUIRE(ctx && env_state && params && cur_obs && obs && act && rew && val && logp && done && flags && nan_count,
                 "uav_rollout: NULL argument");
     UAV_REQUIRE(n_env > 0 && horizon > 0, "uav_rollout: n_env=%d horizon=%d", n_env, horizon);
@@ -330,7 +339,8 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
     EnvParams P;
     int rc = env_params_from_cfg(ctx, cfg, n_env, P);
     if (rc) return rc;
-    RolloutBufs B{cur_obs, h, c, obs, act, rew, val, logp, done, flags, keep, last_val, forced_act, noise, nan_count};
+    UAV_REQUIRE((stash == nullptr) == (y_out == nullptr), "uav_rollout: stash and y_out go together");
+    RolloutBufs B{cur_obs, h, c, obs, act, rew, val, logp, done, flags, keep, last_val, forced_act, noise, nan_count, stash, y_out};
     EnvBlob blob = env_blob_view(env_state, n_env);
     switch (hidden) {
         case 64: return launch_rollout<64>(P, blob, n_env, horizon, iter, params, B, as_stream(stream));

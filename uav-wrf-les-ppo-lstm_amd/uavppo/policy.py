@@ -175,6 +175,13 @@ class LSTMActorCritic(_FlatPolicy):
         return ops.gemm(x.view(N * T, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"],
                         out=work.get("heads"))
 
+    def adopt_forward(self, obs, keep, h0, stash, y):
+        """Epoch 0 of a PPO update runs with the rollout's parameters: the fused rollout kernel already wrote
+        this forward pass's stash and y, so register them instead of recomputing (single layer only)."""
+        self._saved = ([(obs, stash, y, h0[0])], keep, y)
+        N, T, H = y.shape
+        return y.view(N * T, H)
+
     def step(self, obs, h, c, keep=None, work=None):
         """One time step for N envs (step-wise rollout of configurations the fused rollout kernel does
         not cover: stacked layers, h = 256).  obs [N, I]; h, c [L, N, H] updated in place; keep [N] or None.

@@ -62,6 +62,8 @@ class VecPPOTrainer:
         self.exp_avg_sq = torch.zeros(P, **f32)
         self.opt_step = 0
         self.iteration = 0
+        self.reuse_rollout_forward = True    # epoch 0 adopts the rollout kernel's stash (same parameters)
+        self._rollout_forward_valid = False
         self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
         self.log = []
         # environments of this rank: global indices [rank*N, (rank+1)*N)
@@ -113,9 +115,12 @@ class VecPPOTrainer:
         elif self.kind == "lstm":
             self.h0.copy_(self.h)
             self.c0.copy_(self.c)
+            reuse = self.reuse_rollout_forward and self.num_minibatches == 1
             ops.rollout_lstm(self.env_state, self.N, self.env_cfg(), self.policy.flat, self.policy.hidden, self.T,
                              self.iteration, self.cur_obs, self.h[0], self.c[0], self.buf, last_val=self.last_val,
-                             forced_act=forced_act, noise=noise, nan_count=self.nan_count)
+                             forced_act=forced_act, noise=noise, nan_count=self.nan_count,
+                             stash=self.work["stash0"] if reuse else None, y=self.work["y0"] if reuse else None)
+            self._rollout_forward_valid = reuse
         else:
             self._collect_stepwise(forced_act, noise)
 
@@ -203,8 +208,14 @@ class VecPPOTrainer:
                         self.ret[sl].reshape(-1), b["val"][sl].reshape(-1), inv_n, hp["clip"], hp["ent_beta"],
                         self.loss_sums, self.dheads, self.dhead_bias)
                 if self.kind == "lstm":
-                    y = self.policy.heads(b["obs"][sl], b["keep"][sl], self.h0[:, sl].contiguous() if M > 1 else self.h0,
-                                          self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work, want_heads=False)
+                    if self._rollout_forward_valid:
+                        # first optimiser step after a fused rollout: parameters unchanged since the rollout
+                        y = self.policy.adopt_forward(b["obs"], b["keep"], self.h0, self.work["stash0"], self.work["y0"])
+                        self._rollout_forward_valid = False
+                    else:
+                        y = self.policy.heads(b["obs"][sl], b["keep"][sl],
+                                              self.h0[:, sl].contiguous() if M > 1 else self.h0,
+                                              self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work, want_heads=False)
                     ops.ppo_loss_from_y(y, self.policy.views["head.weight"], self.policy.views["head.bias"], *args)
                 else:
                     heads = self.policy.heads(b["obs"][sl].reshape(nb * T, 6), stash=self.work["stash"])
