@@ -1,0 +1,93 @@
+"""BASELINE.json's full C3 size (4096 envs x 128 steps, LSTM h=128) through size-independent properties:
+the oracle cannot run there in seconds, so the checks are tile independence, linearity of the gradient
+in the batch, subset agreement with the oracle, determinism and conservation of the statistics.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ppo_oracle as po
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N, T, H = 4096, 128, 128
+
+
+@pytest.fixture(scope="module")
+def trainer():
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=77, use_curriculum=False)
+    tr.collect()
+    tr.compute_advantages()
+    return tr
+
+
+def test_gae_and_normalise_fullsize_vs_oracle_rows(trainer):
+    b = trainer.buf
+    rows = np.random.RandomState(0).choice(N, 24, replace=False)
+    rew, val, done = (b[k][rows].cpu().numpy() for k in ("rew", "val", "done"))
+    want = po.gae_reference_exact(rew, val, done)
+    assert np.allclose(trainer.adv[rows].cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+    a = trainer.adv.double()
+    s = trainer.stats3.cpu().numpy()
+    assert s[2] == N * T and np.isclose(s[0], a.sum().item(), rtol=1e-10)
+    an = trainer.adv_n.double()
+    assert abs(an.mean().item()) < 1e-5 and abs(an.std().item() - 1.0) < 1e-4          # whole-buffer normalisation
+    assert torch.allclose(trainer.ret, trainer.adv_n + b["val"], atol=1e-6)             # returns = normalised adv + V
+
+
+def test_rollout_fullsize_invariants(trainer):
+    b = trainer.buf
+    assert torch.isfinite(b["rew"]).all() and torch.isfinite(b["val"]).all() and trainer.nan_count.item() == 0
+    assert int(b["act"].min()) >= 0 and int(b["act"].max()) <= 4
+    # keep[t] = 1 - done[t-1]; obs[:, :, 4] (step/MAX_STEPS) restarts exactly where an episode ended
+    assert torch.equal(b["keep"][:, 1:], 1 - b["done"][:, :-1]) and bool((b["keep"][:, 0] == 1).all())
+    step = b["obs"][:, :, 4]
+    nxt, ended = step[:, 1:], b["done"][:, :-1] > 0
+    assert bool((nxt[ended] == 0).all()) and torch.allclose(nxt[~ended], step[:, :-1][~ended] + 1e-3, atol=1e-6)
+    assert torch.allclose(b["logp"].exp().mean(), torch.tensor(0.2, device=DEV), atol=5e-3)   # near-uniform init policy
+    # the stash emitted by the rollout is the forward pass of the same parameters
+    from uavppo import ops
+    v = trainer.policy.views
+    y, _, _, _ = ops.lstm_fwd(b["obs"][:64].contiguous(), b["keep"][:64].contiguous(), trainer.h0[0][:64].contiguous(),
+                              trainer.c0[0][:64].contiguous(), v["lstm.weight_ih_l0"], v["lstm.weight_hh_l0"],
+                              v["lstm.bias_ih_l0"], v["lstm.bias_hh_l0"])
+    assert torch.allclose(trainer.work["y0"][:64], y, atol=3e-6)
+
+
+def test_lstm_fullsize_tile_independence_and_gradient_linearity(trainer):
+    """Env tiles are independent problems: a 32-env slice computed alone equals the same slice of the full
+    launch bit for bit; and the weight gradient of the full batch is the sum of the gradients of its halves."""
+    from uavppo import ops
+    b, v = trainer.buf, trainer.policy.views
+    w = (v["lstm.weight_ih_l0"], v["lstm.weight_hh_l0"], v["lstm.bias_ih_l0"], v["lstm.bias_hh_l0"])
+    h0, c0 = trainer.h0[0], trainer.c0[0]
+    y, hn, cn, stash = ops.lstm_fwd(b["obs"], b["keep"], h0, c0, *w)
+    sl = slice(1024, 1056)
+    y2, hn2, cn2, stash2 = ops.lstm_fwd(b["obs"][sl].contiguous(), b["keep"][sl].contiguous(), h0[sl].contiguous(),
+                                        c0[sl].contiguous(), *w)
+    assert torch.equal(y[sl], y2) and torch.equal(cn[sl], cn2) and torch.equal(stash[sl][..., :5 * H], stash2[..., :5 * H])
+    dheads = torch.randn(N, T, 6, device=DEV) / (N * T)
+    full = ops.lstm_bwd(b["obs"], b["keep"], stash, w[0], w[1], y, h0, dheads=dheads, w_head=v["head.weight"])
+    parts = []
+    for lo, hi in ((0, N // 2), (N // 2, N)):
+        p = ops.lstm_bwd(b["obs"][lo:hi].contiguous(), b["keep"][lo:hi].contiguous(), stash[lo:hi].contiguous(), w[0], w[1],
+                         y[lo:hi].contiguous(), h0[lo:hi].contiguous(), dheads=dheads[lo:hi].contiguous(),
+                         w_head=v["head.weight"])
+        parts.append(p)
+        assert torch.equal(p["dh0"], full["dh0"][lo:hi])
+    for k in ("dw_hh", "dw_ih", "db", "dw_head"):
+        tot = parts[0][k] + parts[1][k]
+        scale = full[k].abs().max().item()
+        assert torch.allclose(full[k], tot, rtol=1e-4, atol=2e-6 * scale), k
+
+
+def test_update_fullsize_is_deterministic_and_finite():
+    from uavppo.trainer import VecPPOTrainer
+    outs = []
+    for _ in range(2):
+        tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=5, use_curriculum=False, epochs=2)
+        tr.train_iteration()
+        outs.append((tr.policy.flat.clone(), tr.loss_sums.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # no atomics: bitwise repeatable
+    pl, vl, ent = (outs[0][1][:3] / (N * T)).tolist()
+    assert np.isfinite([pl, vl, ent]).all() and 1.55 < ent < 1.6095
