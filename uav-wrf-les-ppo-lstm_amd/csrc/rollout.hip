@@ -13,6 +13,9 @@
 //   * that VALU/f64 work for step t overlaps the other waves' recurrent MFMAs for step t+1 (both
 //     only need h_t; wave 0's SIMD partner fills the matrix pipe meanwhile); two workgroup
 //     barriers per step, no inter-workgroup communication.
+// (Tried and measured: spreading the env role over all waves with opposite [env|MFMA] order between SIMD
+//  partners.  Correct, but two inlined copies of the f64 env chain beside 128 weight VGPRs spill ~90 VGPRs
+//  in every wave: 1.9 ms vs 1.2 ms.  The env role stays on wave 0.)
 // Procedural fields make the whole rollout HBM-write-only apart from the policy parameters:
 // 44 B per env-step (obs 24, act 4, rew 4, val 4, logp 4, done 4) + 5 B (keep, flags).
 #include "env_core.h"
