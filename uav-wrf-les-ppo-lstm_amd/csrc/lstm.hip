@@ -21,6 +21,7 @@
 // Backward mirrors it with W_hh^T slices in VGPRs: dgates of a step are written to LDS (and to
 // HBM for the weight-gradient GEMMs), dh_{t-1} = dgates W_hh comes back in the same lane layout
 // as the pointwise needs, so dh/dc also stay in registers across the time loop.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -347,6 +348,195 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
     }
 }
 
+// -------------------------------------------------------------------- backward, LDS-DMA stash prefetch
+// Same math as lstm_bwd_kernel.  The per-step stash values (gates i,f,g,o + c_prev of this wave's 16
+// units x 16 env rows = 5 KB) are fetched by global_load_lds (LDS-DMA: no VGPR destination) TWO steps
+// ahead into a 2-slot per-wave ring, so the HBM latency (2-3 us under this kernel's ~5 TB/s demand) is
+// covered by two MFMA phases instead of one and 24 VGPRs of register prefetch disappear.  Each wave
+// gathers exactly what its own lanes read back, so the only ordering needed is the wave's own counted
+// s_waitcnt: vmcnt(5) = "everything but the 5 DMA ops issued last step has landed" (loads, stores and
+// LDS-DMA retire in issue order; the 5 DMA ops per step are issued unconditionally).
+template <int H>
+struct BwdDmaGeom {
+    static constexpr int S = 4 * H + 4;
+    static constexpr int TCB = 16;                               // steps of dheads/keep staged per chunk
+    static constexpr int SLOT = 5 * MT * 16;                     // floats per wave per slot: [5][16 rows][16 units]
+    static constexpr int NW = H / 16;
+    static constexpr size_t LDS = (2 * MT * S + TCB * MT * 8 + (TCB + 1) * MT) * sizeof(float);   // dynamic part
+};
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_bwd_dma_kernel(
+    const float* __restrict__ keep, const float* __restrict__ stash, const float* __restrict__ w_hh,
+    const float* __restrict__ dheads, const float* __restrict__ w_head, int NH, const float* __restrict__ dhn,
+    const float* __restrict__ dcn, int N, int T, float* __restrict__ dgates, float* __restrict__ dh0,
+    float* __restrict__ dc0) {
+    using G = BwdDmaGeom<H>;
+    constexpr int S = G::S, TCB = G::TCB, SLOT = G::SLOT, NW = G::NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dgbuf = smem;                       // [2][MT][S]
+    float* dhbuf = dgbuf + 2 * MT * S;         // [TCB][MT][8]
+    float* kbuf = dhbuf + TCB * MT * 8;        // [TCB+1][MT]
+    // the DMA ring is its OWN __shared__ object: with everything in one array hipcc cannot prove the MFMA
+    // fragment reads of dgbuf do not alias the in-flight LDS-DMA and puts s_waitcnt vmcnt(0) in front of them
+    __shared__ __attribute__((aligned(16))) float ring[2 * NW * SLOT];   // [2 slots][NW waves][SLOT]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int u = 16 * w + j;
+    const int n0 = blockIdx.x * MT;
+
+    float wt[H];
+#pragma unroll
+    for (int s = 0; s < H; ++s) wt[s] = w_hh[(size_t)(kq * H + s) * H + u];
+    float whb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) whb[a] = (4 * a + kq < NH) ? w_head[(size_t)(4 * a + kq) * H + u] : 0.f;
+
+    float dh_rec[4], dc_next[4];
+    size_t srow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = min(n0 + 4 * kq + r, N - 1);
+        dh_rec[r] = dhn ? dhn[(size_t)n * H + u] : 0.f;
+        dc_next[r] = dcn ? dcn[(size_t)n * H + u] : 0.f;
+        srow[r] = (size_t)n * T;
+    }
+    // DMA gather coordinates of this lane: env row e_d = lane/4, 4-unit group g4 = lane%4 of this wave's 16 units
+    const int e_d = lane >> 2, g4 = lane & 3;
+    const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
+    // LDS-DMA in inline asm (cdna_hip_programming.md 5.7): hipcc does not see these loads, so it neither counts
+    // them nor guards later ds_reads with vmcnt(0); their completion is ordered by the counted waits below.
+    // M0 carries the wave-uniform LDS byte address; the hardware adds lane*16.
+    typedef __attribute__((address_space(3))) float lds_f;
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)(ring + w * SLOT)));
+    auto issue = [&](int t, int slot) {           // 5 x 1 KiB wave-instructions: [q][row e_d][units 4*g4..]
+        const float* src = stash + (drow + t) * (6 * H) + 16 * w + 4 * g4;
+        const unsigned dst = ring_base + (unsigned)(slot * NW * SLOT * 4);
+        unsigned m0save;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0save)
+            : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(dst)
+            : "memory");
+    };
+    // prologue: steps T-1 and T-2 (clamped) -- always 5 + 5 ops so the counted waits below stay exact
+    issue(T - 1, (T - 1) & 1);
+    issue(T >= 2 ? T - 2 : 0, (T - 2) & 1);
+
+    int cur = 0;
+    const int nchunk = (T + TCB - 1) / TCB;
+    for (int ch = nchunk - 1; ch >= 0; --ch) {
+        const int t0 = ch * TCB, tc = min(TCB, T - t0);
+        for (int idx = threadIdx.x; idx < MT * tc * 8; idx += blockDim.x) {
+            const int e = idx / (tc * 8), rem = idx % (tc * 8), tt = rem >> 3, f = rem & 7;
+            const int n = min(n0 + e, N - 1);
+            dhbuf[(tt * MT + e) * 8 + f] = (f < NH) ? dheads[((size_t)n * T + t0 + tt) * NH + f] : 0.f;
+        }
+        for (int idx = threadIdx.x; idx < MT * tc; idx += blockDim.x) {
+            const int e = idx / tc, tt = idx % tc;
+            const int n = min(n0 + e, N - 1);
+            kbuf[tt * MT + e] = keep ? keep[(size_t)n * T + t0 + tt] : 1.f;
+        }
+        lds_barrier();
+        for (int tt = tc - 1; tt >= 0; --tt) {
+            const int t = t0 + tt;
+            float* dgw = dgbuf + cur * MT * S;
+            f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
+            {
+                const float* dr = &dhbuf[(tt * MT + j) * 8];
+                dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[kq], whb[0], dyacc, 0, 0, 0);
+                dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[4 + kq], whb[1], dyacc, 0, 0, 0);
+            }
+            // the slot of step t: issued two steps ago; only last step's 5 DMA ops may still be in flight
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            const float* sl = ring + ((t & 1) * NW + w) * SLOT;
+            float pf[4][5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) pf[r][q] = sl[q * 256 + (4 * kq + r) * 16 + j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = 4 * kq + r;
+                const float gi = pf[r][0], gf = pf[r][1], gg = pf[r][2], go = pf[r][3], cp = pf[r][4];
+                const float dh = dyacc[r] + dh_rec[r];
+                const float c = gf * cp + gi * gg;
+                const float tch = tanhf_(c);
+                const float dc = dh * go * (1.0f - tch * tch) + dc_next[r];
+                const float dgi = dc * gg * gi * (1.0f - gi);
+                const float dgf = dc * cp * gf * (1.0f - gf);
+                const float dgg = dc * gi * (1.0f - gg * gg);
+                const float dgo = dh * tch * go * (1.0f - go);
+                const float kp = kbuf[tt * MT + e];
+                dc_next[r] = dc * gf * kp;
+                dgw[e * S + 0 * H + u] = dgi;
+                dgw[e * S + 1 * H + u] = dgf;
+                dgw[e * S + 2 * H + u] = dgg;
+                dgw[e * S + 3 * H + u] = dgo;
+                if (n0 + e < N) {
+                    float* gp = dgates + (srow[r] + t) * (4 * H);
+                    gp[u] = dgi; gp[H + u] = dgf; gp[2 * H + u] = dgg; gp[3 * H + u] = dgo;
+                }
+            }
+            // refill this slot with step t-2 (all of this wave's reads of it have returned: lgkmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue(t >= 2 ? t - 2 : 0, t & 1);
+            lds_barrier();
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            const float* drow_l = dgw + j * S + kq * H;
+#pragma unroll
+            for (int s = 0; s < H; s += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(drow_l + s);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wt[s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wt[s + 1], a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wt[s + 2], a2, 0, 0, 0);
+                a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wt[s + 3], a3, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float kp = kbuf[tt * MT + 4 * kq + r];
+                dh_rec[r] = ((a0[r] + a1[r]) + (a2[r] + a3[r])) * kp;
+            }
+            cur ^= 1;
+        }
+        lds_barrier();     // kbuf / dhbuf are restaged by the next chunk
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the clamped tail DMAs before the LDS is released
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 4 * kq + r;
+        if (n < N) {
+            if (dh0) dh0[(size_t)n * H + u] = dh_rec[r];
+            if (dc0) dc0[(size_t)n * H + u] = dc_next[r];
+        }
+    }
+}
+
+template <int H>
+static int launch_bwd_dma(const float* keep, const float* stash, const float* w_hh, const float* dheads,
+                          const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
+                          float* dh0, float* dc0, hipStream_t st) {
+    const dim3 grid((N + MT - 1) / MT), block(H * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_dma_kernel<H>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdDmaGeom<H>::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_dma_kernel<H>), grid, block, BwdDmaGeom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
+                       NH, dhn, dcn, N, T, dgates, dh0, dc0);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int H>
 static int launch_fwd(bool fuse, const float* x, const float* keep, const float* h0, const float* c0,
                       const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int N, int T, int I,
@@ -389,6 +579,12 @@ __global__ void add2_kernel(const float* a0, const float* a1, float* b, int n) {
 static int lstm_bwd_seq(const float* keep, const float* stash, const float* w_hh, const float* dy,
                         const float* dheads, const float* w_head, int NH, const float* dhn, const float* dcn, int N,
                         int T, int H, float* dgates, float* dh0, float* dc0, hipStream_t st) {
+    if (dheads && !getenv("UAV_BWD_NO_DMA")) {          // the PPO path: LDS-DMA stash prefetch variant
+        switch (H) {
+            case 64: return launch_bwd_dma<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+            case 128: return launch_bwd_dma<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+        }
+    }
     switch (H) {
         case 64: return launch_bwd<64>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
         case 128: return launch_bwd<128>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
