@@ -24,6 +24,7 @@ def _close(a, b, rtol=2e-4, atol=2e-5):
 
 
 @pytest.mark.parametrize("T,N,I,H", [(8, 4, 6, 64), (16, 8, 6, 128), (70, 37, 6, 128), (5, 16, 8, 64), (33, 300, 4, 64),
+                                     (128, 64, 6, 128), (64, 128, 6, 64),      # shapes that take the LDS-DMA wgrad/bwd variants
                                      (12, 20, 64, 64), (9, 17, 128, 128), (1, 1, 6, 128)])
 @pytest.mark.parametrize("use_keep", [False, True])
 def test_lstm_layer_fwd_bwd(ops, T, N, I, H, use_keep):
