@@ -165,8 +165,8 @@ def main():
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
         if args.config == "c3" and os.path.exists(tf):
-            traffic = json.load(open(tf)).get("lstm_bwd_kernel<128>", {}).get("hbm_total_bytes")
-        roofline = {"kernel": "lstm_bwd_kernel<%d>" % H, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+            traffic = json.load(open(tf)).get("lstm_bwd_dma_kernel<128>", {}).get("hbm_total_bytes")
+        roofline = {"kernel": "lstm_bwd_dma_kernel<%d>" % H, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                     "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
                     "hbm_GBps_of_traffic": (traffic / (bwd["avg_ms"] * 1e-3) / 1e9) if traffic else None}
