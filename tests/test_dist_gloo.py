@@ -57,8 +57,9 @@ def _worker(rank, world, port, out):
     g = _grad(p, obs[sl], act[sl], logp[sl], adv_n, ret, val[lo:hi].reshape(-1), 1.0 / (N * T))
     du.allreduce_grad(g)
     fl = du.gather_episode_flags(torch.from_numpy(flags[lo:hi].copy()))
+    succ = du.gather_episode_successes(torch.from_numpy(flags[lo:hi].copy()))
     if rank == 0:
-        torch.save({"adv_n": adv_n, "grad": g, "flags": fl, "cnt": cnt}, out)
+        torch.save({"adv_n": adv_n, "grad": g, "flags": fl, "cnt": cnt, "succ": torch.from_numpy(succ)}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -75,3 +76,5 @@ def test_two_rank_exchange_equals_single_process(tmp_path):
     g = _grad(p, obs, act, logp, adv_n, ret, val.reshape(-1), 1.0 / (N * T))
     assert torch.allclose(got["grad"], g, rtol=1e-4, atol=1e-7)
     assert np.array_equal(got["flags"].numpy(), flags)
+    ended = (flags & 1) > 0
+    assert np.array_equal(got["succ"].numpy(), ((flags & 2) > 0)[ended])        # global (env, time) order

@@ -34,6 +34,28 @@ def allreduce_grad(flat_grad):
     return flat_grad
 
 
+def gather_episode_successes(flags):
+    """Success bits of the episodes that ENDED in this rollout, over all ranks, in (rank, env, time) =
+    global (env, time) order, as a host bool array.  Only the compacted bits travel: flags is non-zero
+    exactly where an episode ended (bit0 done, bit1 reached), so one device-side nonzero() + two tiny
+    all-gathers (counts, then padded bits) replace shipping the whole [N, T] array to every host."""
+    f = flags.reshape(-1)
+    idx = torch.nonzero(f).squeeze(1)
+    succ = ((f[idx] >> 1) & 1).to(torch.uint8)
+    if world() > 1:
+        cnt = torch.tensor([succ.numel()], dtype=torch.int64, device=f.device)
+        cnts = [torch.zeros_like(cnt) for _ in range(world())]
+        dist.all_gather(cnts, cnt)
+        cnts = [int(c.item()) for c in cnts]
+        m = max(max(cnts), 1)
+        pad = torch.zeros(m, dtype=torch.uint8, device=f.device)
+        pad[:succ.numel()] = succ
+        parts = [torch.empty_like(pad) for _ in range(world())]
+        dist.all_gather(parts, pad)
+        succ = torch.cat([p[:c] for p, c in zip(parts, cnts)])
+    return succ.cpu().numpy().astype(bool)
+
+
 def gather_episode_flags(flags):
     """[N_local, T] u8 flags of every rank concatenated in rank (= global env) order, so all ranks
     feed the SAME episode sequence to their replicated curriculum."""

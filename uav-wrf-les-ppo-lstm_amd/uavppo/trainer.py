@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist_utils import allreduce_adv_stats, allreduce_grad, env_shard, gather_episode_flags
+from .dist_utils import allreduce_adv_stats, allreduce_grad, env_shard, gather_episode_successes
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
 
@@ -232,13 +232,12 @@ class VecPPOTrainer:
 
     # ------------------------------------------------------------------------------------------ T1
     def update_curriculum(self):
-        """Feed this iteration's finished episodes to the curriculum (host scalars).  One small
-        device->host copy of the flags per iteration; ranks see the same global sequence."""
+        """Feed this iteration's finished episodes to the curriculum (host scalars).  The success bits are
+        compacted on the device; only they cross to the host / the other ranks, so every rank feeds the same
+        global (env, time)-ordered sequence to its replicated curriculum."""
         if self.curriculum is None:
             return
-        f = gather_episode_flags(self.buf["flags"]).cpu().numpy()
-        ended = (f & 1) > 0
-        self.curriculum.update_many(((f & 2) > 0)[ended])
+        self.curriculum.update_many(gather_episode_successes(self.buf["flags"]))
         self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
 
     def train_iteration(self):
