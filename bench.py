@@ -29,6 +29,11 @@ import torch.distributed as dist  # noqa: E402
 CONFIGS = {   # BASELINE.json configs (per-GPU env count; SURVEY 8 shorthand)
     "c2": dict(num_envs=256, horizon=64, hidden=64, layers=1, variant="v2.0"),
     "c3": dict(num_envs=4096, horizon=128, hidden=128, layers=1, variant="v2.0"),
+    # C4: 8192 envs over 8 GPUs = 1024 per GPU, sigma=15 (PPOV2.1), materialised bank of F=64 fields in HBM
+    "c4": dict(num_envs=1024, horizon=128, hidden=128, layers=1, variant="v2.1", bank_fields=64),
+    # C5 policy family: 32768 envs over 8 GPUs = 4096 per GPU, T=256, LSTM h=256 stacked x2 (generic per-step
+    # path; the trend-observation channels of C5 are not implemented: obs_dim stays 6)
+    "c5": dict(num_envs=4096, horizon=256, hidden=256, layers=2, variant="v2.1"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
 PEAK_HBM_GBS = 8000.0
@@ -116,8 +121,17 @@ def main():
     from uavppo.trainer import VecPPOTrainer
     cfg = CONFIGS[args.config]
     N, T, H = cfg["num_envs"], cfg["horizon"], cfg["hidden"]
+    bank = bank_src = None
+    if cfg.get("bank_fields"):
+        # synthetic bank generated with E3's formula by the procedural sampler itself (env_materialise kernel)
+        from uavppo.vec_env import VecMethaneEnv
+        F = cfg["bank_fields"]
+        gen = VecMethaneEnv(F, cfg["variant"], dev, seed=4321)
+        gen.reset()
+        bank = torch.stack([ops.env_materialise(gen.state, F, gen.cfg(), f) for f in range(F)])
+        bank_src = gen.peek()[1]
     tr = VecPPOTrainer(N, T, "lstm", hidden=H, layers=cfg["layers"], variant=cfg["variant"], device=dev,
-                       seed=1234, rank=rank, world_size=world)
+                       seed=1234, rank=rank, world_size=world, bank=bank, bank_sources=bank_src)
 
     def barrier():
         if world > 1:
@@ -157,7 +171,7 @@ def main():
     # its average duration, timed live with HIP events on the launch stream.  `traffic` = HBM bytes per
     # launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), measured at
     # this very shape and stored under profiles/ (a profiler cannot run inside the timed region).
-    fl_bwd = N * T * 2 * 4 * H * H
+    fl_bwd = N * T * 2 * 4 * H * H * cfg["layers"]
     bwd = timers.get("lstm_bwd")
     roofline = None
     if bwd:
@@ -175,7 +189,8 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
-        "config": {"workload": f"BASELINE configs[2] ({args.config}): PPOV2.0, {N} envs/GPU x T={T}, LSTM h={H}, obs 6, "
+        "config": {"workload": f"BASELINE config {args.config.upper()}: PPO{cfg['variant'].upper()}, {N} envs/GPU x T={T}, "
+                               f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs 6, "
                                f"5 actions, reference_exact GAE, {tr.hp['epochs']} epochs x {tr.num_minibatches} minibatch "
                                f"of {N * T} samples/GPU", "num_envs_per_gpu": N, "horizon": T, "hidden": H,
                    "minibatch_samples": N * T // tr.num_minibatches, "parallelism": f"dp{world} (env shards, RCCL grad all-reduce)"},
