@@ -31,9 +31,9 @@ CONFIGS = {   # BASELINE.json configs (per-GPU env count; SURVEY 8 shorthand)
     "c3": dict(num_envs=4096, horizon=128, hidden=128, layers=1, variant="v2.0"),
     # C4: 8192 envs over 8 GPUs = 1024 per GPU, sigma=15 (PPOV2.1), materialised bank of F=64 fields in HBM
     "c4": dict(num_envs=1024, horizon=128, hidden=128, layers=1, variant="v2.1", bank_fields=64),
-    # C5 policy family: 32768 envs over 8 GPUs = 4096 per GPU, T=256, LSTM h=256 stacked x2 (generic per-step
-    # path; the trend-observation channels of C5 are not implemented: obs_dim stays 6)
-    "c5": dict(num_envs=4096, horizon=256, hidden=256, layers=2, variant="v2.1"),
+    # C5: 32768 envs over 8 GPUs = 4096 per GPU, T=256, LSTM h=256 stacked x2, obs 6 + 2 trend channels
+    # (generic per-step LSTM path + step-wise rollout: correct, launch-bound)
+    "c5": dict(num_envs=4096, horizon=256, hidden=256, layers=2, variant="v2.1", trend_k=2),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
 PEAK_HBM_GBS = 8000.0
@@ -131,7 +131,8 @@ def main():
         bank = torch.stack([ops.env_materialise(gen.state, F, gen.cfg(), f) for f in range(F)])
         bank_src = gen.peek()[1]
     tr = VecPPOTrainer(N, T, "lstm", hidden=H, layers=cfg["layers"], variant=cfg["variant"], device=dev,
-                       seed=1234, rank=rank, world_size=world, bank=bank, bank_sources=bank_src)
+                       seed=1234, rank=rank, world_size=world, bank=bank, bank_sources=bank_src,
+                       trend_k=cfg.get("trend_k", 0))
 
     def barrier():
         if world > 1:
@@ -190,7 +191,7 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
         "config": {"workload": f"BASELINE config {args.config.upper()}: PPO{cfg['variant'].upper()}, {N} envs/GPU x T={T}, "
-                               f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs 6, "
+                               f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs {6 + cfg.get('trend_k', 0)}, "
                                f"5 actions, reference_exact GAE, {tr.hp['epochs']} epochs x {tr.num_minibatches} minibatch "
                                f"of {N * T} samples/GPU", "num_envs_per_gpu": N, "horizon": T, "hidden": H,
                    "minibatch_samples": N * T // tr.num_minibatches, "parallelism": f"dp{world} (env shards, RCCL grad all-reduce)"},

@@ -167,6 +167,9 @@ typedef struct uav_env_cfg {
     int32_t bonus_is_f64;   /* explore_bonus became np.float64 (model.py:142): f64 arithmetic */
     int32_t env_offset;     /* global index of this rank's env 0 (RNG key / field choice)   */
     int32_t n_env_total;    /* envs over all ranks; episode k of env e uses field (e+k*total)%F */
+    int32_t trend_k;        /* extra observation channels obs[6+i] = obs[2](t) - obs[2](t-1-i), i < trend_k <= 2
+                               (BASELINE C5 'trend obs'); every obs buffer then has 6 + trend_k features */
+    int32_t pad_;
     double  radius;         /* current_radius  (model.py:132)                               */
     double  bonus;          /* explore_bonus   (model.py:133)                               */
     uint64_t seed;          /* counter-RNG key (procedural fields, sources, step noise)     */
@@ -175,13 +178,13 @@ typedef struct uav_env_cfg {
 } uav_env_cfg;
 
 size_t uav_env_state_bytes(int n_env);
-/* reset every env (environment.py:41-49); obs_out f32 [n_env][6] */
+/* reset every env (environment.py:41-49); obs_out f32 [n_env][6 + trend_k] */
 int uav_env_reset(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg /*host*/,
                   float* obs_out, uav_stream stream);
 /* one step of every env with auto-reset (environment.py:82-169 + the reset of
  * train_ppo2.0.py:139).  act i32 [n]; noise f64 [n][2] standard normals or NULL (counter RNG).
- * obs_out [n][6] = next state to act on; rew f32 [n]; done f32 [n]; flags u8 [n] (bit0 done,
- * bit1 reached); info f32 [n][5] or NULL; term_obs [n][6] or NULL (obs of the ended step). */
+ * obs_out [n][6+trend_k] = next state to act on; rew f32 [n]; done f32 [n]; flags u8 [n] (bit0 done,
+ * bit1 reached); info f32 [n][5] or NULL; term_obs [n][6+trend_k] or NULL (obs of the ended step). */
 int uav_env_step(uav_ctx* ctx, void* state, int n_env, const uav_env_cfg* cfg /*host*/,
                  const int32_t* act, const double* noise, float* obs_out, float* rew, float* done,
                  uint8_t* flags, float* info, float* term_obs, double* rew64, uav_stream stream);

@@ -145,3 +145,33 @@ def test_env_offset_shards_are_consistent():
         of, rf, _, _ = full.step(a)
         os_, rs, _, _ = shard.step(a[4:].contiguous())
         assert torch.equal(of[4:], os_) and torch.equal(rf[4:], rs)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_trend_observation_channels(k):
+    """BASELINE C5 'trend obs': obs[6+i] = obs[2](t) - obs[2](t-1-i); the 6 reference features are unchanged
+    (bit-exact) and the extra channels equal the oracle's f32 differences, across auto-resets."""
+    from uavppo.vec_env import VecMethaneEnv
+    n, F = 3, 9
+    bank = FieldBank.from_seed(F, "v2.1", seed=12)
+    ora = OracleVecEnv(n, bank, "v2.1", radius=55.0, trend_k=k)
+    env = VecMethaneEnv(n, "v2.1", DEV, bank=bank.interleaved(), bank_sources=bank.sources, trend_k=k)
+    base = VecMethaneEnv(n, "v2.1", DEV, bank=bank.interleaved(), bank_sources=bank.sources)
+    env.current_radius = base.current_radius = 55.0
+    o_ref = ora.reset()
+    assert env.obs_dim == 6 + k and np.array_equal(env.reset().cpu().numpy(), o_ref)
+    base.reset()
+    rng = np.random.RandomState(5)
+    ndone = 0
+    for t in range(140):
+        act = homing(ora.envs) if t % 3 else rng.randint(0, 5, n).astype(np.int32)
+        z = rng.randn(n, 2)
+        o_ref, r_ref, d_ref, _, _, term_ref = ora.step(act, z)
+        a, zz = torch.from_numpy(act).to(DEV), torch.from_numpy(z).to(DEV)
+        o, r, d, _ = env.step(a, zz)
+        ob, rb, _, _ = base.step(a, zz)
+        assert np.array_equal(o.cpu().numpy(), o_ref), t
+        assert np.array_equal(env.term_obs.cpu().numpy(), term_ref), t
+        assert torch.equal(o[:, :6], ob) and torch.equal(r, rb)          # reference features / rewards untouched
+        ndone += int(d_ref.sum())
+    assert ndone >= 2

@@ -315,3 +315,19 @@ def test_lstm_trainer_edge_shapes(N, T, H):
     # GAE of the collected buffer against the oracle
     b = {k: v.cpu().numpy() for k, v in tr.buf.items()}
     assert np.allclose(tr.adv.cpu().numpy(), po.gae_reference_exact(b["rew"], b["val"], b["done"]), rtol=2e-5, atol=2e-5)
+
+
+def test_c5_trend_policy_trains():
+    """C5 shape family with the trend channels: obs_dim 8, stacked h=256 LSTM, step-wise rollout."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(32, 12, "lstm", hidden=256, layers=2, variant="v2.1", device=DEV, seed=3, trend_k=2,
+                       use_curriculum=False, epochs=2)
+    assert tr.buf["obs"].shape == (32, 12, 8) and tr.policy.views["lstm.weight_ih_l0"].shape == (1024, 8)
+    tr.train_iteration()
+    o = tr.buf["obs"]
+    assert torch.allclose(o[:, 1:, 6], o[:, 1:, 2] - o[:, :-1, 2], atol=1e-6) or bool((tr.buf["done"] > 0).any())
+    assert np.isfinite(tr.losses()).all()
+    # a fused-kernel-sized policy with trend obs also works (falls back to the step-wise rollout)
+    tr2 = VecPPOTrainer(40, 10, "lstm", hidden=128, device=DEV, seed=3, trend_k=1, use_curriculum=False, epochs=1)
+    tr2.train_iteration()
+    assert np.isfinite(tr2.losses()).all() and tr2.buf["obs"].shape[-1] == 7

@@ -29,6 +29,8 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
     P.n_env_total = cfg->n_env_total > 0 ? cfg->n_env_total : n_env;
     P.env_offset = cfg->env_offset;
     P.max_steps = (cfg->variant == UAV_ENV_V11) ? 5000 : 1000;           // config.py:7
+    UAV_REQUIRE(cfg->trend_k >= 0 && cfg->trend_k <= 2, "env: trend_k must be 0, 1 or 2");
+    P.trend_k = cfg->trend_k;
     P.radius = cfg->radius;
     P.reach_bonus = fmin(500.0, 150.0 * (50.0 / cfg->radius));
     P.bonus = cfg->bonus;
@@ -50,9 +52,10 @@ __global__ __launch_bounds__(256) void env_reset_kernel(EnvParams P, EnvBlob b, 
     unsigned short* vis = b.visited + (size_t)i * NVIS;
     env_begin_episode(P, P.env_offset + i, s, vis);
     env_store(b, i, s);
-    float o[6];
+    float o[8];
     env_obs(P, s, vis, o);
-    for (int k = 0; k < 6; ++k) obs_out[(size_t)i * 6 + k] = o[k];
+    const int od = 6 + P.trend_k;
+    for (int k = 0; k < od; ++k) obs_out[(size_t)i * od + k] = o[k];
 }
 
 __global__ __launch_bounds__(256) void env_step_kernel(EnvParams P, EnvBlob b, int n, const int32_t* __restrict__ act,
@@ -72,7 +75,8 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams P, EnvBlob b, i
     a = a < 0 ? 0 : (a > 4 ? 4 : a);
     StepOut o;
     env_step_core(P, eg, s, vis, a, z0, z1, o);
-    if (term_obs) for (int k = 0; k < 6; ++k) term_obs[(size_t)i * 6 + k] = o.obs[k];
+    const int od = 6 + P.trend_k;
+    if (term_obs) for (int k = 0; k < od; ++k) term_obs[(size_t)i * od + k] = o.obs[k];
     if (info) for (int k = 0; k < 5; ++k) info[(size_t)i * 5 + k] = (float)o.info[k];
     rew[i] = (float)o.reward;
     if (rew64) rew64[i] = o.reward;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams P, EnvBlob b, i
         env_obs(P, s, vis, o.obs);
     }
     env_store(b, i, s);
-    for (int k = 0; k < 6; ++k) obs_out[(size_t)i * 6 + k] = o.obs[k];
+    for (int k = 0; k < od; ++k) obs_out[(size_t)i * od + k] = o.obs[k];
 }
 
 __global__ __launch_bounds__(256) void env_peek_kernel(EnvBlob b, int n, float* pos, double* source, int32_t* steps,

@@ -17,7 +17,7 @@ constexpr int NVIS = CELLS * CELLS;
 
 struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived constants
     int variant, field_mode, n_fields, bonus_is_f64;
-    int n_env_total, env_offset, max_steps, pad_;
+    int n_env_total, env_offset, max_steps, trend_k;   // trend_k: extra observation channels (0..2)
     double radius, bonus, clip_hi, two_sigma2;
     double reach_bonus;       // min(500, 150*(50/radius)), environment.py:151 -- a per-launch constant
     uint64_t seed;
@@ -31,15 +31,16 @@ struct EnvState {             // registers of one env
     double sx, sy;            // source_pos
     int steps, episode;
     double conc, tke;         // conc = field/100 (the value obs[2] and prev_conc both use), tke = raw field
+    float q1, q2;             // obs[2] of the previous two observations (trend channels; reset value at episode start)
 };
 
 // SoA view of the caller-owned state blob
 struct EnvBlob {
-    float* px; float* py; double* sx; double* sy; int* steps; int* episode; double* conc; double* tke;
+    float* px; float* py; double* sx; double* sy; int* steps; int* episode; double* conc; double* tke; float* q1; float* q2;
     unsigned short* visited;  // [n][NVIS]
 };
 __host__ __device__ inline size_t env_blob_bytes(int n) {
-    return (size_t)n * (4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 2 * NVIS) + 256;
+    return (size_t)n * (4 + 4 + 8 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 2 * NVIS) + 256;
 }
 __host__ __device__ inline EnvBlob env_blob_view(void* base, int n) {
     EnvBlob b;
@@ -52,6 +53,8 @@ __host__ __device__ inline EnvBlob env_blob_view(void* base, int n) {
     b.py = (float*)p; p += (size_t)n * 4;
     b.steps = (int*)p; p += (size_t)n * 4;
     b.episode = (int*)p; p += (size_t)n * 4;
+    b.q1 = (float*)p; p += (size_t)n * 4;
+    b.q2 = (float*)p; p += (size_t)n * 4;
     b.visited = (unsigned short*)p;
     return b;
 }
@@ -59,11 +62,13 @@ __device__ __forceinline__ EnvState env_load(const EnvBlob& b, int i) {
     EnvState s;
     s.px = b.px[i]; s.py = b.py[i]; s.sx = b.sx[i]; s.sy = b.sy[i];
     s.steps = b.steps[i]; s.episode = b.episode[i]; s.conc = b.conc[i]; s.tke = b.tke[i];
+    s.q1 = b.q1[i]; s.q2 = b.q2[i];
     return s;
 }
 __device__ __forceinline__ void env_store(const EnvBlob& b, int i, const EnvState& s) {
     b.px[i] = s.px; b.py[i] = s.py; b.sx[i] = s.sx; b.sy[i] = s.sy;
     b.steps[i] = s.steps; b.episode[i] = s.episode; b.conc[i] = s.conc; b.tke[i] = s.tke;
+    b.q1[i] = s.q1; b.q2[i] = s.q2;
 }
 
 __device__ __forceinline__ int clipi(int v) { return v < 0 ? 0 : (v > GRID - 1 ? GRID - 1 : v); }
@@ -120,6 +125,10 @@ __device__ __forceinline__ void env_obs(const EnvParams& P, const EnvState& s, c
     o[3] = (float)(s.tke / 9.0);
     o[4] = (float)((double)s.steps / (double)P.max_steps);
     o[5] = lvl;
+    // trend channels (BASELINE C5 'grad[CH4] trend obs'; build-defined): change of the
+    // concentration feature against the previous one / two observations of the episode
+    o[6] = o[2] - s.q1;
+    o[7] = o[2] - s.q2;
 }
 
 // E2: start episode s.episode of env `env_global`
@@ -140,10 +149,11 @@ __device__ __forceinline__ void env_begin_episode(const EnvParams& P, int env_gl
     double c;
     field_at(P, env_global, s, 0, 0, c, s.tke);
     s.conc = c / 100.0;
+    s.q1 = s.q2 = (float)s.conc;
 }
 
 struct StepOut {
-    float obs[6];        // observation of the state AFTER the move (terminal obs if done)
+    float obs[8];        // observation of the state AFTER the move (terminal obs if done); [6],[7] = trend channels
     double reward;
     bool done, reached;
     double info[5];      // concentration_reward, explore_reward, move_penalty, tke_penalty, boundary_penalty
@@ -171,8 +181,11 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
     // only when the f32 rounding crosses an integer
     const int fx = clipi((int)s.px), fy = clipi((int)s.py);
     double craw;
+    const float o2_old = (float)s.conc;
     field_at(P, env_global, s, fx, fy, craw, s.tke);
     s.conc = craw / 100.0;
+    s.q2 = s.q1;
+    s.q1 = o2_old;
     const int cx = clipi((int)nx), cy = clipi((int)ny);
     double cur = s.conc;
     if (cx != fx || cy != fy) {

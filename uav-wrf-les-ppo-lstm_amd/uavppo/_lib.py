@@ -21,6 +21,7 @@ class EnvCfg(C.Structure):
     """struct uav_env_cfg (include/uavppo.h)."""
     _fields_ = [("variant", C.c_int32), ("field_mode", C.c_int32), ("n_fields", C.c_int32),
                 ("bonus_is_f64", C.c_int32), ("env_offset", C.c_int32), ("n_env_total", C.c_int32),
+                ("trend_k", C.c_int32), ("pad_", C.c_int32),
                 ("radius", C.c_double), ("bonus", C.c_double),
                 ("seed", C.c_uint64), ("bank", C.c_void_p), ("bank_src", C.c_void_p)]
 

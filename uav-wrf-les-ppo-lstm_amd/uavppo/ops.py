@@ -255,7 +255,7 @@ def env_state_bytes(n_env):
     return int(lib().uav_env_state_bytes(int(n_env)))
 
 
-def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_offset=0, n_env_total=0):
+def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_offset=0, n_env_total=0, trend_k=0):
     """uav_env_cfg (host struct).  bonus: python float -> the reference's f32 expression,
     numpy.float64 -> its f64 expression (see csrc/env_core.h, environment.py:133)."""
     import numpy as np
@@ -266,6 +266,7 @@ def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_o
     cfg.bonus_is_f64 = int(isinstance(bonus, np.float64))
     cfg.env_offset = int(env_offset)
     cfg.n_env_total = int(n_env_total)
+    cfg.trend_k = int(trend_k)
     cfg.radius = float(radius)
     cfg.bonus = float(bonus)
     cfg.seed = int(seed)
@@ -278,15 +279,15 @@ def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_o
 
 def env_reset(state, n_env, cfg, obs_out):
     check(lib().uav_env_reset(_h(state), _p(state, U8, name="env state"), n_env, C.byref(cfg),
-                              _p(obs_out, F32, (n_env, 6), "obs_out"), _stream()), "uav_env_reset")
+                              _p(obs_out, F32, (n_env, 6 + cfg.trend_k), "obs_out"), _stream()), "uav_env_reset")
 
 
 def env_step(state, n_env, cfg, act, obs_out, rew, done, flags, noise=None, info=None, term_obs=None, rew64=None):
     check(lib().uav_env_step(_h(state), _p(state, U8, name="env state"), n_env, C.byref(cfg),
                              _p(act, I32, (n_env,), "act"), _p(noise, F64, (n_env, 2), "noise"),
-                             _p(obs_out, F32, (n_env, 6), "obs_out"), _p(rew, F32, (n_env,), "rew"),
+                             _p(obs_out, F32, (n_env, 6 + cfg.trend_k), "obs_out"), _p(rew, F32, (n_env,), "rew"),
                              _p(done, F32, (n_env,), "done"), _p(flags, U8, (n_env,), "flags"),
-                             _p(info, F32, (n_env, 5), "info"), _p(term_obs, F32, (n_env, 6), "term_obs"),
+                             _p(info, F32, (n_env, 5), "info"), _p(term_obs, F32, (n_env, 6 + cfg.trend_k), "term_obs"),
                              _p(rew64, F64, (n_env,), "rew64"), _stream()), "uav_env_step")
 
 

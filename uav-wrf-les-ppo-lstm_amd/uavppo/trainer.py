@@ -24,7 +24,7 @@ DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, ent_beta=0.01, lr=3e-5, epochs=5
 class VecPPOTrainer:
     def __init__(self, num_envs, horizon, policy="lstm", hidden=128, layers=1, variant="v2.0", device="cuda",
                  seed=1234, gae_mode="reference_exact", num_minibatches=1, bank=None, bank_sources=None,
-                 rank=0, world_size=1, use_curriculum=True, **hp):
+                 rank=0, world_size=1, use_curriculum=True, trend_k=0, **hp):
         self.hp = dict(DEFAULTS)
         self.hp.update(hp)
         self.N, self.T = int(num_envs), int(horizon)
@@ -36,15 +36,17 @@ class VecPPOTrainer:
         if self.N % self.num_minibatches:
             raise ValueError("num_envs must be divisible by num_minibatches (minibatches are whole env sequences)")
         self.kind = policy
+        self.trend_k = int(trend_k)
+        self.obs_dim = D = 6 + self.trend_k      # 6 reference features + trend channels (BASELINE C5)
         if policy == "lstm":
-            self.policy = LSTMActorCritic(6, hidden, layers, 5, self.device, seed=self.seed)
+            self.policy = LSTMActorCritic(D, hidden, layers, 5, self.device, seed=self.seed)
         elif policy == "mlp":
-            self.policy = MLPActorCritic(6, 5, device=self.device, seed=self.seed)
+            self.policy = MLPActorCritic(D, 5, device=self.device, seed=self.seed)
         else:
             raise ValueError(policy)
         N, T, d = self.N, self.T, self.device
         f32 = dict(dtype=torch.float32, device=d)
-        self.buf = {"obs": torch.zeros(N, T, 6, **f32), "act": torch.zeros(N, T, dtype=torch.int32, device=d),
+        self.buf = {"obs": torch.zeros(N, T, D, **f32), "act": torch.zeros(N, T, dtype=torch.int32, device=d),
                     "rew": torch.zeros(N, T, **f32), "val": torch.zeros(N, T, **f32), "logp": torch.zeros(N, T, **f32),
                     "done": torch.zeros(N, T, **f32), "flags": torch.zeros(N, T, dtype=torch.uint8, device=d),
                     "keep": torch.ones(N, T, **f32)}
@@ -68,7 +70,7 @@ class VecPPOTrainer:
         self.log = []
         # environments of this rank: global indices [rank*N, (rank+1)*N)
         self.env_state = torch.zeros(ops.env_state_bytes(N), dtype=torch.uint8, device=d)
-        self.cur_obs = torch.zeros(N, 6, **f32)
+        self.cur_obs = torch.zeros(N, D, **f32)
         self.bank = None if bank is None else torch.as_tensor(bank, dtype=torch.float64).to(d).contiguous()
         self.bank_sources = None if bank_sources is None else torch.as_tensor(bank_sources, dtype=torch.float64).to(d).contiguous()
         self.curriculum = Curriculum() if use_curriculum else None
@@ -97,7 +99,8 @@ class VecPPOTrainer:
     # ------------------------------------------------------------------------------------------
     def env_cfg(self):
         return ops.make_env_cfg(self.variant, self.radius, self.bonus, self.seed, self.bank, self.bank_sources,
-                                env_offset=env_shard(self.rank, self.N)[0], n_env_total=self.world * self.N)
+                                env_offset=env_shard(self.rank, self.N)[0], n_env_total=self.world * self.N,
+                                trend_k=self.trend_k)
 
     def reset(self):
         ops.env_reset(self.env_state, self.N, self.env_cfg(), self.cur_obs)
@@ -108,7 +111,7 @@ class VecPPOTrainer:
     # ------------------------------------------------------------------------------------------ R1
     def collect(self, forced_act=None, noise=None):
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
-        if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128)):
+        if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128) or self.trend_k):
             self.h0.copy_(self.h)
             self.c0.copy_(self.c)
             self._collect_stepwise_lstm(forced_act, noise)
@@ -218,7 +221,7 @@ class VecPPOTrainer:
                                               self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work, want_heads=False)
                     ops.ppo_loss_from_y(y, self.policy.views["head.weight"], self.policy.views["head.bias"], *args)
                 else:
-                    heads = self.policy.heads(b["obs"][sl].reshape(nb * T, 6), stash=self.work["stash"])
+                    heads = self.policy.heads(b["obs"][sl].reshape(nb * T, self.obs_dim), stash=self.work["stash"])
                     ops.ppo_loss_heads(heads, *args)
                 grad = (self.policy.backward(self.dheads, self.work, self.dhead_bias) if self.kind == "lstm"
                         else self.policy.backward(self.dheads))

@@ -18,7 +18,7 @@ INFO_KEYS = ("concentration_reward", "explore_reward", "move_penalty", "tke_pena
 
 class VecMethaneEnv:
     def __init__(self, num_envs, variant="v2.0", device="cuda", seed=1234, bank=None, bank_sources=None,
-                 env_offset=0, n_env_total=None):
+                 env_offset=0, n_env_total=None, trend_k=0):
         self.num_envs = int(num_envs)
         self.variant = variant
         self.device = torch.device(device)
@@ -26,6 +26,8 @@ class VecMethaneEnv:
         self.env_offset = int(env_offset)
         self.n_env_total = int(n_env_total or num_envs)
         self.max_steps = ops.ENV_MAX_STEPS[variant]
+        self.trend_k = int(trend_k)          # extra obs channels: obs[2](t) - obs[2](t-1-i)  (BASELINE C5)
+        self.obs_dim = 6 + self.trend_k
         self.current_radius = 50.0           # INITIAL_RADIUS, config.py:27 / environment.py:31
         self.explore_bonus = 0.6             # EXPLORE_BONUS,  config.py:21 / environment.py:38
         self.bank = None if bank is None else torch.as_tensor(bank, dtype=torch.float64).to(self.device).contiguous()
@@ -33,17 +35,17 @@ class VecMethaneEnv:
                              torch.as_tensor(bank_sources, dtype=torch.float64).to(self.device).contiguous())
         n, d = self.num_envs, self.device
         self.state = torch.zeros(ops.env_state_bytes(n), dtype=torch.uint8, device=d)
-        self.obs = torch.zeros(n, 6, dtype=torch.float32, device=d)
+        self.obs = torch.zeros(n, self.obs_dim, dtype=torch.float32, device=d)
         self.rew = torch.zeros(n, dtype=torch.float32, device=d)
         self.rew64 = torch.zeros(n, dtype=torch.float64, device=d)
         self.done = torch.zeros(n, dtype=torch.float32, device=d)
         self.flags = torch.zeros(n, dtype=torch.uint8, device=d)
         self.info = torch.zeros(n, 5, dtype=torch.float32, device=d)
-        self.term_obs = torch.zeros(n, 6, dtype=torch.float32, device=d)
+        self.term_obs = torch.zeros(n, self.obs_dim, dtype=torch.float32, device=d)
 
     def cfg(self):
         return ops.make_env_cfg(self.variant, self.current_radius, self.explore_bonus, self.seed, self.bank,
-                                self.bank_sources, self.env_offset, self.n_env_total)
+                                self.bank_sources, self.env_offset, self.n_env_total, self.trend_k)
 
     def reset(self):
         ops.env_reset(self.state, self.num_envs, self.cfg(), self.obs)
