@@ -50,6 +50,10 @@ def cpu_baseline(seconds=12.0):
     import numpy as np
     from oracle import ppo_oracle as po
     from oracle.env_oracle import OracleEnv
+    # batch-1 forwards and 256-sample updates do not scale with threads; the box's default (128 threads on a
+    # 16-CPU share) oversubscribes and runs this loop ~6x SLOWER than one thread -- time the fast setting
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     torch.manual_seed(0)
     gen = torch.Generator().manual_seed(0)
     p = {}
@@ -86,7 +90,8 @@ def cpu_baseline(seconds=12.0):
             updates += 1
         state = env.reset() if d else o
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    torch.set_num_threads(prev_threads)
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": f"{steps} env steps of 1 env + {updates} _update_model calls (256-sample buffer, MLP policy, "
                       f"{dt:.1f} s) -- reference-faithful CPU loop of oracle/",
             "updates_per_s": updates / dt}
