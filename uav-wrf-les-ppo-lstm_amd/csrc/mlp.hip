@@ -124,14 +124,19 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_kernel(float* __restrict__ d,
     }
 }
 
-// out[c] = sum_b partial[b][c]  (fixed order)
+// out[c] = sum_b partial[b][c]: 8 independent partial sums in a fixed association (deterministic; a serial
+// 1024-deep chain cost 160 us per call)
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float* __restrict__ partial, int nb, int C,
                                                           float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * C + c];
-    out[c] = s;
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nb; b += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p8[k] += partial[(int64_t)(b + k) * C + c];
+    for (; b < nb; ++b) p8[0] += partial[(int64_t)b * C + c];
+    out[c] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
 }
 
 // partial[block][C] = sum over the block's rows of X[row][c]   (C <= 1024)
