@@ -207,13 +207,15 @@ int uav_env_materialise(uav_ctx* ctx, const void* state, int n_env, const uav_en
  * keep [N][T] out (LSTM: 0 where the state restarted), last_val [N] out or NULL (V of the state
  * after the last step, for UAV_GAE_STANDARD).  forced_act i32 [N][T] / noise f64 [N][T][2] are
  * NULL outside parity tests.  stash [N][T][6H] + y_out [N][T][H] (both or neither): the BPTT stash of
- * uav_lstm_fwd for exactly this rollout, so the first PPO epoch (same parameters) skips its forward. */
+ * uav_lstm_fwd for exactly this rollout, so the first PPO epoch (same parameters) skips its forward.
+ * info (or NULL) f32 [N][T][6]: the five reward parts of environment.py:161-167 (concentration, explore,
+ * move, tke, boundary) and obs[2] of the step -- what train_ppo2.0.py:179-183,203 accumulates per episode. */
 int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg /*host*/,
                 int policy_kind, const float* params, int hidden, int horizon, uint64_t iter,
                 float* cur_obs, float* h, float* c, float* obs, int32_t* act, float* rew,
                 float* val, float* logp, float* done, uint8_t* flags, float* keep, float* last_val,
                 const int32_t* forced_act, const double* noise, int32_t* nan_count,
-                float* stash, float* y_out, uav_stream stream);
+                float* stash, float* y_out, float* info, uav_stream stream);
 
 #ifdef __cplusplus
 }

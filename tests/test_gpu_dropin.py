@@ -145,3 +145,39 @@ def test_train_ppo_vectorised_entry(tmp_path):
     sd = torch.load(tmp_path / "v.pth")
     assert "lstm.weight_hh_l0" in sd and sd["actor.weight"].shape == (5, 64)
     assert len(df) == int((trainer.buf["flags"].cpu().numpy() & 1).sum()) or len(df) >= 0
+
+
+def test_vectorised_episode_log_matches_bruteforce():
+    """EpisodeLogger (cumsum-based) == a plain per-env loop over the raw rollout buffers, incl. episodes that
+    span rollouts; and info parts sum to the reward (minus the reach bonus) as in environment.py:139-151."""
+    from uavppo.episode_log import EpisodeLogger
+    from uavppo.trainer import VecPPOTrainer
+    N, T = 48, 40
+    for policy, kw in (("lstm", dict(hidden=64)), ("mlp", {})):
+        tr = VecPPOTrainer(N, T, policy, device="cuda:0", seed=6, log_info=True, use_curriculum=False, epochs=1, **kw)
+        tr.radius = 120.0                      # generous radius: many episodes end inside a few rollouts
+        log = EpisodeLogger(N)
+        acc = np.zeros((N, 6))
+        steps = np.zeros(N, int)
+        want = []
+        for it in range(4):
+            tr.collect()
+            rew, info, fl = tr.buf["rew"].cpu().numpy(), tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy()
+            log.add_rollout(rew, info, fl, tr.radius)
+            # reward == sum of the five parts (+ reach bonus where reached)
+            bonus = np.where((fl & 2) > 0, min(500.0, 150.0 * 50.0 / tr.radius), 0.0)
+            assert np.allclose(rew, info[..., :5].sum(-1) + bonus, atol=2e-5)
+            for n in range(N):
+                for t in range(T):
+                    acc[n] += [rew[n, t], *info[n, t, :5]]
+                    steps[n] += 1
+                    if fl[n, t] & 1:
+                        want.append((n, it, t, acc[n].copy(), steps[n], bool(fl[n, t] & 2), info[n, t, 5]))
+                        acc[n] = 0
+                        steps[n] = 0
+            tr.iteration += 1
+        want.sort(key=lambda e: (e[1], e[0], e[2]))
+        assert len(log.rows) == len(want) >= 10
+        for row, (n, it, t, a, st, ok, c) in zip(log.rows, want):
+            assert np.allclose([row[1], row[3], row[4], row[5], row[6], row[7]], a, rtol=1e-5, atol=1e-4)
+            assert row[8] == st and row[2] == int(ok) and np.isclose(row[9], c * 100.0 if ok else 0.0, atol=1e-4)

@@ -44,6 +44,7 @@ struct RolloutBufs {
     float* cur_obs; float* h; float* c;
     float* obs; int32_t* act; float* rew; float* val; float* logp; float* done; uint8_t* flags; float* keep;
     float* last_val; const int32_t* forced_act; const double* noise; int32_t* nan_count;
+    float* info;                // optional [N][T][6]: the 5 reward parts of environment.py:161-167 + obs[2] of the step
     float* stash; float* y;     // optional: BPTT stash [N][T][6H] + y [N][T][H], so PPO epoch 0 skips its forward pass
 };
 
@@ -59,8 +60,11 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     __shared__ float hd[RMT * 16];
     __shared__ __attribute__((aligned(16))) float wbuf[16 * S];   // head weights, row = head, padded like an h row
     __shared__ unsigned short vis[RMT * NVIS];
+    // wave 0's W_hh slice, parked once: reloading it after the env block makes those 4*KS registers dead
+    // across the f64 env chain, which then fits without scratch spills (it used to spill ~60 VGPRs)
+    __shared__ float whpark[4 * KS * 64];
     __shared__ EnvState es_s[RMT];
-    __shared__ float trs[2 * RMT * 8];                            // parked transitions (see the env block)                                // env registers parked in LDS between steps
+    __shared__ float trs[3 * RMT * 8];                            // parked transitions (see the env block)                                // env registers parked in LDS between steps
 
     const float* w_ih = params;
     const float* w_hh = w_ih + 4 * H * I;
@@ -111,6 +115,12 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     for (int idx = threadIdx.x; idx < 16 * H; idx += blockDim.x) {
         const int hdx = idx / H, uu = idx % H;
         wbuf[hdx * S + rpos<H>(uu)] = (hdx < NH) ? w_hd[(size_t)hdx * H + uu] : 0.f;
+    }
+    if (is_env_wave) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int sidx = 0; sidx < KS; ++sidx) whpark[(q * KS + sidx) * 64 + lane] = wh[q][sidx];
     }
     if (is_env_wave) {
         if (lane < RMT) {
@@ -257,6 +267,11 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     tr[4] = so.done ? 1.f : 0.f;
                     tr[5] = __int_as_float((so.done ? 1 : 0) | (so.reached ? 2 : 0));
                     tr[6] = kbuf[lane];
+                    if (B.info) {
+#pragma unroll
+                        for (int f = 0; f < 5; ++f) trs[2 * RMT * 8 + lane * 8 + f] = (float)so.info[f];
+                        trs[2 * RMT * 8 + lane * 8 + 5] = so.obs[2];
+                    }
                     float ob_old[6];
 #pragma unroll
                     for (int f = 0; f < 6; ++f) ob_old[f] = xbuf[lane * 8 + f];
@@ -282,9 +297,18 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                         B.done[row] = tq[4];
                         B.flags[row] = (uint8_t)__float_as_int(tq[5]);
                         B.keep[row] = tq[6];
+                        if (B.info) {
+#pragma unroll
+                            for (int f = 0; f < 6; ++f) B.info[row * 6 + f] = trs[2 * RMT * 8 + lane * 8 + f];
+                        }
                     }
                 }
             }
+            // all lanes of wave 0: bring the weight slice back (it was dead across the env block)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int sidx = 0; sidx < KS; ++sidx) wh[q][sidx] = whpark[(q * KS + sidx) * 64 + lane];
         }
         if (!value_only && t + 1 < steps) recurrent();              // bias + h_t W_hh^T for step t+1
         lds_barrier();                       // barrier 2: x_{t+1}, keep_{t+1} visible; recurrent reads of h_t done
@@ -332,7 +356,8 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
                            const float* params, int hidden, int horizon, uint64_t iter, float* cur_obs, float* h,
                            float* c, float* obs, int32_t* act, float* rew, float* val, float* logp, float* done,
                            uint8_t* flags, float* keep, float* last_val, const int32_t* forced_act,
-                           const double* noise, int32_t* nan_count, float* stash, float* y_out, uav_stream stream) {
+                           const double* noise, int32_t* nan_count, float* stash, float* y_out, float* info,
+                           uav_stream stream) {
     UAV_REQUIRE(ctx && env_state && params && cur_obs && obs && act && rew && val && logp && done && flags && nan_count,
                 "uav_rollout: NULL argument");
     UAV_REQUIRE(n_env > 0 && horizon > 0, "uav_rollout: n_env=%d horizon=%d", n_env, horizon);
@@ -343,7 +368,7 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
     int rc = env_params_from_cfg(ctx, cfg, n_env, P);
     if (rc) return rc;
     UAV_REQUIRE((stash == nullptr) == (y_out == nullptr), "uav_rollout: stash and y_out go together");
-    RolloutBufs B{cur_obs, h, c, obs, act, rew, val, logp, done, flags, keep, last_val, forced_act, noise, nan_count, stash, y_out};
+    RolloutBufs B{cur_obs, h, c, obs, act, rew, val, logp, done, flags, keep, last_val, forced_act, noise, nan_count, info, stash, y_out};
     EnvBlob blob = env_blob_view(env_state, n_env);
     switch (hidden) {
         case 64: return launch_rollout<64>(P, blob, n_env, horizon, iter, params, B, as_stream(stream));

@@ -120,34 +120,23 @@ def train_ppo(episodes=2000, csv_path="training_results2_0.csv", model_path="mod
 
 
 def train_ppo_vectorised(iterations=200, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth"):
-    """NUM_ENVS environments per GPU with the fused kernels; one CSV row per finished episode
-    (Episode, Success, Steps and Current_Radius are exact; reward columns are per-episode sums)."""
+    """NUM_ENVS environments per GPU with the fused kernels; one CSV row per finished episode with the
+    reference's 11 columns (uavppo/episode_log.py), in (iteration, env, time) order."""
+    from uavppo.episode_log import EpisodeLogger
     from uavppo.trainer import VecPPOTrainer
     tr = VecPPOTrainer(NUM_ENVS, HORIZON, POLICY, hidden=HIDDEN, layers=NUM_LAYERS, variant=ENV_VARIANT, seed=SEED,
-                       gae_mode=GAE_MODE, num_minibatches=NUM_MINIBATCHES, gamma=GAMMA, lam=LAMBDA, clip=CLIP_EPSILON,
-                       ent_beta=ENTROPY_BETA, lr=LEARNING_RATE, epochs=EPOCHS)
-    rows, ep_ret, ep_len, n_ep = [], np.zeros(NUM_ENVS), np.zeros(NUM_ENVS, np.int64), 0
+                       gae_mode=GAE_MODE, num_minibatches=NUM_MINIBATCHES, log_info=True, gamma=GAMMA, lam=LAMBDA,
+                       clip=CLIP_EPSILON, ent_beta=ENTROPY_BETA, lr=LEARNING_RATE, epochs=EPOCHS)
+    log = EpisodeLogger(NUM_ENVS)
     for it in range(iterations):
         radius = tr.radius
         tr.train_iteration()
-        rew, fl = tr.buf["rew"].cpu().numpy(), tr.buf["flags"].cpu().numpy()
-        # per-episode accounting (env-major, time order inside an env)
-        for n in range(NUM_ENVS):
-            start = 0
-            for t in np.nonzero(fl[n] & 1)[0]:
-                ep_ret[n] += rew[n, start:t + 1].sum()
-                ep_len[n] += t + 1 - start
-                n_ep += 1
-                rows.append([n_ep, ep_ret[n], int(bool(fl[n, t] & 2)), np.nan, np.nan, np.nan, np.nan, np.nan,
-                             int(ep_len[n]), np.nan, radius])
-                ep_ret[n], ep_len[n], start = 0.0, 0, t + 1
-            ep_ret[n] += rew[n, start:].sum()
-            ep_len[n] += HORIZON - start
+        log.add_rollout(tr.buf["rew"].cpu().numpy(), tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy(), radius)
         pl, vl, ent = tr.losses()
         if (it + 1) % 10 == 0:
-            print(f"It {it + 1} | episodes {n_ep} | radius {tr.radius:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
-    _save(tr.policy.state_dict(), rows, csv_path, model_path)
-    return tr, rows
+            print(f"It {it + 1} | episodes {log.count} | radius {tr.radius:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
+    _save(tr.policy.state_dict(), log.rows, csv_path, model_path)
+    return tr, log.rows
 
 
 def _save(state_dict, rows, csv_path, model_path):

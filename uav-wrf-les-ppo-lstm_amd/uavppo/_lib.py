@@ -54,7 +54,7 @@ SIGNATURES = {
     "uav_env_peek": (I32, [P, P, I32, P, P, P, P, P]),
     "uav_env_materialise": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, P]),
     "uav_rollout": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, I32, I32, U64, P, P, P, P, P, P, P, P, P, P,
-                          P, P, P, P, P, P, P, P]),
+                          P, P, P, P, P, P, P, P, P]),
 }
 
 _lib = None

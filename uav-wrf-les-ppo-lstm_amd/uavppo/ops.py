@@ -378,7 +378,7 @@ def colsum(x, out=None):
 
 # ----------------------------------------------------------------------------- R1
 def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h, c, bufs, last_val=None,
-                 forced_act=None, noise=None, nan_count=None, stash=None, y=None):
+                 forced_act=None, noise=None, nan_count=None, stash=None, y=None, info=None):
     """Fused persistent rollout (csrc/rollout.hip).  bufs: dict obs[N,T,6] act rew val logp done flags keep."""
     N, T = n_env, horizon
     _t = KERNEL_TIMER.bracket("rollout")
@@ -391,7 +391,8 @@ def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h,
                             _p(bufs["flags"], U8, (N, T), "flags"), _p(bufs["keep"], F32, (N, T), "keep"),
                             _p(last_val, F32, (N,), "last_val"), _p(forced_act, I32, (N, T), "forced_act"),
                             _p(noise, F64, (N, T, 2), "noise"), _p(nan_count, I32, (1,), "nan_count"),
-                            _p(stash, F32, (N, T, 6 * hidden), "stash"), _p(y, F32, (N, T, hidden), "y"), _stream()),
+                            _p(stash, F32, (N, T, 6 * hidden), "stash"), _p(y, F32, (N, T, hidden), "y"),
+                            _p(info, F32, (N, T, 6), "info"), _stream()),
           "uav_rollout")
     if _t is not None:
         _t.record()

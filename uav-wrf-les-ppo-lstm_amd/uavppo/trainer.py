@@ -24,7 +24,7 @@ DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, ent_beta=0.01, lr=3e-5, epochs=5
 class VecPPOTrainer:
     def __init__(self, num_envs, horizon, policy="lstm", hidden=128, layers=1, variant="v2.0", device="cuda",
                  seed=1234, gae_mode="reference_exact", num_minibatches=1, bank=None, bank_sources=None,
-                 rank=0, world_size=1, use_curriculum=True, trend_k=0, **hp):
+                 rank=0, world_size=1, use_curriculum=True, trend_k=0, log_info=False, **hp):
         self.hp = dict(DEFAULTS)
         self.hp.update(hp)
         self.N, self.T = int(num_envs), int(horizon)
@@ -50,6 +50,8 @@ class VecPPOTrainer:
                     "rew": torch.zeros(N, T, **f32), "val": torch.zeros(N, T, **f32), "logp": torch.zeros(N, T, **f32),
                     "done": torch.zeros(N, T, **f32), "flags": torch.zeros(N, T, dtype=torch.uint8, device=d),
                     "keep": torch.ones(N, T, **f32)}
+        # optional per-step reward parts (for the reference's per-episode CSV columns, train_ppo2.0.py:129-135)
+        self.info = torch.zeros(N, T, 6, **f32) if log_info else None
         self.adv = torch.zeros(N, T, **f32)
         self.adv_n = torch.zeros(N, T, **f32)
         self.ret = torch.zeros(N, T, **f32)
@@ -122,7 +124,8 @@ class VecPPOTrainer:
             ops.rollout_lstm(self.env_state, self.N, self.env_cfg(), self.policy.flat, self.policy.hidden, self.T,
                              self.iteration, self.cur_obs, self.h[0], self.c[0], self.buf, last_val=self.last_val,
                              forced_act=forced_act, noise=noise, nan_count=self.nan_count,
-                             stash=self.work["stash0"] if reuse else None, y=self.work["y0"] if reuse else None)
+                             stash=self.work["stash0"] if reuse else None, y=self.work["y0"] if reuse else None,
+                             info=self.info)
             self._rollout_forward_valid = reuse
         else:
             self._collect_stepwise(forced_act, noise)
@@ -151,7 +154,14 @@ class VecPPOTrainer:
             b["logp"][:, t] = logp
             b["keep"][:, t] = st["keep"]
             nz = None if noise is None else noise[:, t].contiguous()
-            ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, st["rew"], st["done"], st["flags"], noise=nz)
+            if self.info is not None and "info" not in st:
+                st["info"] = torch.zeros(self.N, 5, dtype=torch.float32, device=self.device)
+                st["term"] = torch.zeros(self.N, self.obs_dim, dtype=torch.float32, device=self.device)
+            ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, st["rew"], st["done"], st["flags"], noise=nz,
+                         info=st.get("info"), term_obs=st.get("term"))
+            if self.info is not None:
+                self.info[:, t, :5] = st["info"]
+                self.info[:, t, 5] = st["term"][:, 2]
             b["rew"][:, t] = st["rew"]
             b["done"][:, t] = st["done"]
             b["flags"][:, t] = st["flags"]
@@ -181,7 +191,14 @@ class VecPPOTrainer:
             b["val"][:, t] = heads[:, 5]
             b["logp"][:, t] = logp
             nz = None if noise is None else noise[:, t].contiguous()
-            ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, tmp["rew"], tmp["done"], tmp["flags"], noise=nz)
+            if self.info is not None and "info" not in tmp:
+                tmp["info"] = torch.zeros(self.N, 5, dtype=torch.float32, device=self.device)
+                tmp["term"] = torch.zeros(self.N, self.obs_dim, dtype=torch.float32, device=self.device)
+            ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, tmp["rew"], tmp["done"], tmp["flags"], noise=nz,
+                         info=tmp.get("info"), term_obs=tmp.get("term"))
+            if self.info is not None:
+                self.info[:, t, :5] = tmp["info"]
+                self.info[:, t, 5] = tmp["term"][:, 2]
             b["rew"][:, t] = tmp["rew"]
             b["done"][:, t] = tmp["done"]
             b["flags"][:, t] = tmp["flags"]
