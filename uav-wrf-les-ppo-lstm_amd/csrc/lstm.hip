@@ -40,6 +40,11 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
                      float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
+// UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split-bf16 ones)
+static bool f32_mfma_requested() {
+    static const bool v = getenv("UAV_LSTM_F32_MFMA") != nullptr;
+    return v;
+}
 constexpr int TC = 32;      // time steps staged per chunk
 
 #define sigmoidf_ fast_sigmoid
@@ -206,6 +211,274 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(
             cn[(size_t)n * H + u] = c_reg[r];
         }
     }
+}
+
+// ------------------------------------------------------------------------- forward, split-bf16 MFMA
+// Same recurrence, but the h W_hh^T product runs on the bf16 matrix pipe at f32 accuracy: every f32 operand is
+// split into three bf16 pieces (a = a0 + a1 + a2, 8 significand bits each, so the split is exact) and the six
+// piece products a_i b_j with i + j <= 2 are accumulated in f32 by v_mfma_f32_16x16x32_bf16.  The dropped
+// products are below 2^-24 |a b|, i.e. under the rounding of the f32 accumulation itself: measured error equals
+// the exact-f32 MFMA chain's (tools/bf16x6_probe.hip: 2.69e-7 vs 2.75e-7 on a K=128 dot product) at 2.6x its
+// rate (6 x 16 cycles per K=32 slab against 8 x 32).  W_hh pieces stay in VGPRs (192 at H=128); h_t is split
+// once by the lane that produces it and exchanged through three bf16 LDS planes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
+    p0 = (__bf16)a;
+    const float r1 = a - (float)p0;
+    p1 = (__bf16)r1;
+    p2 = (__bf16)(r1 - (float)p1);
+}
+__device__ __forceinline__ unsigned short bf_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
+template <int H>
+struct FwdX6Geom {
+    static constexpr int NS = H / 32;          // K = 32 slabs over the hidden dimension
+    static constexpr int RS = H + 8;           // bf16 elements per padded row: 16 lanes x ds_read_b128 conflict-free
+    static constexpr int PLANE = MT * RS;
+    // three bf16 pieces of W_hh are 1.5x its f32 size = 3/4 of the CU's register file at H=128: the smallest
+    // piece of QL of the four gates lives in a wave-private LDS slab instead (read back as lane-contiguous b128)
+    static constexpr int QL = (H >= 128) ? 3 : 0;
+    static constexpr int WPARK = QL * NS * 64 * 8;                       // bf16 elements per wave
+    static constexpr int TCX = 16;                                       // steps of x / keep staged per chunk
+    static constexpr int XPT = MT * TCX * 8 / (H * 4);                   // staged x elements per thread
+    static constexpr size_t LDS = (2 * 3 * PLANE + (H / 16) * WPARK) * sizeof(unsigned short) +
+                                  (2 * TCX * MT * 8 + 2 * TCX * MT + (H / 16) * 8 * 64 + 4 * H) * sizeof(float);
+};
+
+#ifdef UAV_X6_PROFILE
+// phase timing of the split-bf16 forward (instrumented build only, -DUAV_X6_PROFILE): s_memtime at four marks
+// per step, summed over the sequence by wave 0 and the last wave of workgroup 0
+__device__ unsigned long long g_x6_prof[2][4];
+#define X6_PROF_DECL unsigned long long pm_[4] = {0, 0, 0, 0}, pl_ = __builtin_readcyclecounter()
+#define X6_PROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pm_[i] += n_ - pl_; pl_ = n_; } while (0)
+#define X6_PROF_DEP(v) asm volatile("" ::"v"(v))
+#define X6_PROF_FLUSH() do { if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == H / 16 - 1)) \
+        for (int i_ = 0; i_ < 4; ++i_) g_x6_prof[w ? 1 : 0][i_] = pm_[i_]; } while (0)
+extern "C" int uav_x6_prof_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6_prof), sizeof(g_x6_prof)) == hipSuccess ? 0 : 1;
+}
+#else
+#define X6_PROF_DECL
+#define X6_PROF_MARK(i)
+#define X6_PROF_DEP(v)
+#define X6_PROF_FLUSH()
+#endif
+
+// Orientation: gates^T = W h^T, i.e. the WEIGHTS are the MFMA A operand (16 units of one gate) and h^T the B
+// operand (16 envs), so a lane's four accumulator rows are four CONSECUTIVE units of ONE env: y and the five
+// stash values leave as dwordx4 stores (6 per step instead of 24 dword stores -- the vector-memory issue rate,
+// 16 cycles per wave-instruction, paced the step as much as the MFMAs did), h_t is parked with one ds_write_b64
+// per piece, and keep is one value per lane.
+template <int H, bool FUSE_X>
+__global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
+    const float* __restrict__ x, const float* __restrict__ keep, const float* __restrict__ h0,
+    const float* __restrict__ c0, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+    const float* __restrict__ b_ih, const float* __restrict__ b_hh, int N, int T, int I,
+    float* __restrict__ y, float* __restrict__ hn, float* __restrict__ cn, float* __restrict__ stash) {
+    using G = FwdX6Geom<H>;
+    constexpr int NS = G::NS, RS = G::RS, PLANE = G::PLANE, QL = G::QL, WPARK = G::WPARK, TC = G::TCX, XPT = G::XPT;
+    constexpr int NT = H * 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* hpl = reinterpret_cast<unsigned short*>(smem);       // [2][3 pieces][MT][RS] bf16
+    unsigned short* wpark = hpl + 2 * 3 * PLANE;                         // [waves][QL][NS][64 lanes][8] bf16
+    float* xbuf = reinterpret_cast<float*>(wpark + (H / 16) * WPARK);    // [2][TC][MT][8]
+    float* kbuf = xbuf + 2 * TC * MT * 8;                                // [2][TC][MT]: keep[t + 1] of the chunk's steps
+    float* wxl = kbuf + 2 * TC * MT;                                     // [waves][4 gates][2 k-steps][64 lanes]
+    float* bl = wxl + (H / 16) * 512;                                    // [4H] b_ih + b_hh
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int uw = 16 * w + j;                 // unit whose weight row this lane holds (A operand row)
+    const int uo = 16 * w + 4 * kq;            // first of this lane's four output units; its env is j
+    const int n0 = blockIdx.x * MT;
+    const int n = min(n0 + j, N - 1);
+    const bool live = n0 + j < N;
+
+    // A fragments of 16x16x32: lane (j, kq) holds k = 32 s + 8 kq .. + 7 of unit uw, per gate q and piece p
+    bf16x8 wb[4][NS][2], wb2[4 - QL][NS];
+    bf16x8* const wpk = reinterpret_cast<bf16x8*>(wpark + w * WPARK) + lane;      // + (q * NS + s) * 64
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float* src = w_hh + (size_t)(q * H + uw) * H + 32 * s + 8 * kq;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            bf16x8 p2v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __bf16 p0, p1, p2;
+                split3(v[i], p0, p1, p2);
+                wb[q][s][0][i] = p0; wb[q][s][1][i] = p1; p2v[i] = p2;
+            }
+            if (q < QL) wpk[(q * NS + s) * 64] = p2v;
+            else wb2[q < QL ? 0 : q - QL][s] = p2v;
+        }
+    float* const wxw = wxl + w * 512 + lane;                             // this lane's W_ih fragments: + (2 q + s) * 64
+    if (FUSE_X) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * kq + s;
+                wxw[(2 * q + s) * 64] = (k < I) ? w_ih[(size_t)(q * H + uw) * I + k] : 0.f;
+            }
+        for (int idx = threadIdx.x; idx < 4 * H; idx += NT) bl[idx] = b_ih[idx] + b_hh[idx];
+    }
+    auto put_h = [&](unsigned short* plane0, const float (&hv)[4]) {     // split and park h[env j][uo .. uo+3]
+        unsigned short b[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            __bf16 p0, p1, p2;
+            split3(hv[r], p0, p1, p2);
+            b[0][r] = bf_bits(p0); b[1][r] = bf_bits(p1); b[2][r] = bf_bits(p2);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            uint2 v;
+            v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+            v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+            *reinterpret_cast<uint2*>(plane0 + pc * PLANE + j * RS + uo) = v;
+        }
+    };
+
+    // chunk staging through registers: chunk c + 1 is loaded while chunk c runs, committed to the other buffer
+    float xr[XPT], kr = 1.f;
+    auto stage_load = [&](int t0) {
+        if (FUSE_X) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int idx = threadIdx.x + i * NT;                    // (e, tt, f) with f fastest
+                const int e = idx / (TC * 8), tt = (idx >> 3) % TC, f = idx & 7;
+                const int ne = min(n0 + e, N - 1), t = min(t0 + tt, T - 1);
+                xr[i] = (f < I) ? x[((size_t)ne * T + t) * I + f] : 0.f;
+            }
+        }
+        if (threadIdx.x < TC * MT) {
+            const int e = threadIdx.x / TC, tt = threadIdx.x % TC;
+            const int ne = min(n0 + e, N - 1), t = t0 + tt + 1;
+            kr = (keep && t < T) ? keep[(size_t)ne * T + t] : 1.f;
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (FUSE_X) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int e = idx / (TC * 8), tt = (idx >> 3) % TC, f = idx & 7;
+                xbuf[((buf * TC + tt) * MT + e) * 8 + f] = xr[i];
+            }
+        }
+        if (threadIdx.x < TC * MT) kbuf[(buf * TC + threadIdx.x % TC) * MT + threadIdx.x / TC] = kr;
+    };
+
+    float c_reg[4];
+    {
+        const float k0 = keep ? keep[(size_t)n * T] : 1.f;
+        const float4 cv = *reinterpret_cast<const float4*>(c0 + (size_t)n * H + uo);
+        const float4 hv4 = *reinterpret_cast<const float4*>(h0 + (size_t)n * H + uo);
+        c_reg[0] = cv.x * k0; c_reg[1] = cv.y * k0; c_reg[2] = cv.z * k0; c_reg[3] = cv.w * k0;
+        const float hv[4] = {hv4.x * k0, hv4.y * k0, hv4.z * k0, hv4.w * k0};
+        put_h(hpl, hv);
+        if (stash && I > 6 && live)                                      // h_prev of step 0 (generic wgrad path)
+            *reinterpret_cast<float4*>(stash + ((size_t)n * T) * (6 * H) + 5 * H + uo) = float4{hv[0], hv[1], hv[2], hv[3]};
+    }
+    stage_load(0);
+    stage_commit(0);
+    int cur = 0;
+    X6_PROF_DECL;
+    lds_barrier();
+
+    const int nchunk = (T + TC - 1) / TC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int t0 = ch * TC, tc = min(TC, T - t0), xb = ch & 1;
+        if (ch + 1 < nchunk) stage_load(t0 + TC);
+        for (int tt = 0; tt < tc; ++tt) {
+            const int t = t0 + tt;
+            const size_t row = (size_t)n * T + t;
+            X6_PROF_MARK(0);
+            f32x4 acc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = FUSE_X ? *reinterpret_cast<const float4*>(bl + q * H + uo)
+                                        : *reinterpret_cast<const float4*>(stash + row * (6 * H) + q * H + uo);
+                acc[q] = f32x4{v.x, v.y, v.z, v.w};
+            }
+            if (FUSE_X) {       // K = I <= 8 input projection: two exact-f32 k-steps
+                const float2 ax = *reinterpret_cast<const float2*>(&xbuf[((xb * TC + tt) * MT + j) * 8 + 2 * kq]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q) * 64], ax.x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q + 1) * 64], ax.y, acc[q], 0, 0, 0);
+                }
+            }
+            const unsigned short* hrow = hpl + cur * 3 * PLANE + j * RS + 8 * kq;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hrow + 32 * s);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hrow + PLANE + 32 * s);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(hrow + 2 * PLANE + 32 * s);
+                // smallest products first; four independent accumulators between dependent MFMAs
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q][s][0], a2, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q][s][1], a1, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 b2 = (q < QL) ? wpk[(q * NS + s) * 64] : wb2[q < QL ? 0 : q - QL][s];
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a0, acc[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q][s][0], a1, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q][s][1], a0, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q][s][0], a0, acc[q], 0, 0, 0);
+            }
+            X6_PROF_DEP(acc[0][0]); X6_PROF_DEP(acc[1][1]); X6_PROF_DEP(acc[2][2]); X6_PROF_DEP(acc[3][3]);
+            X6_PROF_MARK(1);
+            const float kn = kbuf[(xb * TC + tt) * MT + j];              // keep of step t+1 (1 past the end)
+            float gi[4], gf[4], gg[4], go[4], cp[4], hh[4], hm[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gi[r] = sigmoidf_(acc[0][r]); gf[r] = sigmoidf_(acc[1][r]);
+                gg[r] = tanhf_(acc[2][r]); go[r] = sigmoidf_(acc[3][r]);
+                cp[r] = c_reg[r];
+                const float c = gf[r] * cp[r] + gi[r] * gg[r];
+                hh[r] = go[r] * tanhf_(c);
+                hm[r] = hh[r] * kn;
+                c_reg[r] = (t == T - 1) ? c : c * kn;                    // cn is the unmasked final cell state
+            }
+            put_h(hpl + (cur ^ 1) * 3 * PLANE, hm);
+            if (live) {
+                *reinterpret_cast<float4*>(y + row * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
+                if (stash) {
+                    float* sp = stash + row * (6 * H) + uo;
+                    *reinterpret_cast<float4*>(sp) = float4{gi[0], gi[1], gi[2], gi[3]};
+                    *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
+                    *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
+                    *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
+                    *reinterpret_cast<float4*>(sp + 4 * H) = float4{cp[0], cp[1], cp[2], cp[3]};
+                    if (I > 6 && t + 1 < T)                              // h_prev of step t+1 (generic wgrad path)
+                        *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hm[0], hm[1], hm[2], hm[3]};
+                }
+                if (t == T - 1) {
+                    *reinterpret_cast<float4*>(hn + (size_t)n * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
+                    *reinterpret_cast<float4*>(cn + (size_t)n * H + uo) = float4{c_reg[0], c_reg[1], c_reg[2], c_reg[3]};
+                }
+            }
+            cur ^= 1;
+            X6_PROF_MARK(2);
+            lds_barrier();
+            X6_PROF_MARK(3);
+        }
+        if (ch + 1 < nchunk) {
+            stage_commit(xb ^ 1);
+            lds_barrier();
+        }
+    }
+    X6_PROF_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------- backward
@@ -542,6 +815,25 @@ static int launch_fwd(bool fuse, const float* x, const float* keep, const float*
                       const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int N, int T, int I,
                       float* y, float* hn, float* cn, float* stash, hipStream_t st) {
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
+    if (!f32_mfma_requested()) {         // default: split-bf16 products on the bf16 matrix pipe (f32 accuracy)
+        const size_t lx = FwdX6Geom<H>::LDS;
+        static bool attr_set = false;
+        if (!attr_set) {
+            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_x6_kernel<H, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
+            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_x6_kernel<H, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
+            attr_set = true;
+        }
+        if (fuse)
+            hipLaunchKernelGGL((lstm_fwd_x6_kernel<H, true>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
+                               b_hh, N, T, I, y, hn, cn, stash);
+        else
+            hipLaunchKernelGGL((lstm_fwd_x6_kernel<H, false>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
+                               b_hh, N, T, I, y, hn, cn, stash);
+        UAV_LAUNCH_CHECK();
+        return 0;
+    }
     const size_t lds = FwdGeom<H>::LDS;
     if (fuse)
         hipLaunchKernelGGL((lstm_fwd_kernel<H, true>), grid, block, lds, st, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N,

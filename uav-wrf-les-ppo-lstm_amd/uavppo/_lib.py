@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  -- FIRST: torch's bundled HIP runtime must be the one libuavppo.so binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuavppo.so")
+LIB_PATH = os.environ.get("UAVPPO_LIB") or os.path.join(_HERE, "libuavppo.so")   # override: instrumented builds
 
 c_f32p = C.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 P, I32, I64, U64, F32, F64, SZ = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_size_t
