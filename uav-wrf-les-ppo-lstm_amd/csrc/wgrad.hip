@@ -306,6 +306,280 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_dma_kernel(
     for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
 }
 
+// ------------------------------------------------------------------------------ split-bf16 variant
+// The same products on the bf16 matrix pipe at f32 accuracy (see lstm.hip, lstm_fwd_x6_kernel): both operands
+// are split exactly into three bf16 pieces and the six piece products with i + j <= 2 are accumulated in f32
+// by v_mfma_f32_16x16x32_bf16 -- 6 x 16 cycles per 32 rows against 8 x 32 for the exact-f32 chain.
+// K slab = 32 rows.  Operands:
+//   A = dG^T   each dG element is used by exactly one lane (wave w owns gate rows [64w, 64w+64)), so it never
+//              touches LDS: lane (i, kq) loads rows 8kq..8kq+7 of gate columns 64w+4i .. +3 straight from HBM
+//              (dwordx2 per tile pair: tile mi holds the gate rows 64w + 4i + mi, a row permutation undone when
+//              the slab is written), one slab ahead, and splits them in registers;
+//   B = [Hprev | x, 1]  and  Y   are needed by every wave: split ONCE by the thread that loaded them (column c,
+//              8 consecutive rows: coalesced wave loads, one slab ahead) and parked k-contiguous in LDS piece
+//              planes [piece][column][32 rows + pad], read back as conflict-free ds_read_b128 fragments.
+// The split is VALU work (~550 instructions per wave and slab) and the two waves of a SIMD would do it at the
+// same time, leaving the matrix pipe idle (measured: 7000 of 13700 cycles per slab).  So the wave groups run
+// the slab body in rotated order -- EARLY waves: split0 mfma0 commit split1 mfma1, LATE waves: mfma0 commit
+// split1 mfma1 split0(next) -- and one group's MFMAs cover the other group's VALU phases.
+// keep[] and the t == 0 test are wave-uniform (scalar).  Needs full 32-row slabs, T >= 8, I <= 6.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
+    p0 = (__bf16)a;
+    const float r1 = a - (float)p0;
+    p1 = (__bf16)r1;
+    p2 = (__bf16)(r1 - (float)p1);
+}
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __bf16 a, b, c;
+        split3(v[i], a, b, c);
+        p0[i] = a; p1[i] = b; p2[i] = c;
+    }
+}
+
+constexpr int KS6 = 32;         // rows per slab
+
+template <int H>
+struct WGX {
+    static constexpr int NW = H / 16, NT = H * 4;
+    static constexpr int NT_ = H / 16 + 1, NC = H + 16;
+    static constexpr int KP = KS6 + 8;                               // padded k stride (bf16): conflict-free b128
+    static constexpr int BPL = NC * KP, YPL = H * KP, DPL = 16 * KP; // elements per piece plane
+    static constexpr int BUF = 3 * (BPL + YPL + DPL);                // bf16 elements per buffer
+    static constexpr size_t LDS = 2 * BUF * sizeof(unsigned short);
+    static constexpr int XV = 16 * KS6 / NT;                         // x|1 elements per thread per slab
+    static constexpr int DV = (8 * KS6 + NT - 1) / NT;               // dheads elements per thread per slab
+};
+
+#ifdef UAV_X6_PROFILE
+__device__ unsigned long long g_wx6_prof[2][8];
+#define WX_PROF_DECL unsigned long long pm_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl_ = __builtin_readcyclecounter()
+#define WX_PROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pm_[i] += n_ - pl_; pl_ = n_; } while (0)
+#define WX_PROF_DEP(v) asm volatile("" ::"v"(v))
+#define WX_PROF_FLUSH() do { if (blockIdx.x == 0 && lane == 0 && (w == 0 || w == H / 16 - 1)) \
+        for (int i_ = 0; i_ < 8; ++i_) g_wx6_prof[w ? 1 : 0][i_] = pm_[i_]; } while (0)
+extern "C" int uav_wx6_prof_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wx6_prof), sizeof(g_wx6_prof)) == hipSuccess ? 0 : 1;
+}
+#else
+#define WX_PROF_DECL
+#define WX_PROF_MARK(i)
+#define WX_PROF_DEP(v)
+#define WX_PROF_FLUSH()
+#endif
+
+template <int H, bool HEADS>
+__global__ __launch_bounds__(H * 4) void lstm_wgrad_x6_kernel(
+    const float* __restrict__ dgates, const float* __restrict__ y, const float* __restrict__ keep,
+    const float* __restrict__ h0, const float* __restrict__ x, int I, const float* __restrict__ dheads, int NH,
+    int N, int T, int rows_per_block, float* __restrict__ slabs) {
+    using G = WGX<H>;
+    constexpr int NT_ = G::NT_, KP = G::KP, BPL = G::BPL, YPL = G::YPL, DPL = G::DPL, BUF = G::BUF, NT = G::NT;
+    constexpr int XV = G::XV, DV = G::DV, NW = G::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = w >= NW / 2;                 // waves w and w + NW/2 share a SIMD
+    const int j = lane & 15, kq = lane >> 4;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int nslab = rows_per_block / KS6;
+
+    // staging coordinates: column c, row group rg (wave-uniform) -> rows 8 rg .. 8 rg + 7 of the slab
+    const int c = tid % H;
+    const int rg = __builtin_amdgcn_readfirstlane(tid / H);
+
+    f32x4 acc[4][NT_];
+    f32x4 acch = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // heads 8..15 of the dheads^T image are never written: zero both buffers once
+    for (int idx = tid; idx < 2 * 3 * DPL; idx += NT) {
+        const int b = idx / (3 * DPL), rem = idx % (3 * DPL);
+        sm16[b * BUF + 3 * (BPL + YPL) + rem] = 0;
+    }
+
+    // ---- A operand: raw dG values of this lane, [tile mi][row 8 kq + e]; tile mi <-> gate rows 64w + 4i + mi
+    float raw[4][8];
+    auto load_a = [&](int slab, int pair) {
+        slab = slab < nslab ? slab : nslab - 1;                       // clamped: the tail issues harmless reloads
+        // 32-bit element offsets from the (scalar) base pointer: the launch checks N*T*4H < 2^30
+        const unsigned off = (unsigned)(r_begin + slab * KS6 + 8 * kq) * (4 * H) + 64 * w + 4 * j + 2 * pair;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float2 t2 = *reinterpret_cast<const float2*>(dgates + (off + (unsigned)e * (4 * H)));
+            raw[2 * pair][e] = t2.x;
+            raw[2 * pair + 1][e] = t2.y;
+        }
+    };
+    // ---- B / Y / x / dheads staging registers (one slab ahead)
+    constexpr int NV = HEADS ? 9 : 8;                                // Y = the same rows of y, shifted by one
+    float v[NV], hz = 0.f, xv[XV], dv[DV];
+    float kv = 1.f;                                                  // keep[q0 + (lane & 7)]: read back by v_readlane
+    int i_start = -1;                                                // row of this thread's group with t == 0
+    auto load_b = [&](int slab) {
+        slab = slab < nslab ? slab : nslab - 1;
+        const int q0 = r_begin + slab * KS6 + 8 * rg;                 // first row of this thread's group (uniform)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int rr = q0 - 1 + i;
+            v[i] = y[(unsigned)(rr < 0 ? 0 : rr) * H + c];
+        }
+        const int tq = q0 % T;                                        // T >= 8: at most one sequence start in 8 rows
+        i_start = (tq == 0) ? 0 : (tq + 7 >= T ? T - tq : -1);
+        if (i_start >= 0) hz = h0[(unsigned)((q0 + i_start) / T) * H + c];
+        // a vector load, NOT a scalar one: s_load returns through lgkmcnt, so every LDS fragment wait behind it
+        // would also wait out its HBM latency
+        kv = keep ? keep[q0 + (lane & 7)] : 1.f;
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int idx = tid + k * NT, q = idx >> 4, f = idx & 15;
+            const unsigned r = (unsigned)(r_begin + slab * KS6 + q);
+            xv[k] = (f < I) ? x[r * I + f] : (f == 6 ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < DV; ++k) {
+            const int idx = tid + k * NT, q = idx >> 3, a = idx & 7;
+            const unsigned r = (unsigned)(r_begin + slab * KS6 + (q < KS6 ? q : 0));
+            dv[k] = (HEADS && a < NH && q < KS6) ? dheads[r * NH + a] : 0.f;
+        }
+    };
+    auto commit_b = [&](int buf) {
+        unsigned short* bp = sm16 + buf * BUF;
+        unsigned short* yp = bp + 3 * BPL;
+        unsigned short* dp = yp + 3 * YPL;
+        float hp[8], yy[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float kpi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kv), i));
+            hp[i] = ((i == i_start) ? hz : v[i]) * kpi;
+            yy[i] = HEADS ? v[i + 1 < NV ? i + 1 : 0] : 0.f;
+        }
+        bf16x8 p0, p1, p2;
+        split8(hp, p0, p1, p2);
+        *reinterpret_cast<bf16x8*>(bp + c * KP + 8 * rg) = p0;
+        *reinterpret_cast<bf16x8*>(bp + BPL + c * KP + 8 * rg) = p1;
+        *reinterpret_cast<bf16x8*>(bp + 2 * BPL + c * KP + 8 * rg) = p2;
+        if (HEADS) {
+            split8(yy, p0, p1, p2);
+            *reinterpret_cast<bf16x8*>(yp + c * KP + 8 * rg) = p0;
+            *reinterpret_cast<bf16x8*>(yp + YPL + c * KP + 8 * rg) = p1;
+            *reinterpret_cast<bf16x8*>(yp + 2 * YPL + c * KP + 8 * rg) = p2;
+        }
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int idx = tid + k * NT, q = idx >> 4, f = idx & 15;
+            __bf16 a, b, cc;
+            split3(xv[k], a, b, cc);
+            unsigned short* d = bp + (H + f) * KP + q;
+            d[0] = __builtin_bit_cast(unsigned short, a);
+            d[BPL] = __builtin_bit_cast(unsigned short, b);
+            d[2 * BPL] = __builtin_bit_cast(unsigned short, cc);
+        }
+        if (HEADS) {
+#pragma unroll
+            for (int k = 0; k < DV; ++k) {
+                const int idx = tid + k * NT, q = idx >> 3, a = idx & 7;
+                if (q < KS6) {
+                    __bf16 pa, pb, pc;
+                    split3(dv[k], pa, pb, pc);
+                    unsigned short* d = dp + a * KP + q;
+                    d[0] = __builtin_bit_cast(unsigned short, pa);
+                    d[DPL] = __builtin_bit_cast(unsigned short, pb);
+                    d[2 * DPL] = __builtin_bit_cast(unsigned short, pc);
+                }
+            }
+        }
+    };
+    // six piece products, smallest first
+    auto mac6 = [&](f32x4& d, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], d, 0, 0, 0);
+    };
+    bf16x8 ap[2][3];
+    // split the raw values of a tile pair (slab `sl`), then refill the freed registers from slab sl + 1
+    auto split_pair = [&](int sl, int pair) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) split8(raw[2 * pair + m], ap[m][0], ap[m][1], ap[m][2]);
+        load_a(sl + 1, pair);
+    };
+    auto mfma_pair = [&](int buf, int pair) {
+        const unsigned short* bp = sm16 + buf * BUF;
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) {
+            bf16x8 bb[3];
+            const unsigned short* src = bp + (16 * ni + j) * KP + 8 * kq;
+            bb[0] = *reinterpret_cast<const bf16x8*>(src);
+            bb[1] = *reinterpret_cast<const bf16x8*>(src + BPL);
+            bb[2] = *reinterpret_cast<const bf16x8*>(src + 2 * BPL);
+            mac6(acc[2 * pair][ni], ap[0], bb);
+            mac6(acc[2 * pair + 1][ni], ap[1], bb);
+        }
+        if (HEADS && pair == 1) {                         // dW_head tile of this wave: dheads^T Y[:, 16w .. 16w+16)
+            const unsigned short* yp = bp + 3 * BPL;
+            const unsigned short* dp = yp + 3 * YPL;
+            bf16x8 da[3], yb[3];
+            const unsigned short* sa = dp + j * KP + 8 * kq;
+            const unsigned short* sb = yp + (16 * w + j) * KP + 8 * kq;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                da[pc] = *reinterpret_cast<const bf16x8*>(sa + pc * DPL);
+                yb[pc] = *reinterpret_cast<const bf16x8*>(sb + pc * YPL);
+            }
+            mac6(acch, da, yb);
+        }
+    };
+
+    load_b(0);
+    load_a(0, 0);
+    load_a(0, 1);
+    commit_b(0);
+    load_b(1);
+    split_pair(0, 0);
+    lds_barrier();
+    WX_PROF_DECL;
+    // one body for both groups -- mfma0 commit split1 mfma1 split0(next) -- and the group decides where in it the
+    // slab barrier sits: EARLY waves wait before split0(next), LATE waves after it, so after every barrier the
+    // LATE wave of a SIMD streams MFMAs while the EARLY one still splits, and so on round the slab
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        WX_PROF_MARK(0);
+        mfma_pair(buf, 0);
+        WX_PROF_DEP(acc[0][NT_ - 1]); WX_PROF_DEP(acc[1][NT_ - 1]); WX_PROF_MARK(2);
+        commit_b(buf ^ 1);                                // planes of slab sl + 1 (a clamped copy on the last slab)
+        load_b(sl + 2);
+        WX_PROF_MARK(5);
+        split_pair(sl, 1);
+        WX_PROF_DEP(ap[0][0]); WX_PROF_DEP(ap[1][2]); WX_PROF_MARK(3);
+        mfma_pair(buf, 1);
+        WX_PROF_DEP(acc[2][NT_ - 1]); WX_PROF_DEP(acc[3][NT_ - 1]); WX_PROF_MARK(4);
+        if (!late) { lds_barrier(); WX_PROF_MARK(7); }
+        split_pair(sl + 1, 0);                            // pair 0 of the NEXT slab (raw loaded one slab ago)
+        WX_PROF_DEP(ap[0][0]); WX_PROF_DEP(ap[1][2]); WX_PROF_MARK(1);
+        if (late) { lds_barrier(); WX_PROF_MARK(7); }
+    }
+    WX_PROF_FLUSH();
+    float* slab = slabs + (size_t)blockIdx.x * WG<H>::SLAB;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(size_t)(64 * w + 4 * (4 * kq + r) + mi) * G::NC + 16 * ni + j] = acc[mi][ni][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
+}
+
 // sum the slabs in block order and scatter into dW_hh / dW_ih / db / dW_head
 template <int H>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nb, int I, int NH,
@@ -353,6 +627,35 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
         attr_set = true;
     }
     float* slabs = (float*)ctx->ws;
+    // split-bf16 variant: full 32-row slabs everywhere, T >= 8 (at most one sequence start per 8 rows)
+    {
+        int64_t rpx = (NTr + nb - 1) / nb;
+        rpx = (rpx + KS6 - 1) / KS6 * KS6;
+        const int nbx = (int)((NTr + rpx - 1) / rpx);
+        const bool x6_ok = (NTr % rpx == 0) && T >= 8 && I <= 6 && (!dheads || NH <= 8) && NTr * 4 * H < (1ll << 30) &&
+                           (y_prev_src == ytop || ytop == nullptr) && !getenv("UAV_LSTM_F32_MFMA");
+        if (x6_ok) {
+            using GX = WGX<H>;
+            static bool attr3 = false;
+            if (!attr3) {
+                UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_x6_kernel<H, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX::LDS));
+                UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_x6_kernel<H, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX::LDS));
+                attr3 = true;
+            }
+            if (dheads)
+                hipLaunchKernelGGL((lstm_wgrad_x6_kernel<H, true>), dim3(nbx), dim3(H * 4), GX::LDS, st, dgates, y_prev_src,
+                                   keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
+            else
+                hipLaunchKernelGGL((lstm_wgrad_x6_kernel<H, false>), dim3(nbx), dim3(H * 4), GX::LDS, st, dgates, y_prev_src,
+                                   keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
+            hipLaunchKernelGGL((wgrad_reduce_kernel<H>), dim3((unsigned)((G::SLAB + 255) / 256)), dim3(256), 0, st, slabs,
+                               nbx, I, NH, dw_ih, dw_hh, db, dw_head);
+            UAV_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     // LDS-DMA variant: full 16-row chunks everywhere, I <= 6 dword images, at least 2 chunks per block
     const bool dma_ok = (NTr % rpb == 0) && (rpb % KC == 0) && (rpb / KC >= 2) && I <= 6 && (!dheads || NH <= 6) &&
                         (y_prev_src == ytop || ytop == nullptr) && !getenv("UAV_WGRAD_NO_DMA");
