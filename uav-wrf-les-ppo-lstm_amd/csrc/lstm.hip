@@ -793,6 +793,226 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_dma_kernel(
     }
 }
 
+// ------------------------------------------------------------------- backward, split-bf16 MFMA
+// dh_{t-1}^T = W_hh^T dG_t^T on the bf16 matrix pipe at f32 accuracy (3-way split, six products; see
+// lstm_fwd_x6_kernel).  Orientation as in the forward: the weights are the A operand, so lane (j, kq) owns env j
+// and the four consecutive units uo..uo+3 -- its stash values arrive as five ds_read_b128 from the LDS-DMA ring,
+// its 16 gate gradients leave as four dwordx4 stores and are parked (split once, by their producer) as
+// ds_write_b64 in three bf16 planes [piece][env][4H + pad] that every wave reads back as B fragments.
+// All three pieces of this wave's W_hh^T slice stay in VGPRs (192 at H=128): the stash never passes through
+// registers two steps ahead, which is what makes that fit.  The planes are single-buffered (LDS also holds the
+// 80 KB ring), so a step has two barriers: planes free -> write -> planes complete -> MFMA.
+// Per step waves 0 and 1 additionally DMA the step's dheads / keep rows (96 + 16 floats) for everyone.
+template <int H>
+struct BwdX6Geom {
+    static constexpr int NW = H / 16;
+    static constexpr int NS = 4 * H / 32;                            // K = 32 slabs over the 4H gate rows
+    static constexpr int SP = 4 * H + 8;                             // padded plane row (bf16)
+    static constexpr int PLANE = MT * SP;
+    static constexpr int SLOT = 5 * MT * 16;                         // floats per wave per ring slot
+    static constexpr int SMALL = 128;                                // floats per small slot: dheads[16][6] | keep[16]
+    // the smallest weight piece of the first SPK slabs lives in a wave-private LDS slab (lane-contiguous b128):
+    // 192 weight VGPRs + the pointwise working set do not fit in 256 otherwise, and a scratch reload would put
+    // s_waitcnt vmcnt(0) in front of the counted LDS-DMA waits
+    static constexpr int SPK = (H >= 128) ? 3 : 0;
+    static constexpr int WPARK = SPK * 64 * 8;                       // bf16 elements per wave
+    static constexpr size_t LDS = (3 * PLANE + NW * WPARK) * sizeof(unsigned short) +
+                                  (2 * NW * SLOT + 2 * SMALL) * sizeof(float);
+};
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_bwd_x6_kernel(
+    const float* __restrict__ keep, const float* __restrict__ stash, const float* __restrict__ w_hh,
+    const float* __restrict__ dheads, const float* __restrict__ w_head, int NH, const float* __restrict__ dhn,
+    const float* __restrict__ dcn, int N, int T, float* __restrict__ dgates, float* __restrict__ dh0,
+    float* __restrict__ dc0) {
+    using G = BwdX6Geom<H>;
+    constexpr int NS = G::NS, SP = G::SP, PLANE = G::PLANE, SLOT = G::SLOT, NW = G::NW, SMALL = G::SMALL;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SPK = G::SPK, WPARK = G::WPARK;
+    unsigned short* dgp = reinterpret_cast<unsigned short*>(smem);          // [3 pieces][MT][SP]
+    unsigned short* wpark = dgp + 3 * PLANE;                                // [NW][SPK][64 lanes][8]
+    float* ring = reinterpret_cast<float*>(wpark + NW * WPARK);             // [2 slots][NW][SLOT]
+    float* small = ring + 2 * NW * SLOT;                                    // [2 slots][SMALL]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int uw = 16 * w + j;                 // unit whose W_hh^T row this lane holds (A operand row)
+    const int uo = 16 * w + 4 * kq;            // first of this lane's four units; its env is j
+    const int n0 = blockIdx.x * MT;
+    const int n = min(n0 + j, N - 1);
+    const bool live = n0 + j < N;
+
+    // A fragments: lane (j, kq) holds W_hh[k = 32 s + 8 kq + e][uw], e = 0..7, as three bf16 pieces
+    bf16x8 wa[NS][2], wa2[NS - SPK];
+    bf16x8* const wpk = reinterpret_cast<bf16x8*>(wpark + w * WPARK) + lane;           // + s * 64
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        bf16x8 p2v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __bf16 p0, p1, p2;
+            split3(w_hh[(size_t)(32 * s + 8 * kq + e) * H + uw], p0, p1, p2);
+            wa[s][0][e] = p0; wa[s][1][e] = p1; p2v[e] = p2;
+        }
+        if (s < SPK) wpk[s * 64] = p2v;
+        else wa2[s < SPK ? 0 : s - SPK] = p2v;
+    }
+    float whb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) whb[a] = (4 * a + kq < NH) ? w_head[(size_t)(4 * a + kq) * H + uw] : 0.f;
+
+    float dh_rec[4], dc_next[4];
+    {
+        const float4 a4 = dhn ? *reinterpret_cast<const float4*>(dhn + (size_t)n * H + uo) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 c4 = dcn ? *reinterpret_cast<const float4*>(dcn + (size_t)n * H + uo) : float4{0.f, 0.f, 0.f, 0.f};
+        dh_rec[0] = a4.x; dh_rec[1] = a4.y; dh_rec[2] = a4.z; dh_rec[3] = a4.w;
+        dc_next[0] = c4.x; dc_next[1] = c4.y; dc_next[2] = c4.z; dc_next[3] = c4.w;
+    }
+    const size_t srow = (size_t)n * T;
+
+    // ---- LDS-DMA (inline asm, see lstm_bwd_dma_kernel): stash gather [q][env lane/4][units 4 (lane%4) ..]
+    typedef __attribute__((address_space(3))) float lds_f;
+    const int e_d = lane >> 2, g4 = lane & 3;
+    const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)(ring + w * SLOT)));
+    const unsigned small_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)small));
+    auto issue = [&](int t, int slot) {
+        const float* src = stash + (drow + t) * (6 * H) + 16 * w + 4 * g4;
+        const unsigned dst = ring_base + (unsigned)(slot * NW * SLOT * 4);
+        unsigned m0save;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0save)
+            : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(dst)
+            : "memory");
+    };
+    // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)]
+    auto issue_small = [&](int t, int slot) {
+        const int e = w * 64 + lane;                                         // element of the 128-float image
+        const float* src;
+        if (e < 16 * NH) src = dheads + ((size_t)min(n0 + e / NH, N - 1) * T + t) * NH + e % NH;
+        else if (e >= 112 && keep) src = keep + (size_t)min(n0 + e - 112, N - 1) * T + t;
+        else src = w_hh + (lane & 15);                                       // padding: any readable dwords
+        const unsigned dst = small_base + (unsigned)((slot * SMALL + w * 64) * 4);
+        unsigned m0save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0save) : "v"(src), "s"(dst) : "memory");
+    };
+    const bool small_wave = w < 2;
+    issue(T - 1, (T - 1) & 1);
+    if (small_wave) issue_small(T - 1, (T - 1) & 1);
+    issue(T >= 2 ? T - 2 : 0, (T - 2) & 1);
+    if (small_wave) issue_small(T >= 2 ? T - 2 : 0, (T - 2) & 1);
+
+    for (int t = T - 1; t >= 0; --t) {
+        // slot of step t: issued two steps ago; only last step's DMA ops of this wave may still be in flight
+        if (small_wave) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        const float* sl = ring + ((t & 1) * NW + w) * SLOT + j * 16 + 4 * kq;
+        float4 pf[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pf[q] = *reinterpret_cast<const float4*>(sl + q * 256);
+        lds_barrier();           // b2: every wave is done with the planes of step t+1; the small image of step t landed
+        const float* sm = small + (t & 1) * SMALL;
+        f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float d0 = (kq < NH) ? sm[j * NH + kq] : 0.f;
+            const float d1 = (4 + kq < NH) ? sm[j * NH + 4 + kq] : 0.f;
+            dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(whb[0], d0, dyacc, 0, 0, 0);
+            dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(whb[1], d1, dyacc, 0, 0, 0);
+        }
+        const float kp = keep ? sm[112 + j] : 1.f;                           // keep[env j][t]
+        const float gi[4] = {pf[0].x, pf[0].y, pf[0].z, pf[0].w}, gf[4] = {pf[1].x, pf[1].y, pf[1].z, pf[1].w};
+        const float gg[4] = {pf[2].x, pf[2].y, pf[2].z, pf[2].w}, go[4] = {pf[3].x, pf[3].y, pf[3].z, pf[3].w};
+        const float cp[4] = {pf[4].x, pf[4].y, pf[4].z, pf[4].w};
+        float dg[4][4];                                                      // [gate][unit r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = dyacc[r] + dh_rec[r];
+            const float c = gf[r] * cp[r] + gi[r] * gg[r];
+            const float tch = tanhf_(c);
+            const float dc = dh * go[r] * (1.0f - tch * tch) + dc_next[r];
+            dg[0][r] = dc * gg[r] * gi[r] * (1.0f - gi[r]);
+            dg[1][r] = dc * cp[r] * gf[r] * (1.0f - gf[r]);
+            dg[2][r] = dc * gi[r] * (1.0f - gg[r] * gg[r]);
+            dg[3][r] = dh * tch * go[r] * (1.0f - go[r]);
+            dc_next[r] = dc * gf[r] * kp;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short b[3][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __bf16 p0, p1, p2;
+                split3(dg[q][r], p0, p1, p2);
+                b[0][r] = bf_bits(p0); b[1][r] = bf_bits(p1); b[2][r] = bf_bits(p2);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                uint2 v;
+                v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+                v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+                *reinterpret_cast<uint2*>(dgp + pc * PLANE + j * SP + q * H + uo) = v;
+            }
+            if (live)
+                *reinterpret_cast<float4*>(dgates + (srow + t) * (4 * H) + q * H + uo) =
+                    float4{dg[q][0], dg[q][1], dg[q][2], dg[q][3]};
+        }
+        // refill this wave's ring slot with step t-2 (its reads of the slot have returned: lgkmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue(t >= 2 ? t - 2 : 0, t & 1);
+        lds_barrier();           // b1: planes of step t complete; nobody reads the small image of step t any more
+        if (small_wave) issue_small(t >= 2 ? t - 2 : 0, t & 1);
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const unsigned short* brow = dgp + j * SP + 8 * kq;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            bf16x8 b0[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) b0[pc] = *reinterpret_cast<const bf16x8*>(brow + pc * PLANE + 32 * s);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][0], b0[2], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][1], b0[1], a1, 0, 0, 0);
+            const bf16x8 w2 = (s < SPK) ? wpk[s * 64] : wa2[s < SPK ? 0 : s - SPK];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, b0[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][0], b0[1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][1], b0[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][0], b0[0], a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh_rec[r] = (a0[r] + a1[r]) * kp;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the clamped tail DMAs before the LDS is released
+    if (live) {
+        if (dh0) *reinterpret_cast<float4*>(dh0 + (size_t)n * H + uo) = float4{dh_rec[0], dh_rec[1], dh_rec[2], dh_rec[3]};
+        if (dc0) *reinterpret_cast<float4*>(dc0 + (size_t)n * H + uo) = float4{dc_next[0], dc_next[1], dc_next[2], dc_next[3]};
+    }
+}
+
+template <int H>
+static int launch_bwd_x6(const float* keep, const float* stash, const float* w_hh, const float* dheads,
+                         const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
+                         float* dh0, float* dc0, hipStream_t st) {
+    const dim3 grid((N + MT - 1) / MT), block(H * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_x6_kernel<H>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdX6Geom<H>::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_x6_kernel<H>), grid, block, BwdX6Geom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
+                       NH, dhn, dcn, N, T, dgates, dh0, dc0);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int H>
 static int launch_bwd_dma(const float* keep, const float* stash, const float* w_hh, const float* dheads,
                           const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
@@ -871,7 +1091,13 @@ __global__ void add2_kernel(const float* a0, const float* a1, float* b, int n) {
 static int lstm_bwd_seq(const float* keep, const float* stash, const float* w_hh, const float* dy,
                         const float* dheads, const float* w_head, int NH, const float* dhn, const float* dcn, int N,
                         int T, int H, float* dgates, float* dh0, float* dc0, hipStream_t st) {
-    if (dheads && !getenv("UAV_BWD_NO_DMA")) {          // the PPO path: LDS-DMA stash prefetch variant
+    if (dheads && NH <= 7 && !f32_mfma_requested()) {   // the PPO path, split-bf16 MFMA (f32 accuracy)
+        switch (H) {
+            case 64: return launch_bwd_x6<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+            case 128: return launch_bwd_x6<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+        }
+    }
+    if (dheads && !getenv("UAV_BWD_NO_DMA")) {          // exact-f32 MFMA, LDS-DMA stash prefetch variant
         switch (H) {
             case 64: return launch_bwd_dma<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
             case 128: return launch_bwd_dma<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
