@@ -35,7 +35,8 @@ CONFIGS = {   # BASELINE.json configs (per-GPU env count; SURVEY 8 shorthand)
     # (generic per-step LSTM path + step-wise rollout: correct, launch-bound)
     "c5": dict(num_envs=4096, horizon=256, hidden=256, layers=2, variant="v2.1", trend_k=2),
 }
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s (the split-bf16 kernels issue 6 products)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -172,24 +173,31 @@ def main():
     env_steps = N * T * world * args.steps
     value = env_steps / dt
     opt_steps = tr.hp["epochs"] * tr.num_minibatches
-    # roofline of the dominant kernel (the BPTT sequence kernel): algorithmic flops of its dh = dgates W_hh
-    # product per launch (N*T*2*4H*H; SURVEY 8d's per-env-step LSTM figure restricted to this kernel) over
-    # its average duration, timed live with HIP events on the launch stream.  `traffic` = HBM bytes per
-    # launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes), measured at
-    # this very shape and stored under profiles/ (a profiler cannot run inside the timed region).
+    # roofline of the dominant kernel, the BPTT sequence kernel lstm_bwd_x6_kernel.  With its dh = dG W_hh product
+    # on the bf16 matrix pipe (3-way operand split, f32 accuracy) it sits under the HBM roof, not the MFMA one:
+    # algorithmic bytes per (env, step) = 5H stash values read + 4H gate gradients written + NH dheads + keep,
+    # x N*T per launch (DESIGN.md "Kernels"), over its average launch duration timed live with HIP events on the
+    # launch stream.  `traffic` = HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction +
+    # WRITE_SIZE, separate passes), measured at this very shape and stored under profiles/ (a profiler cannot
+    # run inside the timed region).  The MFMA side is reported next to it in f32-equivalent flops.
+    NHEADS = 6
+    bytes_bwd = N * T * (5 * H + 4 * H + NHEADS + 1) * 4 * cfg["layers"]
     fl_bwd = N * T * 2 * 4 * H * H * cfg["layers"]
     bwd = timers.get("lstm_bwd")
     roofline = None
     if bwd:
-        ach = fl_bwd / (bwd["avg_ms"] * 1e-3) / 1e12
+        sec = bwd["avg_ms"] * 1e-3
+        ach = bytes_bwd / sec / 1e9
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+        kname = "lstm_bwd_x6_kernel<%d>" % H
+        tf = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_pmc.json")
         if args.config == "c3" and os.path.exists(tf):
-            traffic = json.load(open(tf)).get("lstm_bwd_dma_kernel<128>", {}).get("hbm_total_bytes")
-        roofline = {"kernel": "lstm_bwd_dma_kernel<%d>" % H, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                    "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
-                    "hbm_GBps_of_traffic": (traffic / (bwd["avg_ms"] * 1e-3) / 1e9) if traffic else None}
+            traffic = json.load(open(tf)).get(kname, {}).get("hbm_total_bytes")
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBPS, "traffic": traffic, "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
+                    "algorithmic_bytes": bytes_bwd,
+                    "mfma": {"f32_equiv_tflops": fl_bwd / sec / 1e12, "executed_bf16_tflops": 6 * fl_bwd / sec / 1e12,
+                             "bf16_peak_tflops": PEAK_BF16_MFMA_TFLOPS, "frac": 6 * fl_bwd / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
     out = {
         "metric": f"env-steps/sec (rollout + GAE + {tr.hp['epochs']}-epoch PPO update), {N} envs x {T} T per GPU, LSTM h={H}",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

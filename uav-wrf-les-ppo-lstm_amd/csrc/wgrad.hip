@@ -312,9 +312,10 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_dma_kernel(
 // by v_mfma_f32_16x16x32_bf16 -- 6 x 16 cycles per 32 rows against 8 x 32 for the exact-f32 chain.
 // K slab = 32 rows.  Operands:
 //   A = dG^T   each dG element is used by exactly one lane (wave w owns gate rows [64w, 64w+64)), so it never
-//              touches LDS: lane (i, kq) loads rows 8kq..8kq+7 of gate columns 64w+4i .. +3 straight from HBM
-//              (dwordx2 per tile pair: tile mi holds the gate rows 64w + 4i + mi, a row permutation undone when
-//              the slab is written), one slab ahead, and splits them in registers;
+//              touches LDS: lane (i, kq) loads rows 8kq..8kq+7 straight from HBM, one dwordx2 per tile pair p
+//              (gate columns 64w + 32p + 2i, +1: each wave load covers whole 128-B lines; tile 2p+m holds the
+//              gate rows 64w + 32p + 2i + m, a row permutation undone when the slab is written), one slab
+//              ahead, and splits them in registers;
 //   B = [Hprev | x, 1]  and  Y   are needed by every wave: split ONCE by the thread that loaded them (column c,
 //              8 consecutive rows: coalesced wave loads, one slab ahead) and parked k-contiguous in LDS piece
 //              planes [piece][column][32 rows + pad], read back as conflict-free ds_read_b128 fragments.
@@ -404,12 +405,12 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_x6_kernel(
         sm16[b * BUF + 3 * (BPL + YPL) + rem] = 0;
     }
 
-    // ---- A operand: raw dG values of this lane, [tile mi][row 8 kq + e]; tile mi <-> gate rows 64w + 4i + mi
+    // ---- A operand: raw dG values of this lane, [tile mi][row 8 kq + e]; tile 2p+m <-> gate rows 64w + 32p + 2i + m
     float raw[4][8];
     auto load_a = [&](int slab, int pair) {
         slab = slab < nslab ? slab : nslab - 1;                       // clamped: the tail issues harmless reloads
         // 32-bit element offsets from the (scalar) base pointer: the launch checks N*T*4H < 2^30
-        const unsigned off = (unsigned)(r_begin + slab * KS6 + 8 * kq) * (4 * H) + 64 * w + 4 * j + 2 * pair;
+        const unsigned off = (unsigned)(r_begin + slab * KS6 + 8 * kq) * (4 * H) + 64 * w + 32 * pair + 2 * j;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float2 t2 = *reinterpret_cast<const float2*>(dgates + (off + (unsigned)e * (4 * H)));
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_x6_kernel(
         for (int ni = 0; ni < NT_; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                slab[(size_t)(64 * w + 4 * (4 * kq + r) + mi) * G::NC + 16 * ni + j] = acc[mi][ni][r];
+                slab[(size_t)(64 * w + 32 * (mi >> 1) + 2 * (4 * kq + r) + (mi & 1)) * G::NC + 16 * ni + j] = acc[mi][ni][r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
 }
