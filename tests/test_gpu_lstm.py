@@ -128,3 +128,47 @@ def test_lstm_generic_hidden_sizes(ops, T, N, I, H):
     for k, want in (("dx", x.grad.transpose(0, 1)), ("dw_ih", w_ih.grad), ("dw_hh", w_hh.grad), ("db", b_ih.grad),
                     ("dh0", h0.grad), ("dc0", c0.grad)):
         _close(g[k], want)
+
+
+@pytest.mark.parametrize("N,T,H", [(64, 32, 128), (128, 16, 64), (48, 64, 128)])
+def test_split_bf16_kernels_have_f32_accuracy(ops, N, T, H, monkeypatch):
+    """The default LSTM kernels multiply on the bf16 matrix pipe (3-way operand split, six products).  Claim: the
+    result is an f32 computation -- against an f64 LSTM their error is that of the exact-f32-MFMA kernels
+    (UAV_LSTM_F32_MFMA=1 selects those), for forward, backward and weight gradients (shapes with full 32-row slabs)."""
+    torch.manual_seed(N + T)
+    I, A = 6, 6
+    ref = torch.nn.LSTM(I, H, 1).double()
+    w_ih, w_hh, b_ih, b_hh = [p.detach().clone().requires_grad_(True) for p in ref.parameters()]
+    x = torch.randn(T, N, I, dtype=torch.float64)
+    h0 = (torch.randn(N, H, dtype=torch.float64) * 0.3).requires_grad_(True)
+    c0 = (torch.randn(N, H, dtype=torch.float64) * 0.3).requires_grad_(True)
+    keep = (torch.rand(T, N) > 0.1).double()
+    keep[0, 0] = 0.0
+    w_head = (torch.randn(A, H, dtype=torch.float64) * 0.2).requires_grad_(True)
+    dheads = torch.randn(T, N, A, dtype=torch.float64) / (N * T)
+    y, hn, cn = po.lstm_layer_forward(x, h0, c0, w_ih, w_hh, b_ih, b_hh, keep)
+    ((y @ w_head.T) * dheads).sum().backward()
+    want = {"y": y.transpose(0, 1), "dw_ih": w_ih.grad, "dw_hh": w_hh.grad, "db": b_ih.grad, "dh0": h0.grad,
+            "dc0": c0.grad, "dw_head": w_head.grad}
+
+    d = lambda t: t.detach().float().to(DEV).contiguous()
+    xg, kg = d(x.transpose(0, 1)), d(keep.transpose(0, 1))
+    args = (d(h0), d(c0), d(w_ih), d(w_hh), d(b_ih), d(b_hh))
+
+    def run():
+        yg, hng, cng, stash = ops.lstm_fwd(xg, kg, *args)
+        g = ops.lstm_bwd(xg, kg, stash, args[2], args[3], yg, args[0], dheads=d(dheads.transpose(0, 1)), w_head=d(w_head))
+        g["y"] = yg
+        return {k: g[k].detach().cpu().double() for k in want}
+
+    def errs(got):
+        return {k: float((got[k] - want[k].detach()).abs().max() / (want[k].detach().abs().max() + 1e-30)) for k in want}
+
+    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    e_x6 = errs(run())
+    monkeypatch.setenv("UAV_LSTM_F32_MFMA", "1")
+    e_f32 = errs(run())
+    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    for k in want:
+        assert e_x6[k] < 5e-6, (k, e_x6)                                 # f32-level agreement with the f64 reference
+        assert e_x6[k] <= 2.0 * e_f32[k] + 2e-7, (k, e_x6[k], e_f32[k])   # ... and no worse than the exact-f32 MFMA chain

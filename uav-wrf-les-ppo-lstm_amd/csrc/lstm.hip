@@ -41,10 +41,7 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 // UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split-bf16 ones)
-static bool f32_mfma_requested() {
-    static const bool v = getenv("UAV_LSTM_F32_MFMA") != nullptr;
-    return v;
-}
+static bool f32_mfma_requested() { return getenv("UAV_LSTM_F32_MFMA") != nullptr; }   // read per call: tests toggle it
 constexpr int TC = 32;      // time steps staged per chunk
 
 #define sigmoidf_ fast_sigmoid
