@@ -148,7 +148,7 @@ def main():
     for _ in range(args.warmup):
         tr.train_iteration()
     # ---- timed region: exactly K iterations, barrier + synchronize on both sides
-    ops.KERNEL_TIMER.enable(("lstm_bwd", "lstm_fwd", "lstm_wgrad", "rollout"))
+    ops.KERNEL_TIMER.enable(("lstm_bwd", "lstm_fwd", "lstm_wgrad", "rollout", "ppo_loss"))
     ev_roll = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()

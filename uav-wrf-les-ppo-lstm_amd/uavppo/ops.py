@@ -173,6 +173,7 @@ def ppo_loss_from_y(y, w_head, b_head, act, logp_old, adv, ret, val_old, inv_n, 
     """Heads + loss fused (csrc/loss.hip: ppo_loss_from_y_kernel): y [n, H] -> dheads [n, A+1]."""
     n, H = y.shape
     A1 = w_head.shape[0]
+    _t = KERNEL_TIMER.bracket("ppo_loss")
     check(lib().uav_ppo_loss_from_y(_h(y), _p(y, F32, (n, H), "y"), _p(w_head, F32, (A1, H), "w_head"),
                                     _p(b_head, F32, (A1,), "b_head"), _p(act, I32, (n,), "act"),
                                     _p(logp_old, F32, (n,), "logp_old"), _p(adv, F32, (n,), "adv"),
@@ -180,6 +181,8 @@ def ppo_loss_from_y(y, w_head, b_head, act, logp_old, adv, ret, val_old, inv_n, 
                                     float(inv_n), float(clip), float(ent_beta), _p(loss_sums, F64, (4,), "loss_sums"),
                                     _p(dheads, F32, (n, A1), "dheads"), _p(dhead_bias, F32, (A1,), "dhead_bias"),
                                     _stream()), "uav_ppo_loss_from_y")
+    if _t is not None:
+        _t.record()
     return loss_sums, dheads
 
 
