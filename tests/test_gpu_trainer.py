@@ -296,7 +296,11 @@ def test_epoch0_reuses_rollout_forward():
     assert torch.allclose(a.work["y0"], y, atol=2e-6)
     assert torch.allclose(a.work["stash0"][..., :5 * H], stash[..., :5 * H], atol=2e-6)
     a.update(); b.update()
-    assert torch.allclose(a.policy.flat, b.policy.flat, atol=2e-6)
+    # the two forward passes differ only in f32 accumulation order (~1e-7); Adam turns a gradient g into a step of
+    # lr * g / (|g| + eps), which amplifies that on elements whose gradient is tiny: bound the difference by a tenth
+    # of the largest possible movement (2 epochs x lr = 6e-5) and require it to be negligible on average
+    diff = (a.policy.flat - b.policy.flat).abs()
+    assert diff.max().item() < 0.1 * 2 * 3e-5 and diff.mean().item() < 1e-7
     assert torch.allclose(a.loss_sums, b.loss_sums, rtol=1e-5)
 
 

@@ -4,10 +4,10 @@
 // env.step -> buffer.store), here for N environments x T steps in ONE launch.
 //
 // One workgroup owns 16 environments for the whole horizon:
-//   * H/16 "gate" waves keep their W_hh / W_ih slices in VGPRs (as lstm.hip) and the cell state in
-//     registers; h_t lives in a padded LDS tile;
+//   * H/16 "gate" waves keep the bf16 pieces of their W_hh slice in VGPRs (as lstm_fwd_x6_kernel) and the
+//     cell state in registers; h_t lives in three bf16 LDS planes;
 //   * wave 0 additionally plays the "env" role: it computes the actor/critic heads of h_t with one
-//     MFMA chain (head weights as B-fragments from LDS), then lanes 0..15 each sample an action
+//     MFMA chain (head-weight pieces as A-fragments from LDS), then lanes 0..15 each sample an action
 //     (counter RNG, torch Categorical(probs) semantics), step their environment (env_core.h, f64)
 //     and store the transition into the (env, T, feat) buffers;
 //   * that VALU/f64 work for step t overlaps the other waves' recurrent MFMAs for step t+1 (both
@@ -30,15 +30,28 @@ constexpr float R_F32_EPS = 1.1920928955078125e-07f;
 #define r_sigmoid fast_sigmoid
 #define r_tanh fast_tanh
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
+    p0 = (__bf16)a;
+    const float r1 = a - (float)p0;
+    p1 = (__bf16)r1;
+    p2 = (__bf16)(r1 - (float)p1);
+}
+__device__ __forceinline__ unsigned short bf_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
+// LDS geometry of the split-bf16 rollout (dynamic part; the env role's small arrays are static)
 template <int H>
 struct RGeom {
     static constexpr int NW = H / 16;
-    static constexpr int KS = H / 4;
-    static constexpr int SEG = KS + 4;
-    static constexpr int S = 4 * SEG + 8;
+    static constexpr int NS = H / 32;                 // K = 32 slabs over the hidden dimension
+    static constexpr int RS = H + 8;                  // padded plane row (bf16): conflict-free ds_read_b128
+    static constexpr int PLANE = RMT * RS;
+    static constexpr int QL = (H >= 128) ? 2 : 0;     // gate waves: gates whose smallest weight piece is LDS-parked
+    static constexpr int WPARK = QL * NS * 64 * 8;    // bf16 per gate wave
+    static constexpr int W0 = 4 * NS * 3 * 64 * 8;    // bf16: ALL weight pieces of wave 0 (its VGPRs belong to the env role)
+    static constexpr size_t LDS = (3 * PLANE /*h*/ + 3 * PLANE /*head weights*/ + W0 + (NW - 1) * WPARK) * sizeof(unsigned short) +
+                                  (NW * 8 * 64 /*W_ih fragments*/ + 4 * H /*bias*/) * sizeof(float);
 };
-template <int H>
-__device__ __forceinline__ int rpos(int u) { return (u / (H / 4)) * RGeom<H>::SEG + (u % (H / 4)); }
 
 struct RolloutBufs {
     float* cur_obs; float* h; float* c;
@@ -48,23 +61,32 @@ struct RolloutBufs {
     float* stash; float* y;     // optional: BPTT stash [N][T][6H] + y [N][T][H], so PPO epoch 0 skips its forward pass
 };
 
+// The recurrent product h W_hh^T runs on the bf16 matrix pipe at f32 accuracy (3-way operand split, six piece
+// products; lstm.hip, lstm_fwd_x6_kernel) in the weights-as-A orientation: lane (j, kq) owns env j and the four
+// consecutive units uo..uo+3, so the stash leaves as dwordx4 stores and h_t is parked with one ds_write_b64 per piece.
+// Wave 0 (gate wave AND env role) keeps NO weights in registers -- all three pieces of its slice sit in LDS and are
+// read back as lane-contiguous b128 fragments -- so the f64 env chain has the register file to itself; the two roles
+// run separate, barrier-matched time loops, which keeps the other waves' 160 weight VGPRs out of wave 0's live set.
 template <int H, int NA>
 __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlob blob, int N, int T,
                                                                         uint64_t iter, const float* __restrict__ params,
                                                                         RolloutBufs B) {
     using G = RGeom<H>;
-    constexpr int KS = G::KS, SEG = G::SEG, S = G::S, I = 6, NH = NA + 1;
-    __shared__ __attribute__((aligned(16))) float hbuf[RMT * S];
+    constexpr int NS = G::NS, RS = G::RS, PLANE = G::PLANE, QL = G::QL, WPARK = G::WPARK, W0 = G::W0, NW = G::NW;
+    constexpr int I = 6, NH = NA + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* hpl = reinterpret_cast<unsigned short*>(smem);          // [3 pieces][RMT][RS] h_t
+    unsigned short* whp = hpl + 3 * PLANE;                                  // [3 pieces][16 heads][RS] head weights
+    unsigned short* w0p = whp + 3 * PLANE;                                  // [4 gates][NS][3 pieces][64 lanes][8]
+    unsigned short* wpark = w0p + W0;                                       // [NW-1][QL][NS][64][8]
+    float* wxl = reinterpret_cast<float*>(wpark + (NW - 1) * WPARK);        // [NW][4 gates][2 k-steps][64 lanes]
+    float* bl = wxl + NW * 512;                                             // [4H] b_ih + b_hh
     __shared__ __attribute__((aligned(16))) float xbuf[RMT * 8];
     __shared__ float kbuf[RMT];
     __shared__ float hd[RMT * 16];
-    __shared__ __attribute__((aligned(16))) float wbuf[16 * S];   // head weights, row = head, padded like an h row
     __shared__ unsigned short vis[RMT * NVIS];
-    // wave 0's W_hh slice, parked once: reloading it after the env block makes those 4*KS registers dead
-    // across the f64 env chain, which then fits without scratch spills (it used to spill ~60 VGPRs)
-    __shared__ float whpark[4 * KS * 64];
     __shared__ EnvState es_s[RMT];
-    __shared__ float trs[3 * RMT * 8];                            // parked transitions (see the env block)                                // env registers parked in LDS between steps
+    __shared__ float trs[3 * RMT * 8];                            // parked transitions (see the env block)
 
     const float* w_ih = params;
     const float* w_hh = w_ih + 4 * H * I;
@@ -78,134 +100,230 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     const int j = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * RMT;
     const bool is_env_wave = (w == 0);   // wave 0: gate wave AND env role
-
-    // ------------------------------------------------------------------ per-role persistent registers
-    float wh[4][KS], wx[4][2], bias[4];
-    float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, h_keep[4] = {0.f, 0.f, 0.f, 0.f};
-    const int u = 16 * w + j;
+    const int uw = 16 * w + j;                 // unit whose weight rows this lane holds / parks (A operand row)
+    const int uo = 16 * w + 4 * kq;            // first of this lane's four units; its env is j
+    const int nj = min(n0 + j, N - 1);
+    const bool live = n0 + j < N;
     const int my_env = n0 + lane;              // env of lanes 0..15 of the env wave
     const bool env_lane = is_env_wave && lane < RMT && my_env < N;
     unsigned short* myvis = vis + (lane & 15) * NVIS;
 
-    {
+    // ------------------------------------------------------------------ weights
+    bf16x8 wb[4][NS][2], wb2[4 - QL][NS];                                   // gate waves only
+    bf16x8* const w0f = reinterpret_cast<bf16x8*>(w0p) + lane;               // + ((q * NS + s) * 3 + piece) * 64
+    bf16x8* const wpk = reinterpret_cast<bf16x8*>(wpark + (w > 0 ? w - 1 : 0) * WPARK) + lane;   // + (q * NS + s) * 64
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float* src = w_hh + (size_t)(q * H + u) * H + kq * KS;
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int s = 0; s < KS; s += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(src + s);
-                wh[q][s] = v.x; wh[q][s + 1] = v.y; wh[q][s + 2] = v.z; wh[q][s + 3] = v.w;
+        for (int s = 0; s < NS; ++s) {
+            const float* src = w_hh + (size_t)(q * H + uw) * H + 32 * s + 8 * kq;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            bf16x8 p0v, p1v, p2v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __bf16 p0, p1, p2;
+                split3(v[i], p0, p1, p2);
+                p0v[i] = p0; p1v[i] = p1; p2v[i] = p2;
             }
-            bias[q] = b_ih[q * H + u] + b_hh[q * H + u];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k = 2 * kq + s;
-                wx[q][s] = (k < I) ? w_ih[(size_t)(q * H + u) * I + k] : 0.f;
+            if (is_env_wave) {
+                w0f[((q * NS + s) * 3 + 0) * 64] = p0v;
+                w0f[((q * NS + s) * 3 + 1) * 64] = p1v;
+                w0f[((q * NS + s) * 3 + 2) * 64] = p2v;
+            } else {
+                wb[q][s][0] = p0v; wb[q][s][1] = p1v;
+                if (q < QL) wpk[(q * NS + s) * 64] = p2v;
+                else wb2[q < QL ? 0 : q - QL][s] = p2v;
             }
         }
+    float* const wxw = wxl + w * 512 + lane;                                 // this lane's W_ih fragments: + (2 q + s) * 64
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 2 * kq + s;
+            wxw[(2 * q + s) * 64] = (k < I) ? w_ih[(size_t)(q * H + uw) * I + k] : 0.f;
+        }
+    for (int idx = threadIdx.x; idx < 4 * H; idx += H * 4) bl[idx] = b_ih[idx] + b_hh[idx];
+    for (int idx = threadIdx.x; idx < 16 * H; idx += H * 4) {                // head weights as three bf16 planes
+        const int hdx = idx / H, uu = idx % H;
+        __bf16 p0, p1, p2;
+        split3((hdx < NH) ? w_hd[(size_t)hdx * H + uu] : 0.f, p0, p1, p2);
+        unsigned short* d = whp + hdx * RS + uu;
+        d[0] = bf_bits(p0); d[PLANE] = bf_bits(p1); d[2 * PLANE] = bf_bits(p2);
+    }
+    auto put_h = [&](const float (&hv)[4]) {                                 // split and park h[env j][uo .. uo+3]
+        unsigned short b[3][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int e = 4 * kq + r;
-            const int n = min(n0 + e, N - 1);
-            c_reg[r] = B.c[(size_t)n * H + u];
-            h_keep[r] = B.h[(size_t)n * H + u];
-            hbuf[e * S + rpos<H>(u)] = h_keep[r];
+            __bf16 p0, p1, p2;
+            split3(hv[r], p0, p1, p2);
+            b[0][r] = bf_bits(p0); b[1][r] = bf_bits(p1); b[2][r] = bf_bits(p2);
         }
-    }
-    for (int idx = threadIdx.x; idx < 16 * H; idx += blockDim.x) {
-        const int hdx = idx / H, uu = idx % H;
-        wbuf[hdx * S + rpos<H>(uu)] = (hdx < NH) ? w_hd[(size_t)hdx * H + uu] : 0.f;
-    }
-    if (is_env_wave) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int sidx = 0; sidx < KS; ++sidx) whpark[(q * KS + sidx) * 64 + lane] = wh[q][sidx];
-    }
-    if (is_env_wave) {
-        if (lane < RMT) {
-            const int n = min(my_env, N - 1);
-            es_s[lane] = env_load(blob, n);
-            for (int k = 0; k < NVIS; ++k) myvis[k] = blob.visited[(size_t)n * NVIS + k];
-#pragma unroll
-            for (int f = 0; f < 8; ++f) xbuf[lane * 8 + f] = f < 6 ? B.cur_obs[(size_t)n * 6 + f] : 0.f;
-            kbuf[lane] = 1.f;
+        for (int pc = 0; pc < 3; ++pc) {
+            uint2 v;
+            v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+            v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+            *reinterpret_cast<uint2*>(hpl + pc * PLANE + j * RS + uo) = v;
         }
+    };
+    float c_reg[4];
+    {
+        const float4 cv = *reinterpret_cast<const float4*>(B.c + (size_t)nj * H + uo);
+        const float4 hv = *reinterpret_cast<const float4*>(B.h + (size_t)nj * H + uo);
+        c_reg[0] = cv.x; c_reg[1] = cv.y; c_reg[2] = cv.z; c_reg[3] = cv.w;
+        const float h_in[4] = {hv.x, hv.y, hv.z, hv.w};
+        put_h(h_in);
+    }
+    if (is_env_wave && lane < RMT) {
+        const int n = min(my_env, N - 1);
+        es_s[lane] = env_load(blob, n);
+        for (int k = 0; k < NVIS; ++k) myvis[k] = blob.visited[(size_t)n * NVIS + k];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) xbuf[lane * 8 + f] = f < 6 ? B.cur_obs[(size_t)n * 6 + f] : 0.f;
+        kbuf[lane] = 1.f;
     }
     lds_barrier();
 
-    // acc = bias + h_{t-1} W_hh^T of the step about to run (gate waves)
     f32x4 acc[4];
-    auto recurrent = [&]() {
+    auto bias_acc = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = f32x4{bias[q], bias[q], bias[q], bias[q]};
-        const float* hrow = hbuf + j * S + kq * SEG;
-#pragma unroll
-        for (int s = 0; s < KS; s += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(hrow + s);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wh[q][s], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wh[q][s + 1], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wh[q][s + 2], acc[q], 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wh[q][s + 3], acc[q], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(bl + q * H + uo);
+            acc[q] = f32x4{v.x, v.y, v.z, v.w};
         }
     };
-    recurrent();
-    lds_barrier();     // every wave has read h_{-1} before step 0 overwrites hbuf
+    // acc = bias + W_hh h^T of the step about to run; the six piece products, smallest first
+    auto recurrent = [&](auto&& wp0, auto&& wp1, auto&& wp2) {
+        bias_acc();
+        const unsigned short* hrow = hpl + j * RS + 8 * kq;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hrow + 32 * s);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hrow + PLANE + 32 * s);
+            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(hrow + 2 * PLANE + 32 * s);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp0(q, s), a2, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp1(q, s), a1, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp2(q, s), a0, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp0(q, s), a1, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp1(q, s), a0, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp0(q, s), a0, acc[q], 0, 0, 0);
+            // keep the h fragments of later slabs from being hoisted up here: one slab's 12 fragment registers at a
+            // time is all the 160 weight VGPRs of a gate wave leave room for
+            asm volatile("" ::: "memory");
+        }
+    };
+    auto recurrent_regs = [&]() {
+        recurrent([&](int q, int s) { return wb[q][s][0]; }, [&](int q, int s) { return wb[q][s][1]; },
+                  [&](int q, int s) { return (q < QL) ? wpk[(q * NS + s) * 64] : wb2[q < QL ? 0 : q - QL][s]; });
+    };
+    auto recurrent_lds = [&]() {
+        recurrent([&](int q, int s) { return w0f[((q * NS + s) * 3 + 0) * 64]; },
+                  [&](int q, int s) { return w0f[((q * NS + s) * 3 + 1) * 64]; },
+                  [&](int q, int s) { return w0f[((q * NS + s) * 3 + 2) * 64]; });
+    };
+    // phase 1: input projection (two exact-f32 k-steps), gate pointwise, h_t parked, stash / y stored.
+    // The recurrent state handed to the next rollout (B.h) is stored at the last real step; keep_fixup zeroes it
+    // again if that step ended the episode.
+    auto finish_cell = [&](int t, bool value_only) {
+        const float2 ax = *reinterpret_cast<const float2*>(&xbuf[j * 8 + 2 * kq]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q) * 64], ax.x, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q + 1) * 64], ax.y, acc[q], 0, 0, 0);
+        }
+        const bool st = B.stash && !value_only && live;       // the update's first epoch reuses this forward pass
+        const unsigned row = (unsigned)(n0 + j) * T + t;       // N*T*6H < 2^32 elements is checked at launch
+        float* sp = B.stash + (size_t)row * (6 * H) + uo;
+        float gi[4], gf[4], gg[4], cc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gi[r] = r_sigmoid(acc[0][r]); gf[r] = r_sigmoid(acc[1][r]); gg[r] = r_tanh(acc[2][r]);
+            cc[r] = gf[r] * c_reg[r] + gi[r] * gg[r];
+        }
+        if (st) {
+            *reinterpret_cast<float4*>(sp) = float4{gi[0], gi[1], gi[2], gi[3]};
+            *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
+            *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
+            *reinterpret_cast<float4*>(sp + 4 * H) = float4{c_reg[0], c_reg[1], c_reg[2], c_reg[3]};
+        }
+        float go[4], hh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            go[r] = r_sigmoid(acc[3][r]);
+            hh[r] = go[r] * r_tanh(cc[r]);
+            if (!value_only) c_reg[r] = cc[r];
+        }
+        put_h(hh);
+        if (st) {
+            *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
+            *reinterpret_cast<float4*>(B.y + (size_t)row * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
+        }
+        if (t == T - 1 && live)
+            *reinterpret_cast<float4*>(B.h + (size_t)(n0 + j) * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
+    };
+    // episode ended at step t: the recurrent state restarts from zero (acc falls back to the bias)
+    auto keep_fixup = [&](int t) {
+        if (kbuf[j] == 0.f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c_reg[r] = 0.f;
+            bias_acc();
+            if (t == T - 1 && live) *reinterpret_cast<float4*>(B.h + (size_t)(n0 + j) * H + uo) = float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
 
     const int steps = T + (B.last_val ? 1 : 0);   // one extra value-only pass for V(s_T)
-    for (int t = 0; t < steps; ++t) {
-        const bool value_only = (t == T);
-        // ---------------------------------------------------------------- phase 1: finish the cell of step t
-        {
-            const float2 ax = *reinterpret_cast<const float2*>(&xbuf[j * 8 + 2 * kq]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax.x, wx[q][0], acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax.y, wx[q][1], acc[q], 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int e = 4 * kq + r;
-                const float gi = r_sigmoid(acc[0][r]), gf = r_sigmoid(acc[1][r]);
-                const float gg = r_tanh(acc[2][r]), go = r_sigmoid(acc[3][r]);
-                const float c = gf * c_reg[r] + gi * gg;
-                const float h = go * r_tanh(c);
-                hbuf[e * S + rpos<H>(u)] = h;
-                if (B.stash && !value_only && n0 + e < N) {
-                    // the update's first epoch uses these parameters: its forward pass IS this rollout
-                    const size_t row = (size_t)(n0 + e) * T + t;
-                    float* sp = B.stash + row * (6 * H);
-                    sp[u] = gi; sp[H + u] = gf; sp[2 * H + u] = gg; sp[3 * H + u] = go;
-                    sp[4 * H + u] = c_reg[r];
-                    B.y[row * H + u] = h;
-                }
-                if (!value_only) { c_reg[r] = c; h_keep[r] = h; }
-            }
+    if (!is_env_wave) {
+        // ------------------------------------------------------------------ gate waves
+        recurrent_regs();
+        lds_barrier();     // every wave has read h_{-1} before step 0 overwrites the planes
+        for (int t = 0; t < steps; ++t) {
+            const bool value_only = (t == T);
+            finish_cell(t, value_only);
+            lds_barrier();                       // barrier 1: h_t visible
+            if (!value_only && t + 1 < steps) recurrent_regs();     // bias + W_hh h_t for step t+1
+            lds_barrier();                       // barrier 2: x_{t+1}, keep_{t+1} visible; reads of h_t done
+            if (!value_only) keep_fixup(t);
         }
-        lds_barrier();                       // barrier 1: h_t visible
-        // ---------------------------------------------------------------- phase 2 (overlapped roles)
-        if (is_env_wave) {
-            // heads of h_t: one MFMA chain, D[row = env][col = head]
-            // four independent accumulation chains (a 16x16x4 f32 MFMA has a 40-cycle dependent latency)
-            f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb2 = ha, hc2 = ha, hd2 = ha;
-            const float* hrow = hbuf + j * S + kq * SEG;
-            const float* wrow = wbuf + j * S + kq * SEG;
+    } else {
+        // ------------------------------------------------------------------ wave 0: gate wave + env role
+        recurrent_lds();
+        lds_barrier();
+        for (int t = 0; t < steps; ++t) {
+            const bool value_only = (t == T);
+            finish_cell(t, value_only);
+            lds_barrier();                       // barrier 1: h_t visible
+            // heads of h_t: D[head 4 kq + r][env j] = W_head h_t^T, six piece products per slab
+            f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb2 = ha;
+            {
+                const unsigned short* hrow = hpl + j * RS + 8 * kq;
+                const unsigned short* wrow = whp + j * RS + 8 * kq;
 #pragma unroll
-            for (int s = 0; s < KS; s += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(hrow + s);
-                const float4 b = *reinterpret_cast<const float4*>(wrow + s);
-                ha = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, ha, 0, 0, 0);
-                hb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, hb2, 0, 0, 0);
-                hc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, hc2, 0, 0, 0);
-                hd2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, hd2, 0, 0, 0);
+                for (int s = 0; s < NS; ++s) {
+                    bf16x8 a[3], bw[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        a[pc] = *reinterpret_cast<const bf16x8*>(hrow + pc * PLANE + 32 * s);
+                        bw[pc] = *reinterpret_cast<const bf16x8*>(wrow + pc * PLANE + 32 * s);
+                    }
+                    ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0], a[2], ha, 0, 0, 0);
+                    hb2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[1], a[1], hb2, 0, 0, 0);
+                    ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[2], a[0], ha, 0, 0, 0);
+                    hb2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0], a[1], hb2, 0, 0, 0);
+                    ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[1], a[0], ha, 0, 0, 0);
+                    hb2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[0], a[0], hb2, 0, 0, 0);
+                }
+                ha = ha + hb2;
             }
-            ha = (ha + hb2) + (hc2 + hd2);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hd[(4 * kq + r) * 16 + j] = ha[r];
+            for (int r = 0; r < 4; ++r) hd[j * 16 + 4 * kq + r] = ha[r];
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the hd tile is written (single wave)
             __builtin_amdgcn_wave_barrier();
             if (lane < RMT) {
@@ -304,37 +422,13 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     }
                 }
             }
-            // all lanes of wave 0: bring the weight slice back (it was dead across the env block)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int sidx = 0; sidx < KS; ++sidx) wh[q][sidx] = whpark[(q * KS + sidx) * 64 + lane];
-        }
-        if (!value_only && t + 1 < steps) recurrent();              // bias + h_t W_hh^T for step t+1
-        lds_barrier();                       // barrier 2: x_{t+1}, keep_{t+1} visible; recurrent reads of h_t done
-        if (!value_only) {
-            // episode ended at step t: the recurrent state restarts from zero (acc rows fall back to the bias)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float kp = kbuf[4 * kq + r];
-                if (kp == 0.f) {
-                    c_reg[r] = 0.f;
-                    h_keep[r] = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q][r] = bias[q];
-                }
-            }
+            if (!value_only && t + 1 < steps) recurrent_lds();      // bias + W_hh h_t for step t+1
+            lds_barrier();                       // barrier 2
+            if (!value_only) keep_fixup(t);
         }
     }
     // ------------------------------------------------------------------ write back persistent state
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 4 * kq + r;
-        if (n < N) {
-            B.h[(size_t)n * H + u] = h_keep[r];
-            B.c[(size_t)n * H + u] = c_reg[r];
-        }
-    }
+    if (live) *reinterpret_cast<float4*>(B.c + (size_t)(n0 + j) * H + uo) = float4{c_reg[0], c_reg[1], c_reg[2], c_reg[3]};
     if (env_lane) {
         env_store(blob, my_env, es_s[lane]);
         for (int k = 0; k < NVIS; ++k) blob.visited[(size_t)my_env * NVIS + k] = myvis[k];
@@ -347,7 +441,13 @@ template <int H>
 static int launch_rollout(const EnvParams& P, EnvBlob blob, int N, int T, uint64_t iter, const float* params,
                           const RolloutBufs& B, hipStream_t st) {
     const dim3 grid((N + RMT - 1) / RMT), block(H * 4);
-    hipLaunchKernelGGL((rollout_lstm_kernel<H, 5>), grid, block, 0, st, P, blob, N, T, iter, params, B);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_lstm_kernel<H, 5>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)RGeom<H>::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rollout_lstm_kernel<H, 5>), grid, block, RGeom<H>::LDS, st, P, blob, N, T, iter, params, B);
     UAV_LAUNCH_CHECK();
     return 0;
 }
