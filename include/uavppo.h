@@ -134,10 +134,14 @@ int uav_mlp_bwd(uav_ctx* ctx, const float* params, const float* x, float* stash,
  * x [N][T][I], keep [N][T] (1 = carry the recurrent state into step t, 0 = restart from zero;
  * NULL = all ones), h0,c0 [N][H].  Outputs y [N][T][H], hn,cn [N][H] and, when stash != NULL,
  * the BPTT stash f32 [N][T][6H] = gates(i,f,g,o after activation) | c_prev | h_prev.
- * w_ih [4H][I], w_hh [4H][H], b_ih,b_hh [4H]. */
+ * w_ih [4H][I], w_hh [4H][H], b_ih,b_hh [4H].
+ * heads != NULL: also heads [N][T][n_heads] = y W_head^T + b_head (the actor | critic Linear layers of
+ * model.py:44,52 applied to the top layer; w_head [n_heads][H], b_head [n_heads], n_heads <= 8), computed inside
+ * the sequence kernel where it exists, so the loss (uav_ppo_loss, packed form) reads n_heads floats per sample. */
 int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* c0,
                  const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  int N, int T, int I, int H, float* y, float* hn, float* cn, float* stash,
+                 const float* w_head, const float* b_head, int n_heads, float* heads,
                  uav_stream stream);
 /* BPTT sequence kernel.  Gradient of y comes either as dy [N][T][H], or -- for the actor-critic
  * heads, fused -- as dheads [N][T][n_heads] with w_head [n_heads][H] (dy = dheads . w_head is
@@ -209,13 +213,15 @@ int uav_env_materialise(uav_ctx* ctx, const void* state, int n_env, const uav_en
  * NULL outside parity tests.  stash [N][T][6H] + y_out [N][T][H] (both or neither): the BPTT stash of
  * uav_lstm_fwd for exactly this rollout, so the first PPO epoch (same parameters) skips its forward.
  * info (or NULL) f32 [N][T][6]: the five reward parts of environment.py:161-167 (concentration, explore,
- * move, tke, boundary) and obs[2] of the step -- what train_ppo2.0.py:179-183,203 accumulates per episode. */
+ * move, tke, boundary) and obs[2] of the step -- what train_ppo2.0.py:179-183,203 accumulates per episode.
+ * heads (or NULL) f32 [N][T][n_act+1]: logits | value of every step (with y_out: epoch 0 of the update needs no
+ * forward pass and no head product). */
 int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg /*host*/,
                 int policy_kind, const float* params, int hidden, int horizon, uint64_t iter,
                 float* cur_obs, float* h, float* c, float* obs, int32_t* act, float* rew,
                 float* val, float* logp, float* done, uint8_t* flags, float* keep, float* last_val,
                 const int32_t* forced_act, const double* noise, int32_t* nan_count,
-                float* stash, float* y_out, float* info, uav_stream stream);
+                float* stash, float* y_out, float* info, float* heads, uav_stream stream);
 
 #ifdef __cplusplus
 }

@@ -172,3 +172,32 @@ def test_split_bf16_kernels_have_f32_accuracy(ops, N, T, H, monkeypatch):
     for k in want:
         assert e_x6[k] < 5e-6, (k, e_x6)                                 # f32-level agreement with the f64 reference
         assert e_x6[k] <= 2.0 * e_f32[k] + 2e-7, (k, e_x6[k], e_f32[k])   # ... and no worse than the exact-f32 MFMA chain
+
+
+@pytest.mark.parametrize("N,T,I,H", [(37, 21, 6, 128), (16, 9, 6, 64), (5, 1, 6, 128), (7, 6, 6, 256), (9, 12, 64, 128)])
+@pytest.mark.parametrize("f32_mfma", [False, True])
+def test_lstm_fwd_emits_heads(ops, N, T, I, H, f32_mfma, monkeypatch):
+    """uav_lstm_fwd's heads output == (y W_head^T + b_head) of model.py:44,52, whether the sequence kernel forms it
+    itself (split-bf16 kernels, from the unmasked h planes: episode resets inside the sequence must not leak into it)
+    or the entry point falls back to one GEMM over y (exact-f32 / wide-input / h=256 paths)."""
+    if f32_mfma:
+        monkeypatch.setenv("UAV_LSTM_F32_MFMA", "1")
+    else:
+        monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    torch.manual_seed(N * 7 + T)
+    dev = DEV
+    x = torch.randn(N, T, I, device=dev)
+    keep = (torch.rand(N, T, device=dev) > 0.3).float()
+    k = 1.0 / H ** 0.5
+    w_ih, w_hh = (torch.rand(4 * H, I, device=dev) * 2 - 1) * k, (torch.rand(4 * H, H, device=dev) * 2 - 1) * k
+    b_ih, b_hh = (torch.rand(4 * H, device=dev) * 2 - 1) * k, (torch.rand(4 * H, device=dev) * 2 - 1) * k
+    h0, c0 = torch.randn(N, H, device=dev) * 0.3, torch.randn(N, H, device=dev) * 0.3
+    w_head, b_head = torch.randn(6, H, device=dev) * 0.3, torch.randn(6, device=dev)
+    heads = torch.full((N, T, 6), float("nan"), device=dev)
+    y, hn, cn, stash = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, w_head=w_head, b_head=b_head, heads=heads)
+    want = y.cpu().double() @ w_head.cpu().double().T + b_head.cpu().double()
+    _close(heads, want.float(), 1e-5, 2e-6)
+    # and y itself is unchanged by asking for heads
+    y2, _, _, _ = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
+    assert torch.equal(y, y2)
+    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)

@@ -237,10 +237,11 @@ struct FwdX6Geom {
     // piece of QL of the four gates lives in a wave-private LDS slab instead (read back as lane-contiguous b128)
     static constexpr int QL = (H >= 128) ? 3 : 0;
     static constexpr int WPARK = QL * NS * 64 * 8;                       // bf16 elements per wave
-    static constexpr int TCX = 16;                                       // steps of x / keep staged per chunk
-    static constexpr int XPT = MT * TCX * 8 / (H * 4);                   // staged x elements per thread
-    static constexpr size_t LDS = (2 * 3 * PLANE + (H / 16) * WPARK) * sizeof(unsigned short) +
-                                  (2 * TCX * MT * 8 + 2 * TCX * MT + (H / 16) * 8 * 64 + 4 * H) * sizeof(float);
+    static constexpr int TCX = 8;                                        // steps of x / keep staged per chunk
+    static constexpr int XPT = (MT * TCX * 8 + H * 4 - 1) / (H * 4);     // staged x elements per thread
+    static constexpr int HPL = 8 * RS;                                   // one piece plane of the (<= 8) head weight rows
+    static constexpr size_t LDS = (2 * 3 * PLANE + (H / 16) * WPARK + 3 * HPL) * sizeof(unsigned short) +
+                                  (2 * TCX * MT * 8 + 2 * TCX * MT + (H / 16) * 8 * 64 + 4 * H + 8) * sizeof(float);
 };
 
 #ifdef UAV_X6_PROFILE
@@ -272,17 +273,19 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
     const float* __restrict__ x, const float* __restrict__ keep, const float* __restrict__ h0,
     const float* __restrict__ c0, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
     const float* __restrict__ b_ih, const float* __restrict__ b_hh, int N, int T, int I,
-    float* __restrict__ y, float* __restrict__ hn, float* __restrict__ cn, float* __restrict__ stash) {
+    float* __restrict__ y, float* __restrict__ hn, float* __restrict__ cn, float* __restrict__ stash,
+    const float* __restrict__ w_head, const float* __restrict__ b_head, int NHD, float* __restrict__ heads) {
     using G = FwdX6Geom<H>;
     constexpr int NS = G::NS, RS = G::RS, PLANE = G::PLANE, QL = G::QL, WPARK = G::WPARK, TC = G::TCX, XPT = G::XPT;
-    constexpr int NT = H * 4;
+    constexpr int NT = H * 4, HPL = G::HPL, NW = H / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned short* hpl = reinterpret_cast<unsigned short*>(smem);       // [2][3 pieces][MT][RS] bf16
     unsigned short* wpark = hpl + 2 * 3 * PLANE;                         // [waves][QL][NS][64 lanes][8] bf16
     float* xbuf = reinterpret_cast<float*>(wpark + (H / 16) * WPARK);    // [2][TC][MT][8]
     float* kbuf = xbuf + 2 * TC * MT * 8;                                // [2][TC][MT]: keep[t + 1] of the chunk's steps
     float* wxl = kbuf + 2 * TC * MT;                                     // [waves][4 gates][2 k-steps][64 lanes]
-    float* bl = wxl + (H / 16) * 512;                                    // [4H] b_ih + b_hh
+    float* bl = wxl + (H / 16) * 512;                                    // [4H] b_ih + b_hh | [8] head bias
+    unsigned short* whp = reinterpret_cast<unsigned short*>(bl + 4 * H + 8);   // [3 pieces][8 heads][RS] bf16
 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -323,6 +326,42 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
             }
         for (int idx = threadIdx.x; idx < 4 * H; idx += NT) bl[idx] = b_ih[idx] + b_hh[idx];
     }
+    if (heads) {                                                         // actor / critic head rows as bf16 piece planes
+        for (int idx = threadIdx.x; idx < 8 * H; idx += NT) {
+            const int hdx = idx / H, uu = idx % H;
+            __bf16 p0, p1, p2;
+            split3((hdx < NHD) ? w_head[(size_t)hdx * H + uu] : 0.f, p0, p1, p2);
+            unsigned short* d = whp + hdx * RS + uu;
+            d[0] = bf_bits(p0); d[HPL] = bf_bits(p1); d[2 * HPL] = bf_bits(p2);
+        }
+        if (threadIdx.x < 8) bl[4 * H + threadIdx.x] = (int)threadIdx.x < NHD ? b_head[threadIdx.x] : 0.f;
+    }
+    // heads of the h held in plane set `buf` (= h_t, UNMASKED): D[head 4kq + r][env j] = W_head h^T + b, stored to
+    // heads[env][t][NHD].  One wave does it, beside its own recurrent MFMAs of the next step; the loss then reads
+    // NHD floats per sample instead of the H floats of y.
+    auto emit_heads = [&](int buf, int t) {
+        f32x4 ha = {0.f, 0.f, 0.f, 0.f};
+        const unsigned short* hrow = hpl + buf * 3 * PLANE + j * RS + 8 * kq;
+        const unsigned short* wrow = whp + (j & 7) * RS + 8 * kq;
+        auto hp = [&](int pc, int s) { return *reinterpret_cast<const bf16x8*>(hrow + pc * PLANE + 32 * s); };
+        auto wp = [&](int pc, int s) { return *reinterpret_cast<const bf16x8*>(wrow + pc * HPL + 32 * s); };
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp(0, s), hp(2, s), ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp(1, s), hp(1, s), ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp(2, s), hp(0, s), ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp(0, s), hp(1, s), ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp(1, s), hp(0, s), ha, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp(0, s), hp(0, s), ha, 0, 0, 0);
+            asm volatile("" ::: "memory");               // one slab's fragments at a time
+        }
+        if (live && kq < 2) {
+            float* dst = heads + ((size_t)n * T + t) * NHD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < NHD) dst[4 * kq + r] = ha[r] + bl[4 * H + 4 * kq + r];
+        }
+    };
     auto put_h = [&](unsigned short* plane0, const float (&hv)[4]) {     // split and park h[env j][uo .. uo+3]
         unsigned short b[3][4];
 #pragma unroll
@@ -347,7 +386,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
 #pragma unroll
             for (int i = 0; i < XPT; ++i) {
                 const int idx = threadIdx.x + i * NT;                    // (e, tt, f) with f fastest
-                const int e = idx / (TC * 8), tt = (idx >> 3) % TC, f = idx & 7;
+                const int e = min(idx / (TC * 8), MT - 1), tt = (idx >> 3) % TC, f = idx & 7;
                 const int ne = min(n0 + e, N - 1), t = min(t0 + tt, T - 1);
                 xr[i] = (f < I) ? x[((size_t)ne * T + t) * I + f] : 0.f;
             }
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
             for (int i = 0; i < XPT; ++i) {
                 const int idx = threadIdx.x + i * NT;
                 const int e = idx / (TC * 8), tt = (idx >> 3) % TC, f = idx & 7;
-                xbuf[((buf * TC + tt) * MT + e) * 8 + f] = xr[i];
+                if (e < MT) xbuf[((buf * TC + tt) * MT + e) * 8 + f] = xr[i];
             }
         }
         if (threadIdx.x < TC * MT) kbuf[(buf * TC + threadIdx.x % TC) * MT + threadIdx.x / TC] = kr;
@@ -384,6 +423,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
     stage_load(0);
     stage_commit(0);
     int cur = 0;
+    float kcur = 1.f;            // keep of the step about to run (the mask on the incoming h); h0 is masked above
     X6_PROF_DECL;
     lds_barrier();
 
@@ -395,21 +435,12 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
             const int t = t0 + tt;
             const size_t row = (size_t)n * T + t;
             X6_PROF_MARK(0);
+            if (heads && w == NW - 1 && t > 0) emit_heads(cur, t - 1);   // heads of h_{t-1}, while no accumulator is live
+            // the planes hold h_{t-1} UNMASKED (the heads need it so); the episode mask k_t is a per-env scalar, so it
+            // is applied to the finished h-part of the accumulator: acc = k_t (W_hh h_{t-1}) + bias + W_ih x_t
             f32x4 acc[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = FUSE_X ? *reinterpret_cast<const float4*>(bl + q * H + uo)
-                                        : *reinterpret_cast<const float4*>(stash + row * (6 * H) + q * H + uo);
-                acc[q] = f32x4{v.x, v.y, v.z, v.w};
-            }
-            if (FUSE_X) {       // K = I <= 8 input projection: two exact-f32 k-steps
-                const float2 ax = *reinterpret_cast<const float2*>(&xbuf[((xb * TC + tt) * MT + j) * 8 + 2 * kq]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q) * 64], ax.x, acc[q], 0, 0, 0);
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q + 1) * 64], ax.y, acc[q], 0, 0, 0);
-                }
-            }
+            for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
             const unsigned short* hrow = hpl + cur * 3 * PLANE + j * RS + 8 * kq;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -433,6 +464,20 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q][s][0], a0, acc[q], 0, 0, 0);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = FUSE_X ? *reinterpret_cast<const float4*>(bl + q * H + uo)
+                                        : *reinterpret_cast<const float4*>(stash + row * (6 * H) + q * H + uo);
+                acc[q] = acc[q] * kcur + f32x4{v.x, v.y, v.z, v.w};
+            }
+            if (FUSE_X) {       // K = I <= 8 input projection: two exact-f32 k-steps
+                const float2 ax = *reinterpret_cast<const float2*>(&xbuf[((xb * TC + tt) * MT + j) * 8 + 2 * kq]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q) * 64], ax.x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q + 1) * 64], ax.y, acc[q], 0, 0, 0);
+                }
+            }
             X6_PROF_DEP(acc[0][0]); X6_PROF_DEP(acc[1][1]); X6_PROF_DEP(acc[2][2]); X6_PROF_DEP(acc[3][3]);
             X6_PROF_MARK(1);
             const float kn = kbuf[(xb * TC + tt) * MT + j];              // keep of step t+1 (1 past the end)
@@ -447,7 +492,8 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
                 hm[r] = hh[r] * kn;
                 c_reg[r] = (t == T - 1) ? c : c * kn;                    // cn is the unmasked final cell state
             }
-            put_h(hpl + (cur ^ 1) * 3 * PLANE, hm);
+            put_h(hpl + (cur ^ 1) * 3 * PLANE, hh);
+            kcur = kn;
             if (live) {
                 *reinterpret_cast<float4*>(y + row * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
                 if (stash) {
@@ -475,6 +521,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
             lds_barrier();
         }
     }
+    if (heads && w == NW - 1) emit_heads(cur, T - 1);                     // planes `cur` hold h_{T-1}
     X6_PROF_FLUSH();
 }
 
@@ -1030,7 +1077,8 @@ static int launch_bwd_dma(const float* keep, const float* stash, const float* w_
 template <int H>
 static int launch_fwd(bool fuse, const float* x, const float* keep, const float* h0, const float* c0,
                       const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int N, int T, int I,
-                      float* y, float* hn, float* cn, float* stash, hipStream_t st) {
+                      float* y, float* hn, float* cn, float* stash, const float* w_head, const float* b_head, int NHD,
+                      float* heads, bool* heads_done, hipStream_t st) {
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
     if (!f32_mfma_requested()) {         // default: split-bf16 products on the bf16 matrix pipe (f32 accuracy)
         const size_t lx = FwdX6Geom<H>::LDS;
@@ -1044,10 +1092,11 @@ static int launch_fwd(bool fuse, const float* x, const float* keep, const float*
         }
         if (fuse)
             hipLaunchKernelGGL((lstm_fwd_x6_kernel<H, true>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
-                               b_hh, N, T, I, y, hn, cn, stash);
+                               b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, NHD, heads);
         else
             hipLaunchKernelGGL((lstm_fwd_x6_kernel<H, false>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
-                               b_hh, N, T, I, y, hn, cn, stash);
+                               b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, NHD, heads);
+        *heads_done = heads != nullptr;
         UAV_LAUNCH_CHECK();
         return 0;
     }
@@ -1112,9 +1161,11 @@ extern "C" {
 
 int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* c0, const float* w_ih,
                  const float* w_hh, const float* b_ih, const float* b_hh, int N, int T, int I, int H, float* y,
-                 float* hn, float* cn, float* stash, uav_stream stream) {
+                 float* hn, float* cn, float* stash, const float* w_head, const float* b_head, int n_heads, float* heads,
+                 uav_stream stream) {
     UAV_REQUIRE(ctx && x && h0 && c0 && w_ih && w_hh && b_ih && b_hh && y && hn && cn, "uav_lstm_fwd: NULL argument");
     UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_fwd: N=%d T=%d I=%d", N, T, I);
+    UAV_REQUIRE(!heads || (w_head && b_head && n_heads > 0 && n_heads <= 8), "uav_lstm_fwd: heads needs w_head, b_head, 1..8 heads");
     hipStream_t st = as_stream(stream);
     const bool persistent = (H == 64 || H == 128);
     const bool fuse = I <= 8 && persistent;
@@ -1129,12 +1180,19 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
         int rc = gemm_f32(&sub, (int64_t)N * T, 4 * H, I, x, I, 1, w_ih, 1, I, stash, 6 * H, bsum, 0, st);
         if (rc) return rc;
     }
+    bool heads_done = false;
+    int rc;
     switch (H) {
-        case 64: return launch_fwd<64>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, st);
-        case 128: return launch_fwd<128>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, st);
+        case 64: rc = launch_fwd<64>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, n_heads, heads, &heads_done, st); break;
+        case 128: rc = launch_fwd<128>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, n_heads, heads, &heads_done, st); break;
+        default:  // any other hidden size: per-step GEMM + pointwise (lstm_generic.hip)
+            rc = lstm_generic_fwd(ctx, keep, h0, c0, w_hh, N, T, H, y, hn, cn, stash, st);
     }
-    // any other hidden size: per-step GEMM + pointwise (lstm_generic.hip)
-    return lstm_generic_fwd(ctx, keep, h0, c0, w_hh, N, T, H, y, hn, cn, stash, st);
+    if (rc) return rc;
+    // kernels without the fused head product: heads = y W_head^T + b_head as one GEMM over the rows of y
+    if (heads && !heads_done)
+        return gemm_f32(ctx, (int64_t)N * T, n_heads, H, y, H, 1, w_head, 1, H, heads, n_heads, b_head, 0, st);
+    return 0;
 }
 
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,

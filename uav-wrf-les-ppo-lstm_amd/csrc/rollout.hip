@@ -58,6 +58,7 @@ struct RolloutBufs {
     float* obs; int32_t* act; float* rew; float* val; float* logp; float* done; uint8_t* flags; float* keep;
     float* last_val; const int32_t* forced_act; const double* noise; int32_t* nan_count;
     float* info;                // optional [N][T][6]: the 5 reward parts of environment.py:161-167 + obs[2] of the step
+    float* heads;               // optional [N][T][NA+1]: logits | value of the step
     float* stash; float* y;     // optional: BPTT stash [N][T][6H] + y [N][T][H], so PPO epoch 0 skips its forward pass
 };
 
@@ -385,6 +386,11 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     tr[4] = so.done ? 1.f : 0.f;
                     tr[5] = __int_as_float((so.done ? 1 : 0) | (so.reached ? 2 : 0));
                     tr[6] = kbuf[lane];
+                    if (B.heads && env_lane) {
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) B.heads[row * NH + a] = z[a];
+                        B.heads[row * NH + NA] = V;
+                    }
                     if (B.info) {
 #pragma unroll
                         for (int f = 0; f < 5; ++f) trs[2 * RMT * 8 + lane * 8 + f] = (float)so.info[f];
@@ -457,7 +463,7 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
                            float* c, float* obs, int32_t* act, float* rew, float* val, float* logp, float* done,
                            uint8_t* flags, float* keep, float* last_val, const int32_t* forced_act,
                            const double* noise, int32_t* nan_count, float* stash, float* y_out, float* info,
-                           uav_stream stream) {
+                           float* heads, uav_stream stream) {
     UAV_REQUIRE(ctx && env_state && params && cur_obs && obs && act && rew && val && logp && done && flags && nan_count,
                 "uav_rollout: NULL argument");
     UAV_REQUIRE(n_env > 0 && horizon > 0, "uav_rollout: n_env=%d horizon=%d", n_env, horizon);
@@ -468,7 +474,8 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
     int rc = env_params_from_cfg(ctx, cfg, n_env, P);
     if (rc) return rc;
     UAV_REQUIRE((stash == nullptr) == (y_out == nullptr), "uav_rollout: stash and y_out go together");
-    RolloutBufs B{cur_obs, h, c, obs, act, rew, val, logp, done, flags, keep, last_val, forced_act, noise, nan_count, info, stash, y_out};
+    UAV_REQUIRE(!stash || (int64_t)n_env * horizon * 6 * hidden < (1ll << 32), "uav_rollout: stash rows exceed 32-bit offsets");
+    RolloutBufs B{cur_obs, h, c, obs, act, rew, val, logp, done, flags, keep, last_val, forced_act, noise, nan_count, info, heads, stash, y_out};
     EnvBlob blob = env_blob_view(env_state, n_env);
     switch (hidden) {
         case 64: return launch_rollout<64>(P, blob, n_env, horizon, iter, params, B, as_stream(stream));

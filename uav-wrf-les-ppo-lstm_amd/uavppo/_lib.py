@@ -45,7 +45,7 @@ SIGNATURES = {
     "uav_mlp_stash_floats": (I64, [I32, I32]),
     "uav_mlp_fwd": (I32, [P, P, P, I64, I32, I32, I32, I32, P, P, P]),
     "uav_mlp_bwd": (I32, [P, P, P, P, P, I64, I32, I32, I32, I32, P, P]),
-    "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P]),
+    "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, P, P]),
     "uav_lstm_wgrad": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),
@@ -54,7 +54,7 @@ SIGNATURES = {
     "uav_env_peek": (I32, [P, P, I32, P, P, P, P, P]),
     "uav_env_materialise": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, P]),
     "uav_rollout": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, I32, I32, U64, P, P, P, P, P, P, P, P, P, P,
-                          P, P, P, P, P, P, P, P, P]),
+                          P, P, P, P, P, P, P, P, P, P]),
 }
 
 _lib = None

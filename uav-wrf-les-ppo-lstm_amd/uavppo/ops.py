@@ -301,8 +301,10 @@ def env_peek(state, n_env, pos=None, source=None, steps=None, episode=None):
 
 
 # ----------------------------------------------------------------------------- L1
-def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=True, y=None):
-    """One nn.LSTM layer over x[N,T,I] (env-major).  Returns y[N,T,H], hn, cn, stash[N,T,6H]."""
+def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=True, y=None, w_head=None, b_head=None,
+             heads=None):
+    """One nn.LSTM layer over x[N,T,I] (env-major).  Returns y[N,T,H], hn, cn, stash[N,T,6H].
+    With w_head [A1,H], b_head [A1] and a heads [N,T,A1] buffer the kernel also writes heads = y W_head^T + b_head."""
     N, T, I = x.shape
     H = w_hh.shape[1]
     dev = x.device
@@ -316,7 +318,12 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
                              _p(h0, F32, (N, H), "h0"), _p(c0, F32, (N, H), "c0"), _p(w_ih, F32, (4 * H, I), "w_ih"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(b_ih, F32, (4 * H,), "b_ih"),
                              _p(b_hh, F32, (4 * H,), "b_hh"), N, T, I, H, _p(y, F32, (N, T, H), "y"), _p(hn), _p(cn),
-                             _p(stash, F32, (N, T, 6 * H), "stash"), _stream()), "uav_lstm_fwd")
+                             _p(stash, F32, (N, T, 6 * H), "stash"),
+                             _p(w_head, F32, None if w_head is None else (w_head.shape[0], H), "w_head"),
+                             _p(b_head, F32, None if w_head is None else (w_head.shape[0],), "b_head"),
+                             0 if w_head is None else int(w_head.shape[0]),
+                             _p(heads, F32, None if w_head is None else (N, T, w_head.shape[0]), "heads"), _stream()),
+          "uav_lstm_fwd")
     if _t is not None:
         _t.record()
     return y, hn, cn, stash
@@ -381,7 +388,7 @@ def colsum(x, out=None):
 
 # ----------------------------------------------------------------------------- R1
 def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h, c, bufs, last_val=None,
-                 forced_act=None, noise=None, nan_count=None, stash=None, y=None, info=None):
+                 forced_act=None, noise=None, nan_count=None, stash=None, y=None, info=None, heads=None):
     """Fused persistent rollout (csrc/rollout.hip).  bufs: dict obs[N,T,6] act rew val logp done flags keep."""
     N, T = n_env, horizon
     _t = KERNEL_TIMER.bracket("rollout")
@@ -395,7 +402,7 @@ def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h,
                             _p(last_val, F32, (N,), "last_val"), _p(forced_act, I32, (N, T), "forced_act"),
                             _p(noise, F64, (N, T, 2), "noise"), _p(nan_count, I32, (1,), "nan_count"),
                             _p(stash, F32, (N, T, 6 * hidden), "stash"), _p(y, F32, (N, T, hidden), "y"),
-                            _p(info, F32, (N, T, 6), "info"), _stream()),
+                            _p(info, F32, (N, T, 6), "info"), _p(heads, F32, (N, T, 6), "heads"), _stream()),
           "uav_rollout")
     if _t is not None:
         _t.record()

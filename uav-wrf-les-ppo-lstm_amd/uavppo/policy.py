@@ -156,24 +156,32 @@ class LSTMActorCritic(_FlatPolicy):
         return z, z.clone()
 
     def heads(self, obs, keep, h0, c0, work=None, want_heads=True):
-        """obs [N,T,I], keep [N,T] or None, h0,c0 [L,N,H] -> heads [N*T, A+1].  Saves what
-        backward() needs.  `work` may hold preallocated 'stash{l}', 'y{l}' tensors."""
+        """obs [N,T,I], keep [N,T] or None, h0,c0 [L,N,H] -> heads [N*T, A+1] (logits | value).  Saves what
+        backward() needs.  `work` may hold preallocated 'stash{l}', 'y{l}', 'heads' tensors.  The top layer's
+        sequence kernel applies the actor / critic rows itself (uav_lstm_fwd heads output)."""
         N, T, _ = obs.shape
         v = self.views
         x = obs
         saved = []
         work = work or {}
+        heads = None
         for l in range(self.num_layers):
+            top = want_heads and l == self.num_layers - 1
+            if top:
+                heads = work.get("heads")
+                if heads is None or heads.shape[0] != N:
+                    heads = torch.empty(N, T, self.n_act + 1, dtype=torch.float32, device=obs.device)
             y, hn, cn, stash = ops.lstm_fwd(x, keep, h0[l], c0[l], v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
                                             v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"],
-                                            stash=work.get(f"stash{l}"), y=work.get(f"y{l}"))
+                                            stash=work.get(f"stash{l}"), y=work.get(f"y{l}"),
+                                            w_head=v["head.weight"] if top else None,
+                                            b_head=v["head.bias"] if top else None, heads=heads if top else None)
             saved.append((x, stash, y, h0[l]))
             x = y
         self._saved = (saved, keep, x)
         if not want_heads:
-            return x.view(N * T, self.hidden)          # trunk output; the loss kernel applies the heads
-        return ops.gemm(x.view(N * T, self.hidden), v["head.weight"], trans_b=True, bias=v["head.bias"],
-                        out=work.get("heads"))
+            return x.view(N * T, self.hidden)          # trunk output (uav_ppo_loss_from_y applies the heads)
+        return heads.view(N * T, self.n_act + 1)
 
     def adopt_forward(self, obs, keep, h0, stash, y):
         """Epoch 0 of a PPO update runs with the rollout's parameters: the fused rollout kernel already wrote

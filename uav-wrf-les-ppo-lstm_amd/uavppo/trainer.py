@@ -84,7 +84,7 @@ class VecPPOTrainer:
             self.h0 = torch.zeros(L, N, H, **f32)     # state at the start of the current rollout (for BPTT)
             self.c0 = torch.zeros(L, N, H, **f32)
             nb = N // self.num_minibatches
-            self.work = {"dgates": torch.empty(nb, T, 4 * H, **f32), "heads": torch.empty(nb * T, 6, **f32)}
+            self.work = {"dgates": torch.empty(nb, T, 4 * H, **f32), "heads": torch.empty(nb, T, 6, **f32)}   # heads: logits | value, written by the sequence kernels
             for l in range(L):
                 self.work[f"stash{l}"] = torch.empty(nb, T, 6 * H, **f32)
                 self.work[f"y{l}"] = torch.empty(nb, T, H, **f32)
@@ -125,7 +125,7 @@ class VecPPOTrainer:
                              self.iteration, self.cur_obs, self.h[0], self.c[0], self.buf, last_val=self.last_val,
                              forced_act=forced_act, noise=noise, nan_count=self.nan_count,
                              stash=self.work["stash0"] if reuse else None, y=self.work["y0"] if reuse else None,
-                             info=self.info)
+                             info=self.info, heads=self.work["heads"] if reuse else None)
             self._rollout_forward_valid = reuse
         else:
             self._collect_stepwise(forced_act, noise)
@@ -229,14 +229,16 @@ class VecPPOTrainer:
                         self.loss_sums, self.dheads, self.dhead_bias)
                 if self.kind == "lstm":
                     if self._rollout_forward_valid:
-                        # first optimiser step after a fused rollout: parameters unchanged since the rollout
-                        y = self.policy.adopt_forward(b["obs"], b["keep"], self.h0, self.work["stash0"], self.work["y0"])
+                        # first optimiser step after a fused rollout: parameters unchanged since the rollout, whose
+                        # kernel already wrote this forward pass (stash, y) and its heads
+                        self.policy.adopt_forward(b["obs"], b["keep"], self.h0, self.work["stash0"], self.work["y0"])
+                        heads = self.work["heads"]
                         self._rollout_forward_valid = False
                     else:
-                        y = self.policy.heads(b["obs"][sl], b["keep"][sl],
-                                              self.h0[:, sl].contiguous() if M > 1 else self.h0,
-                                              self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work, want_heads=False)
-                    ops.ppo_loss_from_y(y, self.policy.views["head.weight"], self.policy.views["head.bias"], *args)
+                        heads = self.policy.heads(b["obs"][sl], b["keep"][sl],
+                                                  self.h0[:, sl].contiguous() if M > 1 else self.h0,
+                                                  self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work)
+                    ops.ppo_loss_heads(heads.view(nb * T, -1), *args)
                 else:
                     heads = self.policy.heads(b["obs"][sl].reshape(nb * T, self.obs_dim), stash=self.work["stash"])
                     ops.ppo_loss_heads(heads, *args)
