@@ -524,6 +524,7 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_x6_kernel(
             bb[2] = *reinterpret_cast<const bf16x8*>(src + 2 * BPL);
             mac6(acc[2 * pair][ni], ap[0], bb);
             mac6(acc[2 * pair + 1][ni], ap[1], bb);
+            if (HEADS && (ni & 1)) asm volatile("" ::: "memory");   // at most two tiles of B fragments in flight: room for the head tile
         }
         if (HEADS && pair == 1) {                         // dW_head tile of this wave: dheads^T Y[:, 16w .. 16w+16)
             const unsigned short* yp = bp + 3 * BPL;
