@@ -42,6 +42,14 @@ def main():
             print("  wgrad wave %s cycles/slab: " % ("0" if wv == 0 else "last") +
                   " | ".join("%s %.0f" % (names[i], buf[wv * 8 + i] / ns) for i in range(8)) +
                   " | total %.0f" % (sum(buf[wv * 8 + i] for i in range(8)) / ns))
+    if hasattr(L, "uav_x6_prof_read"):
+        buf = (C.c_ulonglong * 16)()
+        L.uav_x6_prof_read(buf)
+        names = ["loop", "wait+ring reads+dma issue", "barrier b2", "dy+pointwise+split+stores", "mfma+partials", "barrier b1", "sum"]
+        for wv in range(2):
+            print("  bwd wave %s cycles/step: " % ("0" if wv == 0 else "last") +
+                  " | ".join("%s %.0f" % (names[i], buf[wv * 8 + i] / T) for i in range(7)) +
+                  " | total %.0f" % (sum(buf[wv * 8 + i] for i in range(7)) / T))
     grad = pol.grad.detach().cpu().double().numpy()
     out = os.path.join(ROOT, "gpurun_out", "grad_%s.npy" % ("f32" if os.environ.get("UAV_LSTM_F32_MFMA") else "x6"))
     os.makedirs(os.path.dirname(out), exist_ok=True)
