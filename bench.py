@@ -173,7 +173,7 @@ def main():
     env_steps = N * T * world * args.steps
     value = env_steps / dt
     opt_steps = tr.hp["epochs"] * tr.num_minibatches
-    # roofline of the dominant kernel, the BPTT sequence kernel lstm_bwd_x6_kernel.  With its dh = dG W_hh product
+    # roofline of the dominant kernel, the BPTT sequence kernel lstm_bwd_x6k_kernel.  With its dh = dG W_hh product
     # on the bf16 matrix pipe (3-way operand split, f32 accuracy) it sits under the HBM roof, not the MFMA one:
     # algorithmic bytes per (env, step) = 5H stash values read + 4H gate gradients written + NH dheads + keep,
     # x N*T per launch (DESIGN.md "Kernels"), over its average launch duration timed live with HIP events on the
@@ -189,8 +189,8 @@ def main():
         sec = bwd["avg_ms"] * 1e-3
         ach = bytes_bwd / sec / 1e9
         traffic = None
-        kname = "lstm_bwd_x6_kernel<%d>" % H
-        tf = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic_pmc.json")
+        kname = "lstm_bwd_x6k_kernel<%d>" % H
+        tf = os.path.join(ROOT, "profiles", "r01_f_hbm_traffic_pmc.json")
         if args.config == "c3" and os.path.exists(tf):
             traffic = json.load(open(tf)).get(kname, {}).get("hbm_total_bytes")
         roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
