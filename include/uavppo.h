@@ -114,6 +114,11 @@ int uav_gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, 
 
 /* out[c] = sum over rows of x[r][c]  (bias gradients; deterministic two-stage reduction).  cols <= 1024. */
 int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out, uav_stream stream);
+/* LayerNorm(cols, eps 1e-5) + ReLU over the rows of z [rows][cols] (cols in 64/128/256/512): z is overwritten with the
+ * normalised values, a = relu(z * gamma + beta), rstd [rows].  The nn.LayerNorm -> nn.ReLU pairs of model.py:22-27 and of
+ * the stop predictor's head, PPOV2.0/model.py:213-218. */
+int uav_ln_relu(uav_ctx* ctx, float* z, float* a, float* rstd, const float* gamma, const float* beta, int64_t rows,
+                int cols, uav_stream stream);
 
 /* ---- M2: the reference's MLP policy (model.py:17-53), forward and backward.
  * params: flat f32[36230-like] in the order W1[h1][in] b1 g1 be1 W2[h2][h1] b2 g2 be2

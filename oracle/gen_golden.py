@@ -279,9 +279,67 @@ def gen_e2e(n_updates=24):
     np.savez_compressed(os.path.join(OUT, "e2e_v20.npz"), versions=str(VERS), **out)
 
 
+def gen_eval():
+    """N2: the reference's ThresholdController (PPOV2.0/evaluate_with_lstm.py:10-37) driving its own
+    ConcentrationThresholdPredictor (PPOV2.0/model.py:203-240, eval mode) over synthetic concentration trajectories:
+    thresholds after every update and the step at which should_stop fires.  The script is loaded from the reference
+    tree (its main() is guarded); sklearn's MinMaxScaler is the real one."""
+    import importlib.util
+    cfg, envm, model, _ = _refload.load("PPOV2.0")
+    sys.modules["config"], sys.modules["environment"], sys.modules["model"] = cfg, envm, model
+    try:
+        spec = importlib.util.spec_from_file_location("eval_ref", f"{_refload.REF_ROOT}/PPOV2.0/evaluate_with_lstm.py")
+        ev = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ev)
+    finally:
+        for m in ("config", "environment", "model"):
+            sys.modules.pop(m, None)
+    from sklearn.preprocessing import MinMaxScaler
+    torch.manual_seed(11)
+    net = model.ConcentrationThresholdPredictor(hidden_size=32)      # small fixture; the default 128 is covered on the GPU
+    with torch.no_grad():                       # xavier init gives tiny outputs; put the prediction in concentration units
+        net.fc[4].bias.fill_(52.0)
+        net.fc[4].weight.mul_(8.0)
+    net.eval()
+    rng = np.random.RandomState(5)
+    scaler_params = np.array([0.0, 100.0]) + rng.rand(2)
+    scaler = MinMaxScaler()
+    scaler.fit(scaler_params.reshape(-1, 1))
+    out = {f"sd/{k}": v for k, v in sd_to_np(net.state_dict()).items()}
+    out["scaler_params"] = scaler_params
+    # raw predictor outputs on random windows
+    xw = rng.rand(7, 10, 1).astype(np.float32)
+    with torch.no_grad():
+        out["pred_x"] = xw
+        out["pred_y"] = net(torch.from_numpy(xw), lengths=[10] * 7).numpy()
+    trajs, thr, stop_at = [], [], []
+    for ep in range(8):
+        L = 90
+        t = np.arange(L)
+        peak = 35.0 + 8.0 * ep
+        traj = peak / (1.0 + np.exp(-(t - 30 - 3 * ep) / 6.0)) + rng.rand(L) * 4.0     # rising plume + turbulence
+        if ep % 3 == 2:
+            traj = traj * 0.3                                                        # never reaches the threshold
+        ctl = ev.ThresholdController(net, scaler)
+        ths, stop = [], -1
+        for step in range(1, L + 1):
+            if step % 10 == 0:
+                ctl.update_threshold(list(traj[:step]))
+                ths.append(np.nan if ctl.current_threshold is None else ctl.current_threshold)
+            if ctl.should_stop(traj[step - 1], step):
+                stop = step
+                break
+        trajs.append(traj)
+        thr.append(np.pad(np.asarray(ths, np.float64), (0, 9 - len(ths)), constant_values=np.nan))
+        stop_at.append(stop)
+    out.update(traj=np.asarray(trajs), thresholds=np.asarray(thr), stop_at=np.asarray(stop_at))
+    print("eval: stop_at", stop_at, "thresholds[0]", thr[0][:4])
+    np.savez_compressed(os.path.join(OUT, "eval_v20.npz"), versions=str(VERS), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e"]
+    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval"]
     if "env" in which:
         gen_env()
     if "policy" in which:
@@ -290,3 +348,5 @@ if __name__ == "__main__":
         gen_curriculum()
     if "e2e" in which:
         gen_e2e()
+    if "eval" in which:
+        gen_eval()

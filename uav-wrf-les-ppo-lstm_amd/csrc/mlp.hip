@@ -215,6 +215,12 @@ static int ln_bwd_any(uav_ctx* ctx, int C, float* d, const float* xhat, const fl
 
 extern "C" {
 
+int uav_ln_relu(uav_ctx* ctx, float* z, float* a, float* rstd, const float* gamma, const float* beta, int64_t rows,
+                int cols, uav_stream stream) {
+    UAV_REQUIRE(ctx && z && a && rstd && gamma && beta && rows > 0, "uav_ln_relu: bad argument");
+    return ln_fwd_any(cols, z, a, rstd, gamma, beta, rows, as_stream(stream));
+}
+
 int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out, uav_stream stream) {
     UAV_REQUIRE(ctx && x && out && rows > 0 && cols > 0 && cols <= 1024, "uav_colsum: bad argument");
     UAV_REQUIRE(ctx->ws_bytes >= (size_t)1024 * 1024 * sizeof(float), "uav_colsum: workspace too small");

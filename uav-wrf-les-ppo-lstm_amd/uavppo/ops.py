@@ -311,7 +311,7 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
     y = torch.empty(N, T, H, dtype=F32, device=dev) if y is None else y
     hn = torch.empty(N, H, dtype=F32, device=dev)
     cn = torch.empty(N, H, dtype=F32, device=dev)
-    if stash is None and (want_stash or I > 8):
+    if stash is None and (want_stash or I > 8 or H not in (64, 128)):     # the non-fused / generic paths work through the stash
         stash = torch.empty(N, T, 6 * H, dtype=F32, device=dev)
     _t = KERNEL_TIMER.bracket("lstm_fwd")
     check(lib().uav_lstm_fwd(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"),
@@ -376,6 +376,16 @@ def env_materialise(state, n_env, cfg, env_index, out=None):
     check(lib().uav_env_materialise(_h(state), _p(state, U8, name="env state"), n_env, C.byref(cfg), int(env_index),
                                     _p(out, F64, (500, 500, 2), "field_out"), _stream()), "uav_env_materialise")
     return out
+
+
+def ln_relu(z, gamma, beta):
+    """relu(LayerNorm(z)) over the rows of z [rows, cols]; z is overwritten with the normalised values."""
+    rows, cols = z.shape
+    a = torch.empty_like(z)
+    rstd = torch.empty(rows, dtype=F32, device=z.device)
+    check(lib().uav_ln_relu(_h(z), _p(z, F32, (rows, cols), "z"), _p(a, F32), _p(rstd, F32), _p(gamma, F32, (cols,), "gamma"),
+                            _p(beta, F32, (cols,), "beta"), rows, cols, _stream()), "uav_ln_relu")
+    return a
 
 
 def colsum(x, out=None):
