@@ -230,17 +230,22 @@ __global__ __launch_bounds__(256) void ppo_loss_from_y_kernel(
     loss_block_epilogue<A>(acc, s_db, partial);
 }
 
+// one pass over the block partials: thread (column c = tid % 16, row group g = tid / 16) sums rows g, g+16, ... of
+// column c (coalesced 128-B rows), then the 16 group sums of a column are added in a fixed order
 __global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nb, int n_heads,
                                                          double* __restrict__ out4, float* __restrict__ dbias) {
-    __shared__ double sm[4];
-    for (int k = 0; k < 4 + n_heads; ++k) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < nb; i += 256) s += partial[(size_t)LOSS_PSTRIDE * i + k];
-        const double r = block256_sum(s, sm);
-        if (threadIdx.x == 0) {
-            if (k < 4) out4[k] = r;
-            else if (dbias) dbias[k - 4] = (float)r;
-        }
+    __shared__ double sm[16][17];
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+    double s = 0.0;
+    for (int i = g; i < nb; i += 16) s += partial[(size_t)LOSS_PSTRIDE * i + c];
+    sm[g][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 4 + n_heads) {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sm[k][threadIdx.x];
+        if (threadIdx.x < 4) out4[threadIdx.x] = r;
+        else if (dbias) dbias[threadIdx.x - 4] = (float)r;
     }
 }
 

@@ -218,7 +218,8 @@ class LSTMActorCritic(_FlatPolicy):
         v, g = self.views, self.grad_views
         work = work or {}
         if dhead_bias is not None:
-            g["head.bias"].copy_(dhead_bias)
+            if dhead_bias.data_ptr() != g["head.bias"].data_ptr():      # the loss kernel may write the gradient view directly
+                g["head.bias"].copy_(dhead_bias)
         else:
             ops.colsum(dheads, out=g["head.bias"])
         dy = None

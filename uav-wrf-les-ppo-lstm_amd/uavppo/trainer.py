@@ -95,6 +95,8 @@ class VecPPOTrainer:
             self.work = {"stash": torch.empty(nb * T * (2 * 256 + 2 * 128 + 2), **f32)}
             self._mlp_tmp = {"rew": torch.zeros(N, **f32), "done": torch.zeros(N, **f32),
                              "flags": torch.zeros(N, dtype=torch.uint8, device=d), "stash": None}
+        if policy == "lstm":
+            self.dhead_bias = self.policy.grad_views["head.bias"]       # the loss kernel's column sums ARE this gradient
         self.dheads = torch.empty((N // self.num_minibatches) * T, 6, **f32)
         self.reset()
 
