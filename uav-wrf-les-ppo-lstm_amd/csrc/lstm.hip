@@ -484,28 +484,35 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
             X6_PROF_DEP(acc[0][0]); X6_PROF_DEP(acc[1][1]); X6_PROF_DEP(acc[2][2]); X6_PROF_DEP(acc[3][3]);
             X6_PROF_MARK(1);
             const float kn = kbuf[(xb * TC + tt) * MT + j];              // keep of step t+1 (1 past the end)
-            float gi[4], gf[4], gg[4], go[4], cp[4], hh[4], hm[4];
+            // the stash stores are issued as soon as their values exist, so the write stream starts under the rest of
+            // the gate math instead of in one burst before the barrier
+            float gi[4], gf[4], gg[4], go[4], cp[4], hh[4], hm[4], cc[4];
+            float* sp = stash + row * (6 * H) + uo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                gi[r] = sigmoidf_(acc[0][r]); gf[r] = sigmoidf_(acc[1][r]);
-                gg[r] = tanhf_(acc[2][r]); go[r] = sigmoidf_(acc[3][r]);
+                gi[r] = sigmoidf_(acc[0][r]); gf[r] = sigmoidf_(acc[1][r]); gg[r] = tanhf_(acc[2][r]);
                 cp[r] = c_reg[r];
-                const float c = gf[r] * cp[r] + gi[r] * gg[r];
-                hh[r] = go[r] * tanhf_(c);
+                cc[r] = gf[r] * cp[r] + gi[r] * gg[r];
+            }
+            if (live && stash) {
+                *reinterpret_cast<float4*>(sp) = float4{gi[0], gi[1], gi[2], gi[3]};
+                *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
+                *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
+                *reinterpret_cast<float4*>(sp + 4 * H) = float4{cp[0], cp[1], cp[2], cp[3]};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                go[r] = sigmoidf_(acc[3][r]);
+                hh[r] = go[r] * tanhf_(cc[r]);
                 hm[r] = hh[r] * kn;
-                c_reg[r] = (t == T - 1) ? c : c * kn;                    // cn is the unmasked final cell state
+                c_reg[r] = (t == T - 1) ? cc[r] : cc[r] * kn;            // cn is the unmasked final cell state
             }
             put_h(hpl + (cur ^ 1) * 3 * PLANE, hh);
             kcur = kn;
             if (live) {
                 *reinterpret_cast<float4*>(y + row * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
                 if (stash) {
-                    float* sp = stash + row * (6 * H) + uo;
-                    *reinterpret_cast<float4*>(sp) = float4{gi[0], gi[1], gi[2], gi[3]};
-                    *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
-                    *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
                     *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
-                    *reinterpret_cast<float4*>(sp + 4 * H) = float4{cp[0], cp[1], cp[2], cp[3]};
                     if (I > 6 && t + 1 < T)                              // h_prev of step t+1 (generic wgrad path)
                         *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hm[0], hm[1], hm[2], hm[3]};
                 }
