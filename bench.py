@@ -203,6 +203,9 @@ def main():
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
+        "arithmetic": "f32 results throughout; the LSTM matrix products are evaluated as six bf16 piece products per f32 "
+                      "product (exact 3-way operand split) with f32 accumulation -- same error vs f64 as the exact-f32 MFMA "
+                      "chain (tests/test_gpu_lstm.py::test_split_bf16_kernels_have_f32_accuracy); env arithmetic in f64",
         "config": {"workload": f"BASELINE config {args.config.upper()}: PPO{cfg['variant'].upper()}, {N} envs/GPU x T={T}, "
                                f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs {6 + cfg.get('trend_k', 0)}, "
                                f"5 actions, reference_exact GAE, {tr.hp['epochs']} epochs x {tr.num_minibatches} minibatch "
