@@ -1150,13 +1150,19 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_x6k_kernel(
             : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(ring_base)
             : "memory");
     };
-    // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)]
-    auto issue_small = [&](int t, int slot) {
+    // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)].
+    // The lane's element of step 0 and its per-step stride are fixed: only `+ t * stride` is left in the loop
+    // (the division by NH used to run every step on the two waves everybody waits for).
+    const float* small_at0;
+    unsigned small_stride;
+    {
         const int e = w * 64 + lane;
-        const float* src;
-        if (e < 16 * NH) src = dheads + ((size_t)min(n0 + e / NH, N - 1) * T + t) * NH + e % NH;
-        else if (e >= 112 && keep) src = keep + (size_t)min(n0 + e - 112, N - 1) * T + t;
-        else src = w_hh + (lane & 15);                                       // padding: any readable dwords
+        if (e < 16 * NH) { small_at0 = dheads + (size_t)min(n0 + e / NH, N - 1) * T * NH + e % NH; small_stride = (unsigned)NH; }
+        else if (e >= 112 && keep) { small_at0 = keep + (size_t)min(n0 + e - 112, N - 1) * T; small_stride = 1u; }
+        else { small_at0 = w_hh + (lane & 15); small_stride = 0u; }         // padding: any readable dwords
+    }
+    auto issue_small = [&](int t, int slot) {
+        const float* src = small_at0 + (size_t)((unsigned)t * small_stride);
         const unsigned dst = small_base + (unsigned)((slot * SMALL + w * 64) * 4);
         unsigned m0save;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
