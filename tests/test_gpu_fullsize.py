@@ -91,3 +91,33 @@ def test_update_fullsize_is_deterministic_and_finite():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])     # no atomics: bitwise repeatable
     pl, vl, ent = (outs[0][1][:3] / (N * T)).tolist()
     assert np.isfinite([pl, vl, ent]).all() and 1.55 < ent < 1.6095
+
+
+def test_lstm_fullsize_scaling_causality_and_heads(trainer):
+    """More properties that need no oracle at full size: (a) the backward pass and the weight gradients are linear in
+    dheads, and scaling by a power of two is exact in f32 AND commutes with the bf16 operand split, so the results
+    must scale bit for bit; (b) the sequence is causal: changing observations from step t0 on leaves y[:, :t0]
+    bitwise unchanged; (c) the heads the forward kernel writes are y W_head^T + b_head."""
+    from uavppo import ops
+    b, v = trainer.buf, trainer.policy.views
+    w = (v["lstm.weight_ih_l0"], v["lstm.weight_hh_l0"], v["lstm.bias_ih_l0"], v["lstm.bias_hh_l0"])
+    h0, c0 = trainer.h0[0], trainer.c0[0]
+    heads = torch.empty(N, T, 6, device=DEV)
+    y, hn, cn, stash = ops.lstm_fwd(b["obs"], b["keep"], h0, c0, *w, w_head=v["head.weight"], b_head=v["head.bias"], heads=heads)
+    rows = torch.from_numpy(np.random.RandomState(1).choice(N, 40, replace=False)).to(DEV)
+    want = y[rows].double() @ v["head.weight"].double().T + v["head.bias"].double()
+    assert torch.allclose(heads[rows].double(), want, rtol=1e-5, atol=2e-6)
+    # (a)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    dheads = torch.randn(N, T, 6, generator=g, device=DEV) / (N * T)
+    r1 = ops.lstm_bwd(b["obs"], b["keep"], stash, w[0], w[1], y, h0, dheads=dheads, w_head=v["head.weight"])
+    keep1 = {k: r1[k].clone() for k in ("dw_hh", "dw_ih", "db", "dw_head", "dh0", "dc0")}
+    r4 = ops.lstm_bwd(b["obs"], b["keep"], stash, w[0], w[1], y, h0, dheads=dheads * 4.0, w_head=v["head.weight"])
+    for k, t in keep1.items():
+        assert torch.equal(r4[k], t * 4.0), k
+    # (b)
+    t0 = 77
+    obs2 = b["obs"].clone()
+    obs2[:, t0:] = torch.rand_like(obs2[:, t0:])
+    y2, _, _, _ = ops.lstm_fwd(obs2, b["keep"], h0, c0, *w, want_stash=False)
+    assert torch.equal(y2[:, :t0], y[:, :t0]) and not torch.equal(y2[:, t0:], y[:, t0:])
