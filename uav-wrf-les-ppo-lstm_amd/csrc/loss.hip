@@ -230,20 +230,27 @@ __global__ __launch_bounds__(256) void ppo_loss_from_y_kernel(
     loss_block_epilogue<A>(acc, s_db, partial);
 }
 
-// one pass over the block partials: thread (column c = tid % 16, row group g = tid / 16) sums rows g, g+16, ... of
-// column c (coalesced 128-B rows), then the 16 group sums of a column are added in a fixed order
-__global__ __launch_bounds__(256) void loss_final_kernel(const double* __restrict__ partial, int nb, int n_heads,
-                                                         double* __restrict__ out4, float* __restrict__ dbias) {
-    __shared__ double sm[16][17];
+// one pass over the block partials: thread (column c = tid % 16, row group g = tid / 16) sums rows g, g+64, ... of
+// column c (coalesced 128-B rows, independent loads), then the 64 group sums of a column are added in a fixed order
+__global__ __launch_bounds__(1024) void loss_final_kernel(const double* __restrict__ partial, int nb, int n_heads,
+                                                          double* __restrict__ out4, float* __restrict__ dbias) {
+    __shared__ double sm[64][17];
     const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
-    double s = 0.0;
-    for (int i = g; i < nb; i += 16) s += partial[(size_t)LOSS_PSTRIDE * i + c];
-    sm[g][c] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = g;
+    for (; i + 192 < nb; i += 256) {
+        s0 += partial[(size_t)LOSS_PSTRIDE * i + c];
+        s1 += partial[(size_t)LOSS_PSTRIDE * (i + 64) + c];
+        s2 += partial[(size_t)LOSS_PSTRIDE * (i + 128) + c];
+        s3 += partial[(size_t)LOSS_PSTRIDE * (i + 192) + c];
+    }
+    for (; i < nb; i += 64) s0 += partial[(size_t)LOSS_PSTRIDE * i + c];
+    sm[g][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < 4 + n_heads) {
         double r = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r += sm[k][threadIdx.x];
+        for (int k = 0; k < 64; ++k) r += sm[k][threadIdx.x];
         if (threadIdx.x < 4) out4[threadIdx.x] = r;
         else if (dbias) dbias[threadIdx.x - 4] = (float)r;
     }
@@ -328,7 +335,7 @@ int uav_ppo_loss(uav_ctx* ctx, const float* logits, const float* value, const in
         default: UAV_REQUIRE(false, "uav_ppo_loss: n_act=%d unsupported", n_act);
     }
 #undef LAUNCH_LOSS
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
                        dhead_bias);
     UAV_LAUNCH_CHECK();
     return 0;
@@ -354,7 +361,7 @@ int uav_ppo_loss_from_y(uav_ctx* ctx, const float* y, const float* w_head, const
         default: UAV_REQUIRE(false, "uav_ppo_loss_from_y: hidden=%d unsupported (64/128/256)", hidden);
     }
 #undef LAUNCH_LY
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, as_stream(stream), partial, nb, n_act + 1, loss_sums,
                        dhead_bias);
     UAV_LAUNCH_CHECK();
     return 0;
