@@ -140,3 +140,42 @@ def test_vectorised_greedy_evaluation_matches_oracle_episodes(ev):
     assert np.array_equal(got["stopped_early"], np.asarray(stopped))
     assert np.allclose(got["deviations"], np.asarray(devs), atol=2e-3)
     assert 0 < np.sum(stopped) < N or np.ptp(steps) > 0          # the scenario is not degenerate
+
+
+def test_vectorised_greedy_evaluation_v21_stop_rule_matches_oracle(ev):
+    """PPOV2.1 rule (evaluate_with_lstm.py:69-77): once 20 concentrations are in the trajectory, stop when the
+    PeakAndStopPredictor's stop probability exceeds 0.8.  N parallel episodes == N sequential oracle episodes."""
+    from uavppo.policy import MLPActorCritic
+    from uavppo.vec_env import VecMethaneEnv
+    N, LIM = 10, 90
+    bank = FieldBank.from_seed(N, "v2.1", seed=21)
+    env = VecMethaneEnv(N, "v2.1", DEV, seed=5, bank=bank.interleaved(), bank_sources=bank.sources)
+    pol = MLPActorCritic(6, 5, device=DEV, seed=12)
+    pol.views["head.weight"][:5].mul_(40.0)
+    pred = ev.PeakAndStopPredictor(device=DEV, seed=6)
+    pred.heads_w[1].mul_(12.0)                 # make the stop head decisive one way or the other
+    rng = np.random.RandomState(4)
+    noise = rng.randn(LIM, N, 2)
+    got = ev.evaluate(lambda o: pol.heads(o.contiguous())[:, :5], env, None, peak_stop=pred,
+                      noise=torch.from_numpy(noise).to(DEV), max_steps=LIM, success_distance=50)
+    p = {k: v.detach().cpu() for k, v in pol.named_views().items()}
+    onet = eo.PeakStopPredictorOracle(_cpu_sd(pred))
+    ora = OracleVecEnv(N, bank, "v2.1", radius=50.0)
+    ora.reset()
+    steps, stopped = [], []
+    for i, e in enumerate(ora.envs):
+        state, traj, t, done, st = e.obs(), [], 0, False, False
+        while not done and t < LIM:
+            with torch.no_grad():
+                probs, _, _ = po.mlp_forward(p, torch.from_numpy(state)[None])
+            state, _, done, _r, _i = e.step(int(torch.argmax(probs)), noise[t, i])
+            traj.append(float(state[2]) * 100.0)
+            t += 1
+            hit, _peak = eo.stop_rule_v21(onet, traj)
+            if hit:
+                st, done = True, True
+        steps.append(t)
+        stopped.append(st)
+    assert np.array_equal(got["steps"], np.asarray(steps)), (got["steps"], steps)
+    assert np.array_equal(got["stopped_early"], np.asarray(stopped))
+    assert np.isnan(got["peak_pred"][~np.asarray(stopped)]).all()
