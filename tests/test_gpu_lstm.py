@@ -201,3 +201,30 @@ def test_lstm_fwd_emits_heads(ops, N, T, I, H, f32_mfma, monkeypatch):
     y2, _, _, _ = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
     assert torch.equal(y, y2)
     monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+
+
+def test_lstm_bwd_fused_path_fuzz_against_dy_path(ops):
+    """Many small ragged shapes: the PPO backward (dheads + w_head: split-bf16 K-split kernel, LDS-DMA stash ring)
+    against the plain-dy exact-f32 kernel fed dy = dheads @ w_head -- recurrent gradients, weight gradients, initial-state
+    gradients.  Catches indexing / ring / partial-sum mistakes at sizes where an error cannot hide in tolerance."""
+    rng = np.random.RandomState(7)
+    dev = DEV
+    for case in range(24):
+        H = (64, 128)[case % 2]
+        N, T = int(rng.randint(1, 70)), int(rng.randint(1, 45))
+        torch.manual_seed(case)
+        x = torch.randn(N, T, 6, device=dev)
+        keep = (torch.rand(N, T, device=dev) > 0.15).float() if case % 3 else None
+        w_ih, w_hh = torch.randn(4 * H, 6, device=dev) * 0.1, torch.randn(4 * H, H, device=dev) * 0.1
+        b = torch.randn(4 * H, device=dev) * 0.1
+        h0, c0 = torch.randn(N, H, device=dev), torch.randn(N, H, device=dev)
+        y, hn, cn, stash = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b, b)
+        dheads = torch.randn(N, T, 6, device=dev)
+        w_head = torch.randn(6, H, device=dev)
+        dy = (dheads.reshape(-1, 6).cpu().double() @ w_head.cpu().double()).float().reshape(N, T, H).to(dev)
+        g1 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=dy)
+        g2 = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dheads=dheads, w_head=w_head)
+        for k in ("dgates", "dw_ih", "dw_hh", "db", "dh0", "dc0"):
+            a, bb = g2[k].double().cpu(), g1[k].double().cpu()
+            scale = bb.abs().max().item() + 1e-12
+            assert (a - bb).abs().max().item() <= 2e-5 * max(scale, 1.0) + 1e-4 * scale, (case, N, T, H, k)
