@@ -56,6 +56,18 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
 }
 
+// ---- split-bf16 ("x6") arithmetic: an f32 value as three bf16 pieces a = p0 + p1 + p2 (8 significand bits each, so
+// the split is exact); products of two split operands keep the six piece products with i + j <= 2 and accumulate them
+// in f32 (v_mfma_f32_16x16x32_bf16).  Error and rate: tools/bf16x6_probe.hip; the argument: lstm.hip, lstm_fwd_x6_kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
+    p0 = (__bf16)a;
+    const float r1 = a - (float)p0;
+    p1 = (__bf16)r1;
+    p2 = (__bf16)(r1 - (float)p1);
+}
+__device__ __forceinline__ unsigned short bf_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
+
 // ---- wave / block reductions (deterministic: fixed tree, no atomics) -------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -4,23 +4,22 @@
 // PPOV2.1/model.py:263,284,311,330): gates = x W_ih^T + b_ih + h W_hh^T + b_hh, chunk order
 // i,f,g,o, c' = s(f) c + s(i) tanh(g), h' = s(o) tanh(c').
 //
-// MI355X design (persistent over time, MFMA-bound, exact f32):
+// MI355X design (persistent over time):
 //   * one workgroup owns 16 env sequences for ALL T steps; grid = N/16 (256 WGs at N=4096);
-//   * wave w owns hidden units [16w,16w+16) of all four gates, so the i,f,g,o pre-activations of
-//     one (env, unit) land in ONE lane's accumulators (v_mfma_f32_16x16x4_f32, M = 16 envs) and
-//     the gate pointwise + cell state never leave registers;
-//   * that wave's 4 x 16 x H slice of W_hh stays in VGPRs for the whole sequence (128 VGPRs at
-//     H=128): the recurrent weights are read from HBM once per launch, not once per step;
-//   * h_t goes through a double-buffered, padded LDS tile (one barrier per step), read back as
-//     conflict-free ds_read_b128 A-fragments (k is permuted so each lane reads contiguous floats);
-//   (A half-step stagger of waves 4-7 against 0-3 -- MI355X_MICROARCH "two waves per SIMD" item 9 -- was
-//    built and measured: no gain here, tools/stagger_probe.hip; what paced the step was the IEEE
-//    division sequence inside the activations, now v_rcp_f32.)
-//   * the K=I<=8 input projection rides along as two extra MFMA k-steps (x staged in LDS per
-//     32-step chunk); wider inputs (stacked layers) use a time-batched GEMM into the stash first.
-// Backward mirrors it with W_hh^T slices in VGPRs: dgates of a step are written to LDS (and to
-// HBM for the weight-gradient GEMMs), dh_{t-1} = dgates W_hh comes back in the same lane layout
-// as the pointwise needs, so dh/dc also stay in registers across the time loop.
+//   * the recurrent weights stay on chip for the whole sequence (VGPRs, plus a wave-private LDS slab for the part
+//     that does not fit): they are read from HBM once per launch, not once per step;
+//   * the i,f,g,o pre-activations of one (env, unit) land in ONE lane's accumulators, so the gate pointwise and the
+//     cell state never leave registers; h_t / the gate gradients are exchanged through LDS, one or two barriers a step.
+// Kernel families in this file (dispatch: launch_fwd, lstm_bwd_seq):
+//   DEFAULT  lstm_fwd_x6_kernel, lstm_bwd_x6k_kernel (and its predecessor lstm_bwd_x6_kernel): the matrix products on
+//            the bf16 pipe at f32 accuracy (three-piece operand split, common.h), weights-as-A orientation (a lane owns
+//            one env and four consecutive units: dwordx4 stores), stash by LDS-DMA in the backward;
+//   EXACT-F32 lstm_fwd_kernel, lstm_bwd_kernel (plain dy; stacked layers), lstm_bwd_dma_kernel: v_mfma_f32_16x16x4_f32
+//            with 128 weight VGPRs per lane; selected by UAV_LSTM_F32_MFMA=1 and for the plain-dy backward.
+//   (A half-step stagger of waves 4-7 against 0-3 was built and measured on the exact-f32 forward: no gain,
+//    tools/stagger_probe.hip; what paced the step was the IEEE division sequence inside the activations, now v_rcp_f32.)
+//   * the K=I<=8 input projection rides along as two exact-f32 MFMA k-steps; wider inputs (stacked layers) use a
+//     time-batched GEMM into the stash first.
 #include <stdlib.h>
 #include "common.h"
 
@@ -218,15 +217,7 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_kernel(
 // the exact-f32 MFMA chain's (tools/bf16x6_probe.hip: 2.69e-7 vs 2.75e-7 on a K=128 dot product) at 2.6x its
 // rate (6 x 16 cycles per K=32 slab against 8 x 32).  W_hh pieces stay in VGPRs (192 at H=128); h_t is split
 // once by the lane that produces it and exchanged through three bf16 LDS planes.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
-    p0 = (__bf16)a;
-    const float r1 = a - (float)p0;
-    p1 = (__bf16)r1;
-    p2 = (__bf16)(r1 - (float)p1);
-}
-__device__ __forceinline__ unsigned short bf_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 
 template <int H>
 struct FwdX6Geom {

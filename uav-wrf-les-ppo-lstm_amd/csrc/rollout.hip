@@ -30,14 +30,6 @@ constexpr float R_F32_EPS = 1.1920928955078125e-07f;
 #define r_sigmoid fast_sigmoid
 #define r_tanh fast_tanh
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
-    p0 = (__bf16)a;
-    const float r1 = a - (float)p0;
-    p1 = (__bf16)r1;
-    p2 = (__bf16)(r1 - (float)p1);
-}
-__device__ __forceinline__ unsigned short bf_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 
 // LDS geometry of the split-bf16 rollout (dynamic part; the env role's small arrays are static)
 template <int H>

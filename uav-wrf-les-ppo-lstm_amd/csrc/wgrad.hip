@@ -324,14 +324,7 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_dma_kernel(
 // the slab body in rotated order -- EARLY waves: split0 mfma0 commit split1 mfma1, LATE waves: mfma0 commit
 // split1 mfma1 split0(next) -- and one group's MFMAs cover the other group's VALU phases.
 // keep[] and the t == 0 test are wave-uniform (scalar).  Needs full 32-row slabs, T >= 8, I <= 6.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& p2) {
-    p0 = (__bf16)a;
-    const float r1 = a - (float)p0;
-    p1 = (__bf16)r1;
-    p2 = (__bf16)(r1 - (float)p1);
-}
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p0, bf16x8& p1, bf16x8& p2) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
