@@ -104,6 +104,14 @@ int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, c
 int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, float* exp_avg,
                   float* exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
                   float eps, float max_norm, float* gnorm_out, uav_stream stream);
+/* AdamW (torch.optim.AdamW, PPOV2.0/train_lstm.py:67): as uav_clip_adam with the decoupled decay param *= 1 - lr*weight_decay. */
+int uav_clip_adamw(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                   float* gnorm_out, uav_stream stream);
+/* nn.SmoothL1Loss(beta), reduction mean (train_lstm.py:66), forward + backward: loss_mean f64[1] device,
+ * dpred [n] = d(loss)/d(pred). */
+int uav_smooth_l1(uav_ctx* ctx, const float* pred, const float* target, int64_t n, float beta, double* loss_mean,
+                  float* dpred, uav_stream stream);
 
 /* ---- dense f32 building block (exact-f32 MFMA): C[M][N] (+)= op(A)[M][K] * op(B)[K][N] + bias[N].
  * Element (i,k) of op(A) is A[i*sa_m + k*sa_k]; element (k,j) of op(B) is B[k*sb_k + j*sb_n]
@@ -119,6 +127,10 @@ int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out,
  * the stop predictor's head, PPOV2.0/model.py:213-218. */
 int uav_ln_relu(uav_ctx* ctx, float* z, float* a, float* rstd, const float* gamma, const float* beta, int64_t rows,
                 int cols, uav_stream stream);
+/* backward of uav_ln_relu: d [rows][cols] holds dL/da on entry and dL/dz on return; xhat = the z the forward left behind;
+ * dgamma, dbeta [cols] (overwritten). */
+int uav_ln_relu_bwd(uav_ctx* ctx, float* d, const float* xhat, const float* rstd, const float* gamma, const float* beta,
+                    int64_t rows, int cols, float* dgamma, float* dbeta, uav_stream stream);
 
 /* ---- M2: the reference's MLP policy (model.py:17-53), forward and backward.
  * params: flat f32[36230-like] in the order W1[h1][in] b1 g1 be1 W2[h2][h1] b2 g2 be2

@@ -337,9 +337,71 @@ def gen_eval():
     np.savez_compressed(os.path.join(OUT, "eval_v20.npz"), versions=str(VERS), **out)
 
 
+def gen_train_lstm():
+    """N3: the reference's SequenceDataset (PPOV2.0/train_lstm.py:12-50) on synthetic sequences, and three optimiser steps of
+    its ConcentrationThresholdPredictor / SmoothL1Loss(beta=2) / AdamW(3e-4) / clip_grad_norm_(1.0) loop body (:84-92) run in
+    eval mode (the reference's dropout takes no external masks), plus torch's own ReduceLROnPlateau trace for the scheduler."""
+    import importlib.util
+    cfg, envm, model, _ = _refload.load("PPOV2.0")
+    sys.modules["config"], sys.modules["model"] = cfg, model
+    dl = importlib.util.module_from_spec(importlib.util.spec_from_file_location("data_loader", f"{_refload.REF_ROOT}/PPOV2.0/data_loader.py"))
+    _refload._install_third_party_stubs()
+    sys.modules["data_loader"] = dl
+    dl.__spec__.loader.exec_module(dl)
+    try:
+        spec = importlib.util.spec_from_file_location("train_lstm_ref", f"{_refload.REF_ROOT}/PPOV2.0/train_lstm.py")
+        tl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(tl)
+    finally:
+        for m in ("config", "model", "data_loader"):
+            sys.modules.pop(m, None)
+    rng = np.random.RandomState(17)
+    TS = cfg.TRAINING_SIZE
+    seqs, concs = [], []
+    for i in range(40):
+        L = int(rng.randint(4, 60))
+        seqs.append(list(np.cumsum(rng.rand(L) * 3.0) + rng.rand() * 5.0))
+        concs.append(float(seqs[-1][-1] * (1.0 + 0.2 * rng.rand())))
+    ds = tl.SequenceDataset(seqs, concs, TS)
+    X = np.stack([ds[i][0].numpy() for i in range(len(ds))])
+    Y = np.stack([ds[i][1].numpy() for i in range(len(ds))])[:, 0]
+    out = {"seq_lens": np.asarray([len(s) for s in seqs]), "seq_flat": np.concatenate([np.asarray(s) for s in seqs]),
+           "source_concs": np.asarray(concs), "X": X, "Y": Y, "data_min": ds.scaler.data_min_, "data_max": ds.scaler.data_max_,
+           "training_size": TS}
+    torch.manual_seed(23)
+    net = model.ConcentrationThresholdPredictor(input_size=1, hidden_size=32)
+    net.eval()
+    crit = torch.nn.SmoothL1Loss(beta=2.0)
+    opt = torch.optim.AdamW(net.parameters(), lr=3e-4)
+    out.update({f"init/{k}": v for k, v in sd_to_np(net.state_dict()).items()})
+    xb, yb = torch.from_numpy(X[:24]), torch.from_numpy(Y[:24])
+    losses, gnorms = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        o = net(xb.unsqueeze(-1), lengths=[xb.size(1)] * len(xb))
+        loss = crit(o, yb)
+        loss.backward()
+        gnorms.append(float(torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)))
+        opt.step()
+        losses.append(float(loss))
+    out.update({f"post/{k}": v for k, v in sd_to_np(net.state_dict()).items()})
+    out.update(losses=np.asarray(losses), gnorms=np.asarray(gnorms))
+    # scheduler trace (torch itself)
+    dummy = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-4)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, mode="min", factor=0.5, patience=5)
+    metrics = np.concatenate([np.linspace(5, 3, 8), np.full(9, 3.0), np.linspace(3.0, 2.99995, 10), np.full(14, 2.9999), [1.0]])
+    lrs = []
+    for m in metrics:
+        sch.step(float(m))
+        lrs.append(dummy.param_groups[0]["lr"])
+    out.update(sched_metrics=metrics, sched_lrs=np.asarray(lrs))
+    print("train_lstm: samples", len(ds), "losses", losses, "gnorms", gnorms, "lrs", sorted(set(lrs)))
+    np.savez_compressed(os.path.join(OUT, "train_lstm_v20.npz"), versions=str(VERS), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval"]
+    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval", "train_lstm"]
     if "env" in which:
         gen_env()
     if "policy" in which:
@@ -350,3 +412,5 @@ if __name__ == "__main__":
         gen_e2e()
     if "eval" in which:
         gen_eval()
+    if "train_lstm" in which:
+        gen_train_lstm()

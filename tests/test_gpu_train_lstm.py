@@ -1,0 +1,101 @@
+"""N3: offline training of the stop predictor on the GPU vs the training oracle (pinned to the reference's
+loop body by tests/test_oracle_train_lstm.py).  -m gpu."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lstm_train_oracle as lt
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "train_lstm_v20.npz")
+
+
+@pytest.fixture(scope="module")
+def tl():
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uav-wrf-les-ppo-lstm_amd")
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import train_lstm as m
+    return m
+
+
+def _seqs(g):
+    out, o = [], 0
+    for L in g["seq_lens"]:
+        out.append(list(g["seq_flat"][o:o + L]))
+        o += L
+    return out
+
+
+def test_sequence_dataset_matches_reference_golden(tl):
+    g = np.load(GOLD, allow_pickle=False)
+    ds = tl.SequenceDataset(_seqs(g), g["source_concs"], int(g["training_size"]))
+    assert np.allclose(ds.windows, g["X"], atol=1e-6) and np.allclose(ds.labels, g["Y"], atol=1e-6)
+    assert np.isclose(ds.data_min_[0], g["data_min"][0]) and np.isclose(ds.data_max_[0], g["data_max"][0])
+    x0, y0 = ds[3]
+    assert x0.shape == (int(g["training_size"]),) and y0.shape == (1,)
+
+
+def test_three_eval_mode_steps_match_the_reference_golden(tl):
+    """The reference's model / SmoothL1Loss / clip / AdamW for three steps (eval mode), replayed on the GPU kernels."""
+    from evaluate_with_lstm import ConcentrationThresholdPredictor
+    g = np.load(GOLD, allow_pickle=False)
+    model = ConcentrationThresholdPredictor(hidden_size=32, device=DEV)
+    model.load_state_dict({k[5:]: g[k] for k in g.files if k.startswith("init/")})
+    tr = tl.PredictorTrainer(model, lr=3e-4)
+    x = torch.from_numpy(g["X"][:24]).to(DEV)[:, :, None].contiguous()
+    y = torch.from_numpy(g["Y"][:24]).to(DEV)
+    for k in range(3):
+        loss = tr.train_step(x, y, masks=None)
+        assert np.isclose(float(loss.item()), g["losses"][k], rtol=2e-5), (k, float(loss.item()), g["losses"][k])
+        assert np.isclose(float(tr.gnorm.item()), g["gnorms"][k], rtol=2e-4)
+    for k, v in model.state_dict().items():
+        want = g["post/" + k]
+        assert np.allclose(v.cpu().numpy(), want, rtol=2e-3, atol=3e-6), k      # Adam turns 1e-6 gradient noise into ~1e-6 steps
+
+
+@pytest.mark.parametrize("H", [128, 64])
+def test_train_step_with_dropout_masks_matches_oracle(tl, H):
+    from evaluate_with_lstm import ConcentrationThresholdPredictor
+    torch.manual_seed(H)
+    B, T = 20, 10
+    model = ConcentrationThresholdPredictor(hidden_size=H, device=DEV, seed=5)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = tl.PredictorTrainer(model, lr=3e-4, seed=9)
+    x = torch.rand(B, T, 1, device=DEV)
+    y = torch.rand(B, device=DEV) * 50.0
+    masks = tr.draw_masks(B, T)
+    assert set(masks) == {"l0", "l1", "head"} and abs(float((masks["l0"] > 0).float().mean()) - 0.7) < 0.05
+    opt = lt.AdamWState(params, lr=3e-4)
+    cm = {k: v.cpu() for k, v in masks.items()}
+    for k in range(2):
+        want_loss, want_gn = lt.train_step(params, opt, x.cpu(), y.cpu(), masks=cm)
+        loss = tr.train_step(x, y, masks)
+        assert np.isclose(float(loss.item()), want_loss, rtol=2e-5)
+        assert np.isclose(float(tr.gnorm.item()), want_gn, rtol=3e-4)
+    for k, v in model.state_dict().items():
+        assert torch.allclose(v.cpu(), params[k], rtol=2e-3, atol=3e-6), k
+
+
+def test_training_run_fits_a_synthetic_relation(tl):
+    """A few epochs of train_lstm() on synthetic plume trajectories whose source concentration is a simple function of
+    the window: the epoch loss falls steadily (lr 3e-4 moves the output slowly, exactly as in the reference, which trains for
+    150 epochs) and ReduceLROnPlateau follows torch's rule."""
+    rng = np.random.RandomState(0)
+    seqs, concs = [], []
+    for i in range(256):
+        L = int(rng.randint(12, 40))
+        peak = 20.0 + 60.0 * rng.rand()
+        s = peak / (1.0 + np.exp(-(np.arange(L) - L * 0.6) / 3.0)) + rng.rand(L)
+        seqs.append(list(s))
+        concs.append(float(peak))
+    model, hist = tl.train_lstm(seqs, concs, epochs=12, device=DEV, seed=1, model_dir=None)
+    assert np.isfinite(hist).all() and hist[-1] < hist[0] - 3.0 and hist[-1] <= min(hist) + 1e-9 + 0.2, hist
+    sch = tl.ReduceLROnPlateau(3e-4)
+    ora = lt.ReduceLROnPlateauOracle(3e-4)
+    for m_ in [5, 4, 3, 3, 3, 3, 3, 3, 3, 3, 2.9999, 2.9999, 2.9999, 2.9999, 2.9999, 2.9999, 2.9999, 1.0]:
+        assert sch.step(m_) == ora.step(m_)

@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void norm_final(const double* __restrict__ par
     }
 }
 
+// decay = 1 - lr * weight_decay (torch.optim.AdamW: param.mul_(decay) before the Adam update; 1 for plain Adam)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    const float* __restrict__ scal, float b1, float b2,
-                                                   float step_size, float sqrt_bc2, float eps) {
+                                                   float step_size, float sqrt_bc2, float eps, float decay) {
 #pragma clang fp contract(off)
     const float coef = scal[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -51,13 +52,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / sqrt_bc2 + eps;      // (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps)
-        p[i] = p[i] - step_size * (mi / denom);
+        p[i] = p[i] * decay - step_size * (mi / denom);
     }
 }
 
-extern "C" int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, float* exp_avg,
-                             float* exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
-                             float eps, float max_norm, float* gnorm_out, uav_stream stream) {
+static int clip_adam_impl(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                          float* gnorm_out, uav_stream stream) {
     UAV_REQUIRE(ctx && param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "uav_clip_adam: bad argument");
     double* partial = (double*)ctx->ws;
     float* scal = (float*)((char*)ctx->ws + 4096);
@@ -72,7 +73,45 @@ extern "C" int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, floa
     int ab = (int)((n + 255) / 256);
     if (ab > 2048) ab = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(ab), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
-                       scal, beta1, beta2, step_size, sqrt_bc2, eps);
+                       scal, beta1, beta2, step_size, sqrt_bc2, eps, 1.0f - lr * weight_decay);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             int64_t step, float lr, float beta1, float beta2, float eps, float max_norm, float* gnorm_out,
+                             uav_stream stream) {
+    return clip_adam_impl(ctx, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, 0.f, max_norm, gnorm_out, stream);
+}
+
+extern "C" int uav_clip_adamw(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
+                              float* gnorm_out, uav_stream stream) {
+    return clip_adam_impl(ctx, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, max_norm,
+                          gnorm_out, stream);
+}
+
+// SmoothL1Loss(beta), reduction = mean (train_lstm.py:66): loss_sum[0] += sum_i l(pred_i - target_i) (f64, one block, fixed
+// order), dpred_i = dl/dpred_i / n.  |d| < beta: 0.5 d^2 / beta, else |d| - 0.5 beta.
+__global__ __launch_bounds__(256) void smooth_l1_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        int64_t n, float beta, double* __restrict__ loss_mean,
+                                                        float* __restrict__ dpred) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float d = pred[i] - target[i], a = fabsf(d);
+        if (a < beta) { s += 0.5 * (double)d * d / beta; dpred[i] = d / beta * inv_n; }
+        else { s += (double)a - 0.5 * beta; dpred[i] = (d > 0.f ? 1.f : -1.f) * inv_n; }
+    }
+    const double r = block256_sum(s, sm);
+    if (threadIdx.x == 0) loss_mean[0] = r / (double)n;
+}
+
+extern "C" int uav_smooth_l1(uav_ctx* ctx, const float* pred, const float* target, int64_t n, float beta, double* loss_mean,
+                             float* dpred, uav_stream stream) {
+    UAV_REQUIRE(ctx && pred && target && loss_mean && dpred && n > 0 && beta > 0.f, "uav_smooth_l1: bad argument");
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(1), dim3(256), 0, as_stream(stream), pred, target, n, beta, loss_mean, dpred);
     UAV_LAUNCH_CHECK();
     return 0;
 }

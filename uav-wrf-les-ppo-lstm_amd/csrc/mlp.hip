@@ -221,6 +221,13 @@ int uav_ln_relu(uav_ctx* ctx, float* z, float* a, float* rstd, const float* gamm
     return ln_fwd_any(cols, z, a, rstd, gamma, beta, rows, as_stream(stream));
 }
 
+int uav_ln_relu_bwd(uav_ctx* ctx, float* d, const float* xhat, const float* rstd, const float* gamma, const float* beta,
+                    int64_t rows, int cols, float* dgamma, float* dbeta, uav_stream stream) {
+    UAV_REQUIRE(ctx && d && xhat && rstd && gamma && beta && dgamma && dbeta && rows > 0, "uav_ln_relu_bwd: bad argument");
+    UAV_REQUIRE(ctx->ws_bytes >= ((size_t)LNB_BLOCKS * 2 * cols + 2 * cols) * sizeof(float), "uav_ln_relu_bwd: workspace too small");
+    return ln_bwd_any(ctx, cols, d, xhat, rstd, gamma, beta, rows, dgamma, dbeta, (float*)ctx->ws, as_stream(stream));
+}
+
 int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out, uav_stream stream) {
     UAV_REQUIRE(ctx && x && out && rows > 0 && cols > 0 && cols <= 1024, "uav_colsum: bad argument");
     UAV_REQUIRE(ctx->ws_bytes >= (size_t)1024 * 1024 * sizeof(float), "uav_colsum: workspace too small");

@@ -39,9 +39,12 @@ SIGNATURES = {
     "uav_ppo_loss_from_y": (I32, [P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, F32, P, P, P, P]),
     "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, P, P, P, P, P, P]),
     "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P]),
+    "uav_clip_adamw": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P, P]),
+    "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),
     "uav_gemm_f32": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P]),
     "uav_colsum": (I32, [P, P, I64, I32, P, P]),
     "uav_ln_relu": (I32, [P, P, P, P, P, P, I64, I32, P]),
+    "uav_ln_relu_bwd": (I32, [P, P, P, P, P, P, I64, I32, P, P, P]),
     "uav_mlp_param_count": (I64, [I32, I32, I32, I32]),
     "uav_mlp_stash_floats": (I64, [I32, I32]),
     "uav_mlp_fwd": (I32, [P, P, P, I64, I32, I32, I32, I32, P, P, P]),

@@ -378,14 +378,46 @@ def env_materialise(state, n_env, cfg, env_index, out=None):
     return out
 
 
-def ln_relu(z, gamma, beta):
-    """relu(LayerNorm(z)) over the rows of z [rows, cols]; z is overwritten with the normalised values."""
+def ln_relu(z, gamma, beta, want_stats=False):
+    """relu(LayerNorm(z)) over the rows of z [rows, cols]; z is overwritten with the normalised values.
+    want_stats: also return rstd [rows] (with z = xhat, what ln_relu_bwd needs)."""
     rows, cols = z.shape
     a = torch.empty_like(z)
     rstd = torch.empty(rows, dtype=F32, device=z.device)
     check(lib().uav_ln_relu(_h(z), _p(z, F32, (rows, cols), "z"), _p(a, F32), _p(rstd, F32), _p(gamma, F32, (cols,), "gamma"),
                             _p(beta, F32, (cols,), "beta"), rows, cols, _stream()), "uav_ln_relu")
-    return a
+    return (a, rstd) if want_stats else a
+
+
+def ln_relu_bwd(d, xhat, rstd, gamma, beta):
+    """d [rows, cols] = dL/da on entry, dL/dz on return (in place); returns (d, dgamma, dbeta)."""
+    rows, cols = d.shape
+    dg = torch.empty(cols, dtype=F32, device=d.device)
+    db = torch.empty(cols, dtype=F32, device=d.device)
+    check(lib().uav_ln_relu_bwd(_h(d), _p(d, F32, (rows, cols), "d"), _p(xhat, F32, (rows, cols), "xhat"),
+                                _p(rstd, F32, (rows,), "rstd"), _p(gamma, F32, (cols,), "gamma"), _p(beta, F32, (cols,), "beta"),
+                                rows, cols, _p(dg, F32), _p(db, F32), _stream()), "uav_ln_relu_bwd")
+    return d, dg, db
+
+
+def smooth_l1(pred, target, beta):
+    """nn.SmoothL1Loss(beta) (mean) forward + backward: returns (loss f64[1] device tensor, dpred [n])."""
+    n = pred.numel()
+    loss = torch.zeros(1, dtype=F64, device=pred.device)
+    dpred = torch.empty(n, dtype=F32, device=pred.device)
+    check(lib().uav_smooth_l1(_h(pred), _p(pred, F32, (n,), "pred"), _p(target, F32, (n,), "target"), n, float(beta),
+                              _p(loss, F64), _p(dpred, F32), _stream()), "uav_smooth_l1")
+    return loss, dpred
+
+
+def clip_adamw(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, max_norm=1.0,
+               gnorm_out=None):
+    """clip_grad_norm_(max_norm) + torch.optim.AdamW step on flat buffers (train_lstm.py:67,91-92)."""
+    n = param.numel()
+    check(lib().uav_clip_adamw(_h(param), _p(param, F32, (n,), "param"), _p(grad, F32, (n,), "grad"),
+                               _p(exp_avg, F32, (n,), "exp_avg"), _p(exp_avg_sq, F32, (n,), "exp_avg_sq"), n, int(step),
+                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), float(max_norm),
+                               _p(gnorm_out, F32, (1,), "gnorm_out"), _stream()), "uav_clip_adamw")
 
 
 def colsum(x, out=None):
