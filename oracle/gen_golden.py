@@ -217,6 +217,17 @@ def gen_curriculum():
                 trace.append([tr.current_radius, tr.explore_bonus, env.current_radius, env.explore_bonus])
         out[f"{name}/seq"] = seq
         out[f"{name}/trace"] = np.asarray(trace, np.float64)
+    # RadiusTracker (train_ppo2.0.py:90-108): the two-smallest-radii history over a synthetic (radius, success) stream
+    _, _, _, train = _refload.load("PPOV2.0")
+    rt = train.RadiusTracker()
+    radii = np.concatenate([np.full(30, 50.0), np.full(25, 42.5), np.full(25, 36.1), np.full(20, 42.5), np.full(30, 30.7)])
+    succ = rng.rand(radii.size) < 0.6
+    hist = []
+    for r, sflag in zip(radii, succ):
+        rt.update(float(r), {"r": float(r)}, bool(sflag))
+        hist.append((rt.radius_history + [np.nan, np.nan])[:2])
+    out["tracker_radii"], out["tracker_success"], out["tracker_history"] = radii, succ, np.asarray(hist, np.float64)
+    out["tracker_counts"] = np.asarray([[k, len(v)] for k, v in sorted(rt.success_data.items())], np.float64)
     np.savez_compressed(os.path.join(OUT, "curriculum.npz"), versions=str(VERS), **out)
 
 

@@ -181,3 +181,82 @@ def test_vectorised_episode_log_matches_bruteforce():
         for row, (n, it, t, a, st, ok, c) in zip(log.rows, want):
             assert np.allclose([row[1], row[3], row[4], row[5], row[6], row[7]], a, rtol=1e-5, atol=1e-4)
             assert row[8] == st and row[2] == int(ok) and np.isclose(row[9], c * 100.0 if ok else 0.0, atol=1e-4)
+
+
+def test_vectorised_trajectory_log_matches_oracle_simulation():
+    """Row N4: the trajectories handed to the NetCDF writer (x, y = agent_pos after every step, concentration at that
+    cell, stop position of successful episodes) from the fused rollout's info columns == a step-by-step oracle
+    simulation with the same forced actions and noise; episodes span rollouts; the two-smallest-radii rule decides
+    what is written; product RadiusTracker == reference trace."""
+    from oracle import traj_oracle as to
+    from oracle.env_oracle import FieldBank, OracleVecEnv
+    from uavppo.episode_log import RadiusTracker, TrajectoryLogger
+    from uavppo.trainer import VecPPOTrainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "curriculum.npz"), allow_pickle=False)
+    rt = RadiusTracker()
+    for k, (r, s) in enumerate(zip(g["tracker_radii"], g["tracker_success"])):
+        rt.update(float(r), {"r": float(r)}, bool(s))
+        assert np.allclose((rt.radius_history + [np.nan, np.nan])[:2], g["tracker_history"][k], equal_nan=True)
+
+    N, T, R = 10, 30, 3
+    bank = FieldBank.from_seed(2 * N, "v2.0", seed=13)
+    tr = VecPPOTrainer(N, T, "lstm", hidden=64, variant="v2.0", device="cuda:0", seed=2, bank=bank.interleaved(),
+                       bank_sources=bank.sources, use_curriculum=False, log_info=True)
+    tr.radius = 60.0
+    tr.reset()
+
+    class Rec:
+        max_episodes = 1000
+
+        def __init__(self):
+            self.calls = []
+
+        def write_episode_data(self, *a):
+            self.calls.append(a)
+
+    rec = Rec()
+    log = TrajectoryLogger(N, rec)
+    ora = OracleVecEnv(N, bank, "v2.0", radius=60.0)
+    ora.reset()
+    rng = np.random.RandomState(3)
+    want, part = [], [([], [], []) for _ in range(N)]
+    for it in range(R):
+        noise = rng.randn(N, T, 2)
+        acts = np.zeros((N, T), np.int32)
+        ended = []
+        for t in range(T):
+            a = []
+            for i, e in enumerate(ora.envs):
+                d = e.source - e.pos
+                a.append((3 if d[0] > 0 else 4) if abs(d[0]) > abs(d[1]) else (1 if d[1] > 0 else 2))
+            acts[:, t] = a
+            pos_before = None
+            obs, rew, done, reached, info, term = None, None, None, None, None, None
+            # step every env by hand to read agent_pos BEFORE the auto-reset
+            for i, e in enumerate(ora.envs):
+                o, r_, d_, s_, inf = e.step(int(a[i]), noise[i, t])
+                part[i][0].append(float(e.pos[0])); part[i][1].append(float(e.pos[1])); part[i][2].append(float(o[2]) * 100.0)
+                if d_:
+                    ended.append((i, t, [np.asarray(v) for v in part[i]], bool(s_)))
+                    part[i] = ([], [], [])
+                    ora.episode[i] += 1
+                    ora._begin(i)
+        ended.sort(key=lambda e_: (e_[0], e_[1]))
+        want += ended
+        tr.collect(forced_act=torch.from_numpy(acts).to("cuda:0"), noise=torch.from_numpy(noise).to("cuda:0"))
+        log.add_rollout(tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy(), tr.radius)
+        tr.iteration += 1
+    succ = [w for w in want if w[3]]
+    assert len(want) >= 6 and len(succ) >= 3 and log.count == len(want)
+    assert len(rec.calls) == len(succ)                      # one radius only: every success is written
+    for call, (i, t, (xs, ys, cs), ok) in zip(rec.calls, succ):
+        ep_idx, steps, x, y, c, sx, sy, sc = call
+        assert steps == len(xs) and np.array_equal(np.asarray(x, np.float32), xs.astype(np.float32))       # positions bit-exact
+        assert np.array_equal(np.asarray(y, np.float32), ys.astype(np.float32))
+        assert np.allclose(c, cs, atol=1e-4) and sx == float(np.float32(xs[-1])) and np.isclose(sc, cs[-1], atol=1e-4)
+    # and the arrays that reach the file follow the writer oracle
+    a = to.writer_arrays(log.count + 1, 1000)
+    for call in rec.calls:
+        to.write_episode(a, *call)
+    seqs, _ = to.load_raw_sequences(a)
+    assert len(seqs) == len(succ)

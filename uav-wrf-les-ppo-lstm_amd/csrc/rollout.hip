@@ -49,7 +49,7 @@ struct RolloutBufs {
     float* cur_obs; float* h; float* c;
     float* obs; int32_t* act; float* rew; float* val; float* logp; float* done; uint8_t* flags; float* keep;
     float* last_val; const int32_t* forced_act; const double* noise; int32_t* nan_count;
-    float* info;                // optional [N][T][6]: the 5 reward parts of environment.py:161-167 + obs[2] of the step
+    float* info;                // optional [N][T][8]: the 5 reward parts of environment.py:161-167, obs[2] and agent_pos of the step
     float* heads;               // optional [N][T][NA+1]: logits | value of the step
     float* stash; float* y;     // optional: BPTT stash [N][T][6H] + y [N][T][H], so PPO epoch 0 skips its forward pass
 };
@@ -387,6 +387,8 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
 #pragma unroll
                         for (int f = 0; f < 5; ++f) trs[2 * RMT * 8 + lane * 8 + f] = (float)so.info[f];
                         trs[2 * RMT * 8 + lane * 8 + 5] = so.obs[2];
+                        trs[2 * RMT * 8 + lane * 8 + 6] = es.px;          // agent_pos after the move (before any auto-reset)
+                        trs[2 * RMT * 8 + lane * 8 + 7] = es.py;
                     }
                     float ob_old[6];
 #pragma unroll
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                         B.keep[row] = tq[6];
                         if (B.info) {
 #pragma unroll
-                            for (int f = 0; f < 6; ++f) B.info[row * 6 + f] = trs[2 * RMT * 8 + lane * 8 + f];
+                            for (int f = 0; f < 8; ++f) B.info[row * 8 + f] = trs[2 * RMT * 8 + lane * 8 + f];
                         }
                     }
                 }

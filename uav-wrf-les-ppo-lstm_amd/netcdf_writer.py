@@ -1,0 +1,70 @@
+"""netcdf_writer.py -- counterpart of the reference's PPOV2.0/netcdf_writer.py:4-114: the episode x step trajectory log that
+hands successful episodes from PPO training to the LSTM stage (loaded back by data_loader.load_raw_sequences).
+
+Same constructor, variables (episode, step, x, y, concentration, is_source, source_concentration, source_x, source_y),
+dtypes, fill values and write_episode_data() semantics (the last step's x / y are overwritten with the source coordinates
+and flagged in is_source).  With netCDF4 installed and a filename not ending in .npz the file is a real NETCDF4 file written
+through the reference's own calls; otherwise (this image has no netCDF4) the arrays are kept in memory and close() writes
+an .npz with the same variable names."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class NetCDFWriter:
+    def __init__(self, filename, grid_size, max_episodes=2000, max_steps=1000):
+        self.filename, self.max_episodes, self.max_steps, self.grid_size = filename, max_episodes, max_steps, grid_size
+        self._nc = None
+        if not str(filename).endswith(".npz"):
+            try:
+                from netCDF4 import Dataset
+                self._nc = Dataset(filename, mode="w", format="NETCDF4")
+            except ImportError:
+                self.filename = str(filename) + ".npz"
+        E, S = max_episodes, max_steps
+        if self._nc is not None:
+            nc = self._nc
+            nc.createDimension("episode", E)
+            nc.createDimension("step", S)
+            nc.GRID_SIZE = grid_size
+            self.episode_var = nc.createVariable("episode", np.int32, ("episode",))
+            self.step_var = nc.createVariable("step", np.int32, ("step",))
+            mk = lambda name, dt, dims, fill: nc.createVariable(name, dt, dims, fill_value=fill, zlib=True)
+            self.x_var = mk("x", np.float32, ("episode", "step"), np.nan)
+            self.y_var = mk("y", np.float32, ("episode", "step"), np.nan)
+            self.conc_var = mk("concentration", np.float32, ("episode", "step"), np.nan)
+            self.source_var = mk("is_source", np.int8, ("episode", "step"), 0)
+            self.source_conc_var = mk("source_concentration", np.float32, ("episode",), np.nan)
+            self.source_x_var = mk("source_x", np.float32, ("episode",), np.nan)
+            self.source_y_var = mk("source_y", np.float32, ("episode",), np.nan)
+        else:
+            self.episode_var = np.zeros(E, np.int32)
+            self.step_var = np.zeros(S, np.int32)
+            self.x_var = np.full((E, S), np.nan, np.float32)
+            self.y_var = np.full((E, S), np.nan, np.float32)
+            self.conc_var = np.full((E, S), np.nan, np.float32)
+            self.source_var = np.zeros((E, S), np.int8)
+            self.source_conc_var = np.full(E, np.nan, np.float32)
+            self.source_x_var = np.full(E, np.nan, np.float32)
+            self.source_y_var = np.full(E, np.nan, np.float32)
+
+    def write_episode_data(self, episode_idx, steps, x, y, conc, source_x, source_y, source_conc):
+        """netcdf_writer.py:87-110 (called for successful episodes only)."""
+        self.x_var[episode_idx, :steps] = x
+        self.y_var[episode_idx, :steps] = y
+        self.conc_var[episode_idx, :steps] = conc
+        self.source_var[episode_idx, steps - 1] = 1
+        self.x_var[episode_idx, steps - 1] = source_x
+        self.y_var[episode_idx, steps - 1] = source_y
+        self.source_conc_var[episode_idx] = source_conc
+        self.source_x_var[episode_idx] = source_x
+        self.source_y_var[episode_idx] = source_y
+
+    def close(self):
+        if self._nc is not None:
+            self._nc.close()
+            return
+        np.savez_compressed(self.filename, episode=self.episode_var, step=self.step_var, x=self.x_var, y=self.y_var,
+                            concentration=self.conc_var, is_source=self.source_var,
+                            source_concentration=self.source_conc_var, source_x=self.source_x_var,
+                            source_y=self.source_y_var, GRID_SIZE=np.int64(self.grid_size))

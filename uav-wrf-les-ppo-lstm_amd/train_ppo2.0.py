@@ -119,7 +119,8 @@ def train_ppo(episodes=2000, csv_path="training_results2_0.csv", model_path="mod
     return model, rows
 
 
-def train_ppo_vectorised(iterations=200, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth"):
+def train_ppo_vectorised(iterations=200, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth",
+                         nc_path=None):
     """NUM_ENVS environments per GPU with the fused kernels; one CSV row per finished episode with the
     reference's 11 columns (uavppo/episode_log.py), in (iteration, env, time) order."""
     from uavppo.episode_log import EpisodeLogger
@@ -128,13 +129,23 @@ def train_ppo_vectorised(iterations=200, csv_path="training_results2_0.csv", mod
                        gae_mode=GAE_MODE, num_minibatches=NUM_MINIBATCHES, log_info=True, gamma=GAMMA, lam=LAMBDA,
                        clip=CLIP_EPSILON, ent_beta=ENTROPY_BETA, lr=LEARNING_RATE, epochs=EPOCHS)
     log = EpisodeLogger(NUM_ENVS)
+    traj = None
+    if nc_path:                      # the reference's trajectory log (train_ppo2.0.py:119-125,216-227,259)
+        from netcdf_writer import NetCDFWriter
+        from uavppo.episode_log import TrajectoryLogger
+        traj = TrajectoryLogger(NUM_ENVS, NetCDFWriter(nc_path, GRID_SIZE, max_episodes=2000, max_steps=MAX_STEPS))
     for it in range(iterations):
         radius = tr.radius
         tr.train_iteration()
-        log.add_rollout(tr.buf["rew"].cpu().numpy(), tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy(), radius)
+        info, flags = tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy()
+        log.add_rollout(tr.buf["rew"].cpu().numpy(), info, flags, radius)
+        if traj is not None:
+            traj.add_rollout(info, flags, radius)
         pl, vl, ent = tr.losses()
         if (it + 1) % 10 == 0:
             print(f"It {it + 1} | episodes {log.count} | radius {tr.radius:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
+    if traj is not None:
+        traj.writer.close()
     _save(tr.policy.state_dict(), log.rows, csv_path, model_path)
     return tr, log.rows
 

@@ -44,3 +44,67 @@ class EpisodeLogger:
         tail = cs[:, -1] - np.where(last[:, None] >= 0, cs[np.arange(N), np.maximum(last, 0)], 0.0)
         self.carry = np.where(last[:, None] >= 0, tail, self.carry + tail)
         self.steps = np.where(last >= 0, T - 1 - last, self.steps + T)
+
+
+class RadiusTracker:
+    """train_ppo2.0.py:90-108: the successful episodes per curriculum radius; `radius_history` keeps the two smallest
+    radii seen so far (sorted ascending, the largest dropped)."""
+
+    def __init__(self):
+        self.radius_history = []
+        self.success_data = {}
+
+    def update(self, current_radius, episode_data, is_success):
+        if is_success:
+            self.success_data.setdefault(current_radius, []).append(episode_data)
+            if current_radius not in self.radius_history:
+                self.radius_history.append(current_radius)
+                self.radius_history.sort()
+                if len(self.radius_history) > 2:
+                    del self.radius_history[-1]
+
+
+class TrajectoryLogger:
+    """Per-episode trajectories of the vectorised trainer for the reference's NetCDF log (train_ppo2.0.py:166-175,200-227):
+    x, y = agent_pos after every step, conc = conc_field at that cell, and for a successful episode the position /
+    concentration it stopped at.  Consumes the fused rollout's info [N,T,8] (columns 5,6,7 = obs[2], x, y) and flags;
+    episodes may span rollouts, so per-env partial trajectories are carried.  Episodes are numbered in (iteration, env,
+    time) order like EpisodeLogger's rows; an episode is written when it succeeded and its radius is one of the tracker's
+    two smallest (the reference's rule at :216-227)."""
+
+    def __init__(self, num_envs, writer=None, tracker=None):
+        self.partial = [([], [], []) for _ in range(num_envs)]
+        self.writer, self.tracker = writer, tracker if tracker is not None else RadiusTracker()
+        self.count = 0
+        self.written = []                # (episode index, steps) of the episodes handed to the writer
+
+    def add_rollout(self, info, flags, radius):
+        info, flags = np.asarray(info), np.asarray(flags)
+        N, T = flags.shape
+        x, y, conc = info[..., 6].astype(np.float64), info[..., 7].astype(np.float64), info[..., 5].astype(np.float64) * 100.0
+        n_idx, t_idx = np.nonzero(flags & 1)
+        start = np.zeros(N, np.int64)
+        for n, t in zip(n_idx, t_idx):
+            px, py, pc = self.partial[n]
+            xs = np.concatenate([px, x[n, start[n]:t + 1]]) if len(px) else x[n, start[n]:t + 1]
+            ys = np.concatenate([py, y[n, start[n]:t + 1]]) if len(py) else y[n, start[n]:t + 1]
+            cs = np.concatenate([pc, conc[n, start[n]:t + 1]]) if len(pc) else conc[n, start[n]:t + 1]
+            self.partial[n] = ([], [], [])
+            start[n] = t + 1
+            success = bool(flags[n, t] & 2)
+            ep = {"steps": len(xs), "x": xs, "y": ys, "conc": cs, "success": success, "current_radius": radius,
+                  "source_x": float(xs[-1]) if success else 0.0, "source_y": float(ys[-1]) if success else 0.0,
+                  "source_conc": float(cs[-1]) if success else 0.0}
+            self.tracker.update(radius, ep, success)
+            if success and radius in self.tracker.radius_history and self.writer is not None \
+                    and self.count < self.writer.max_episodes:
+                self.writer.write_episode_data(self.count, ep["steps"], ep["x"], ep["y"], ep["conc"], ep["source_x"],
+                                               ep["source_y"], ep["source_conc"])
+                self.written.append((self.count, ep["steps"]))
+            self.count += 1
+        for n in range(N):
+            if start[n] < T:
+                px, py, pc = self.partial[n]
+                self.partial[n] = (np.concatenate([px, x[n, start[n]:]]) if len(px) else x[n, start[n]:].copy(),
+                                   np.concatenate([py, y[n, start[n]:]]) if len(py) else y[n, start[n]:].copy(),
+                                   np.concatenate([pc, conc[n, start[n]:]]) if len(pc) else conc[n, start[n]:].copy())

@@ -51,7 +51,7 @@ class VecPPOTrainer:
                     "done": torch.zeros(N, T, **f32), "flags": torch.zeros(N, T, dtype=torch.uint8, device=d),
                     "keep": torch.ones(N, T, **f32)}
         # optional per-step reward parts (for the reference's per-episode CSV columns, train_ppo2.0.py:129-135)
-        self.info = torch.zeros(N, T, 6, **f32) if log_info else None
+        self.info = torch.zeros(N, T, 8, **f32) if log_info else None     # reward parts | obs[2] | agent x, y
         self.adv = torch.zeros(N, T, **f32)
         self.adv_n = torch.zeros(N, T, **f32)
         self.ret = torch.zeros(N, T, **f32)
@@ -164,6 +164,7 @@ class VecPPOTrainer:
             if self.info is not None:
                 self.info[:, t, :5] = st["info"]
                 self.info[:, t, 5] = st["term"][:, 2]
+                self.info[:, t, 6:8] = st["term"][:, :2] * 500.0       # step-wise path: position from the observation
             b["rew"][:, t] = st["rew"]
             b["done"][:, t] = st["done"]
             b["flags"][:, t] = st["flags"]
@@ -201,6 +202,7 @@ class VecPPOTrainer:
             if self.info is not None:
                 self.info[:, t, :5] = tmp["info"]
                 self.info[:, t, 5] = tmp["term"][:, 2]
+                self.info[:, t, 6:8] = tmp["term"][:, :2] * 500.0
             b["rew"][:, t] = tmp["rew"]
             b["done"][:, t] = tmp["done"]
             b["flags"][:, t] = tmp["flags"]
