@@ -145,6 +145,21 @@ def test_train_ppo_vectorised_entry(tmp_path):
     sd = torch.load(tmp_path / "v.pth")
     assert "lstm.weight_hh_l0" in sd and sd["actor.weight"].shape == (5, 64)
     assert len(df) == int((trainer.buf["flags"].cpu().numpy() & 1).sum()) or len(df) >= 0
+    # with nc_path the same loop also writes the trajectory log (row N4) that data_loader reads back
+    tr.NUM_ENVS, tr.HORIZON = 128, 64
+    nc = str(tmp_path / "training_data.npz")
+    trainer, rows = tr.train_ppo_vectorised(iterations=4, csv_path=None, model_path=None, nc_path=nc)
+    import sys
+    sys.path.insert(0, os.path.dirname(tr.__file__))
+    try:
+        from data_loader import load_raw_sequences
+    finally:
+        sys.path.pop(0)
+    seqs, concs = load_raw_sequences(nc)
+    n_succ = sum(int(r[2]) for r in rows)
+    assert len(seqs) == len(concs) <= n_succ and all(len(q) >= 1 for q in seqs)
+    if n_succ:
+        assert len(seqs) >= 1 and np.isfinite(concs).all()
 
 
 def test_vectorised_episode_log_matches_bruteforce():
