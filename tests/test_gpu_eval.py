@@ -178,4 +178,4 @@ def test_vectorised_greedy_evaluation_v21_stop_rule_matches_oracle(ev):
         stopped.append(st)
     assert np.array_equal(got["steps"], np.asarray(steps)), (got["steps"], steps)
     assert np.array_equal(got["stopped_early"], np.asarray(stopped))
-    assert np.isnan(got["peak_pred"][~np.asarray(stopped)]).all()
+    assert np.isnan(got["peak_pred"][~np.asarray(stopped)]).all() and np.isfinite(got["peak_pred"][np.asarray(stopped)]).all()

@@ -216,7 +216,7 @@ def evaluate(policy_probs, env, controller=None, peak_stop=None, window_size_v21
             if t >= window_size_v21:
                 peak, prob = peak_stop((traj / 100.0).to(F32))
                 hit = prob > 0.8
-                peak_pred = torch.where(hit & active & ~done_b, peak.to(torch.float64), peak_pred)
+                peak_pred = torch.where(hit & active, peak.to(torch.float64), peak_pred)       # recorded whenever the LSTM stopped it (:85-87)
                 stop_now |= hit
         ended = active & (done_b | stop_now)
         steps = torch.where(ended, torch.full_like(steps, t), steps)
