@@ -121,3 +121,33 @@ def test_lstm_fullsize_scaling_causality_and_heads(trainer):
     obs2[:, t0:] = torch.rand_like(obs2[:, t0:])
     y2, _, _, _ = ops.lstm_fwd(obs2, b["keep"], h0, c0, *w, want_stash=False)
     assert torch.equal(y2[:, :t0], y[:, :t0]) and not torch.equal(y2[:, t0:], y[:, t0:])
+
+
+def test_fullsize_gradient_split_bf16_equals_exact_f32_kernels(trainer, monkeypatch):
+    """At the full C3 size the whole-batch PPO gradient computed by the default kernels (bf16 matrix pipe, three-piece
+    operand split) equals the one from the exact-f32-MFMA kernels to f32 summation noise: the claim `dtype: f32` of the
+    bench line, checked where the oracle cannot run."""
+    from uavppo import ops
+    b, pol = trainer.buf, trainer.policy
+    n = N * T
+    args = (b["act"].reshape(-1), b["logp"].reshape(-1), trainer.adv_n.reshape(-1), trainer.ret.reshape(-1),
+            b["val"].reshape(-1), 1.0 / n, 0.2, 0.01)
+    grads, sums = [], []
+    for f32 in (False, True):
+        if f32:
+            monkeypatch.setenv("UAV_LSTM_F32_MFMA", "1")
+        else:
+            monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+        heads = pol.heads(b["obs"], b["keep"], trainer.h0, trainer.c0, trainer.work)
+        loss = torch.zeros(4, dtype=torch.float64, device=DEV)
+        dheads = torch.empty(n, 6, device=DEV)
+        dbias = torch.empty(6, device=DEV)
+        ops.ppo_loss_heads(heads, *args, loss, dheads, dbias)
+        g = pol.backward(dheads, trainer.work, dbias).clone()
+        grads.append(g.double())
+        sums.append(loss.clone())
+    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    rel = (grads[0] - grads[1]).norm() / grads[1].norm()
+    assert rel.item() < 2e-5, rel.item()
+    assert torch.allclose(sums[0][1:3], sums[1][1:3], rtol=1e-6)              # value-loss and entropy sums
+    assert abs((sums[0][0] - sums[1][0]).item()) < 1e-4                        # policy-loss sum: ~0 by cancellation at init
