@@ -112,6 +112,10 @@ int uav_clip_adamw(uav_ctx* ctx, float* param, const float* grad, float* exp_avg
  * dpred [n] = d(loss)/d(pred). */
 int uav_smooth_l1(uav_ctx* ctx, const float* pred, const float* target, int64_t n, float beta, double* loss_mean,
                   float* dpred, uav_stream stream);
+/* nn.MSELoss(peak, y_peak) + nn.BCELoss(sigmoid(stop_logit), y_stop), both means (PPOV2.1/train_lstm.py:110-113), forward +
+ * backward: out, target, dout f32 [n][2] = (peak, stop_logit) / (y_peak, y_stop) / d(loss)/d(out); loss_mean f64[1]. */
+int uav_mse_bce(uav_ctx* ctx, const float* out, const float* target, int64_t n, double* loss_mean, float* dout,
+                uav_stream stream);
 
 /* ---- dense f32 building block (exact-f32 MFMA): C[M][N] (+)= op(A)[M][K] * op(B)[K][N] + bias[N].
  * Element (i,k) of op(A) is A[i*sa_m + k*sa_k]; element (k,j) of op(B) is B[k*sb_k + j*sb_n]

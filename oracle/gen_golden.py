@@ -410,9 +410,68 @@ def gen_train_lstm():
     np.savez_compressed(os.path.join(OUT, "train_lstm_v20.npz"), versions=str(VERS), **out)
 
 
+def gen_train_lstm_v21():
+    """N3, V2.1 variant: the reference's TrajectoryDataset (PPOV2.1/train_lstm.py:11-74) on synthetic segments under
+    random.seed(5), and three steps of its loop body (:104-118: MSELoss + BCELoss, clip_grad_norm_(1.0), AdamW(1e-3, wd 1e-4))
+    on the torch modules its PeakAndStopPredictor is made of (the class is local to train(), :84-101)."""
+    import importlib.util
+    import random
+    cfg, envm, model, _ = _refload.load("PPOV2.1")
+    rng = np.random.RandomState(29)
+    W = 20
+    segs = []
+    for e in range(30):                      # 30 episodes, 1-3 sliding-window segments each (same source_pos within one)
+        src = rng.rand(2) * 100.0
+        L = W + int(rng.randint(0, 3))
+        pos = src + (rng.rand(L, 2) - 0.5) * (40.0 if e % 2 else 12.0)
+        conc = np.cumsum(rng.rand(L) * 4.0)
+        for i in range(0, L - W + 1):
+            segs.append({"positions": pos[i:i + W], "concentrations": conc[i:i + W], "source_pos": src, "sigma": 15.0})
+    sys.modules["config"], sys.modules["model"] = cfg, model
+    try:
+        spec = importlib.util.spec_from_file_location("train_lstm_ref21", f"{_refload.REF_ROOT}/PPOV2.1/train_lstm.py")
+        tl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(tl)
+        random.seed(5)
+        ds = tl.TrajectoryDataset(segs, stop_radius=10, window_size=W)      # its constructor imports config again
+    finally:
+        for m in ("config", "model"):
+            sys.modules.pop(m, None)
+    X = np.stack([np.asarray(f, np.float64) for f in ds.features])[:, :, 0]
+    out = {"n_seg": len(segs), "positions": np.stack([s["positions"] for s in segs]),
+           "concentrations": np.stack([s["concentrations"] for s in segs]), "source_pos": np.stack([s["source_pos"] for s in segs]),
+           "X": X, "labels": np.asarray(ds.labels, np.float64), "window": W}
+    torch.manual_seed(31)
+    lstm = torch.nn.LSTM(1, 32, num_layers=1, batch_first=True)
+    fc_peak, fc_stop = torch.nn.Linear(32, 1), torch.nn.Linear(32, 1)
+    params = list(lstm.parameters()) + list(fc_peak.parameters()) + list(fc_stop.parameters())
+    sd = lambda: {**{f"lstm.{k}": v.detach().numpy().copy() for k, v in lstm.state_dict().items()},
+                  "fc_peak.weight": fc_peak.weight.detach().numpy().copy(), "fc_peak.bias": fc_peak.bias.detach().numpy().copy(),
+                  "fc_stop.0.weight": fc_stop.weight.detach().numpy().copy(), "fc_stop.0.bias": fc_stop.bias.detach().numpy().copy()}
+    out.update({f"init/{k}": v for k, v in sd().items()})
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-4)
+    xb = torch.tensor(X[:32], dtype=torch.float32).unsqueeze(-1)
+    yb = torch.tensor(np.asarray(ds.labels)[:32], dtype=torch.float32)
+    losses, gnorms = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        _, (h_n, _) = lstm(xb)
+        h = h_n[-1]
+        peak, stop = fc_peak(h).squeeze(-1), torch.sigmoid(fc_stop(h)).squeeze(-1)
+        loss = torch.nn.MSELoss()(peak, yb[:, 0]) + torch.nn.BCELoss()(stop, yb[:, 1])
+        loss.backward()
+        gnorms.append(float(torch.nn.utils.clip_grad_norm_(params, 1.0)))
+        opt.step()
+        losses.append(float(loss))
+    out.update({f"post/{k}": v for k, v in sd().items()})
+    out.update(losses=np.asarray(losses), gnorms=np.asarray(gnorms))
+    np.savez_compressed(os.path.join(OUT, "train_lstm_v21.npz"), **out)
+    print("train_lstm_v21: samples", len(ds), "losses", losses, "gnorms", gnorms, "pos labels", float(np.asarray(ds.labels)[:, 1].sum()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval", "train_lstm"]
+    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval", "train_lstm", "train_lstm_v21"]
     if "env" in which:
         gen_env()
     if "policy" in which:
@@ -425,3 +484,5 @@ if __name__ == "__main__":
         gen_eval()
     if "train_lstm" in which:
         gen_train_lstm()
+    if "train_lstm_v21" in which:
+        gen_train_lstm_v21()

@@ -10,6 +10,14 @@ PPOV2.0/train_lstm.py).  Only tests/, __graft_entry__.smoke() and bench.py's cpu
                           (train_lstm.py:66-67,86-92), gradients by torch autograd on the restated graph
   ReduceLROnPlateauOracle torch.optim.lr_scheduler.ReduceLROnPlateau(mode='min', factor=0.5, patience=5), train_lstm.py:68-73
 
+  trajectory_dataset      TrajectoryDataset._preprocess, PPOV2.1/train_lstm.py:28-66 (segments grouped by source position, up to
+                          1000 groups drawn with random.sample, first segment of each: a negative sample = first window,
+                          label (conc/100, 0), and a positive sample = last window, label (conc/100, within stop_radius))
+  peak_stop_train_step    the V2.1 loop body, PPOV2.1/train_lstm.py:104-118: LSTM(1->H) h_n -> (peak, sigmoid stop),
+                          MSELoss + BCELoss, clip_grad_norm_(1.0), AdamW(1e-3, wd 1e-4)
+
+Pinning (tests/golden/train_lstm_v21.npz, gen_golden.py train_lstm_v21): the reference's TrajectoryDataset itself under
+random.seed(5); three optimiser steps on the torch modules its (function-local) PeakAndStopPredictor is built from.
 Pinning (tests/golden/train_lstm_v20.npz, oracle/gen_golden.py train_lstm): the reference's own SequenceDataset on synthetic
 sequences, and three optimiser steps of its model / criterion / AdamW / clipping run in eval mode (dropout cannot be given
 masks in the reference: with dropout on, the restatement is pinned by its structure only).
@@ -76,6 +84,54 @@ def train_step(params, opt, x, y, masks=None, beta=2.0, max_norm=1.0):
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
     out = predictor_forward(leaf, x, masks)
     loss = F.smooth_l1_loss(out, y, beta=beta)
+    loss.backward()
+    grads = {k: leaf[k].grad for k in params}
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()
+    coef = min(1.0, max_norm / (total + 1e-6))
+    grads = {k: g * coef for k, g in grads.items()}
+    with torch.no_grad():
+        opt.step(params, grads)
+    return float(loss), total
+
+
+def trajectory_dataset(segments, stop_radius=10, window_size=20, rng=None):
+    """segments: dicts with positions [w, 2], concentrations [w], source_pos [2].  rng: a random.Random (the reference uses the
+    global `random` module).  Returns (features [n, window, 1] f64, labels [n, 2] f64)."""
+    import random as _random
+    rng = rng or _random
+    groups = {}
+    for seg in segments:
+        groups.setdefault(tuple(seg["source_pos"]), []).append(seg)
+    chosen = rng.sample(list(groups.values()), min(1000, len(groups)))
+    feats, labels = [], []
+    for segs in chosen:
+        seg = segs[0]
+        conc = np.asarray(seg["concentrations"])
+        if len(conc) < window_size:
+            continue
+        feats.append(conc[:window_size].reshape(-1, 1) / 100.0)
+        labels.append([conc[window_size - 1] / 100.0, 0.0])
+        feats.append(conc[-window_size:].reshape(-1, 1) / 100.0)
+        near = np.linalg.norm(np.asarray(seg["positions"][-1]) - np.asarray(seg["source_pos"])) <= stop_radius
+        labels.append([conc[-1] / 100.0, 1.0 if near else 0.0])
+    return (np.stack(feats) if feats else np.zeros((0, window_size, 1))), np.asarray(labels, np.float64).reshape(-1, 2)
+
+
+def peak_stop_forward(p, x):
+    B, H = x.shape[0], p["lstm.weight_hh_l0"].shape[1]
+    z = torch.zeros(B, H, dtype=x.dtype)
+    _, hn, _ = po.lstm_layer_forward(x.transpose(0, 1), z, z, p["lstm.weight_ih_l0"], p["lstm.weight_hh_l0"],
+                                     p["lstm.bias_ih_l0"], p["lstm.bias_hh_l0"], None)
+    peak = F.linear(hn, p["fc_peak.weight"], p["fc_peak.bias"]).squeeze(-1)
+    stop = torch.sigmoid(F.linear(hn, p["fc_stop.0.weight"], p["fc_stop.0.bias"])).squeeze(-1)
+    return peak, stop
+
+
+def peak_stop_train_step(params, opt, x, y, max_norm=1.0):
+    """x [B, T, 1], y [B, 2] = (peak, stop) labels.  One step in place on `params`; returns (loss, grad_norm)."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    peak, stop = peak_stop_forward(leaf, x)
+    loss = F.mse_loss(peak, y[:, 0]) + F.binary_cross_entropy(stop, y[:, 1])
     loss.backward()
     grads = {k: leaf[k].grad for k in params}
     total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).item()

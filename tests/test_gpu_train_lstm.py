@@ -99,3 +99,77 @@ def test_training_run_fits_a_synthetic_relation(tl):
     ora = lt.ReduceLROnPlateauOracle(3e-4)
     for m_ in [5, 4, 3, 3, 3, 3, 3, 3, 3, 3, 2.9999, 2.9999, 2.9999, 2.9999, 2.9999, 2.9999, 2.9999, 1.0]:
         assert sch.step(m_) == ora.step(m_)
+
+
+# ---- V2.1 variant (PPOV2.1/train_lstm.py)
+GOLD21 = os.path.join(os.path.dirname(__file__), "golden", "train_lstm_v21.npz")
+
+
+def segments_of(g):
+    return [{"positions": g["positions"][i], "concentrations": g["concentrations"][i], "source_pos": g["source_pos"][i]}
+            for i in range(int(g["n_seg"]))]
+
+
+def test_trajectory_dataset_matches_reference_golden(tl):
+    import random
+    g = np.load(GOLD21, allow_pickle=False)
+    ds = tl.TrajectoryDataset(segments_of(g), stop_radius=10, window_size=int(g["window"]), rng=random.Random(5))
+    assert len(ds) == 60 and np.array_equal(np.stack(ds.features)[:, :, 0], g["X"]) and np.array_equal(ds.labels, g["labels"])
+    f, l = ds[1]
+    assert f.shape == (20, 1) and l.shape == (2,) and f.dtype == torch.float32
+
+
+def test_peak_stop_three_steps_match_the_reference_golden(tl):
+    from evaluate_with_lstm import PeakAndStopPredictor
+    g = np.load(GOLD21, allow_pickle=False)
+    model = PeakAndStopPredictor(device=DEV)
+    model.load_state_dict({k[5:]: g[k] for k in g.files if k.startswith("init/")})
+    tr = tl.PeakStopTrainer(model)
+    x = torch.tensor(g["X"][:32], dtype=torch.float32, device=DEV)[:, :, None].contiguous()
+    y = torch.tensor(g["labels"][:32], dtype=torch.float32, device=DEV)
+    for k in range(3):
+        loss = tr.train_step(x, y)
+        assert np.isclose(float(loss.item()), g["losses"][k], rtol=2e-5), (k, float(loss.item()), g["losses"][k])
+        assert np.isclose(float(tr.gnorm.item()), g["gnorms"][k], rtol=2e-4)
+    for k, v in model.state_dict().items():
+        assert np.allclose(v.cpu().numpy(), g["post/" + k], rtol=2e-3, atol=3e-6), k
+
+
+def test_mse_bce_matches_torch_including_saturated_logits():
+    from uavppo import ops
+    torch.manual_seed(3)
+    out = torch.randn(777, 2, device=DEV) * 3
+    out[:4, 1] = torch.tensor([60.0, -60.0, 120.0, -120.0], device=DEV)          # sigmoid saturates: BCELoss clamps log at -100
+    tgt = torch.stack([torch.randn(777, device=DEV), (torch.rand(777, device=DEV) > 0.5).float()], 1)
+    loss, dout = ops.mse_bce(out, tgt)
+    o = out.detach().cpu().double().requires_grad_(True)
+    want = torch.nn.functional.mse_loss(o[:, 0], tgt[:, 0].cpu().double()) + \
+        torch.nn.functional.binary_cross_entropy(torch.sigmoid(o[:, 1]).float().double(), tgt[:, 1].cpu().double())
+    assert np.isclose(float(loss.item()), float(want), rtol=1e-5)
+    gz = torch.autograd.grad(torch.nn.functional.mse_loss(o[:, 0], tgt[:, 0].cpu().double()) +
+                             torch.nn.functional.binary_cross_entropy_with_logits(o[:, 1], tgt[:, 1].cpu().double()), o)[0]
+    assert torch.allclose(dout.cpu().double()[4:], gz[4:], rtol=1e-4, atol=1e-8)
+
+
+def test_train_peak_and_stop_learns_the_stop_label(tl, tmp_path):
+    """Separable toy data: stop = 1 exactly when the window's last concentration is high.  Loss must fall and the
+    saved best checkpoint must load back into the evaluation-side predictor."""
+    import random
+    from evaluate_with_lstm import PeakAndStopPredictor
+    rng = np.random.RandomState(0)
+    segs = []
+    for e in range(96):
+        src = rng.rand(2) * 100
+        near = e % 2 == 0
+        conc = np.linspace(1.0, 95.0 if near else 25.0, 32) + rng.rand(32)       # first window low, last window high iff near
+        pos = np.tile(src + (2.0 if near else 30.0), (32, 1))
+        segs.append({"positions": pos, "concentrations": conc, "source_pos": src, "sigma": 15.0})
+    random.seed(1)
+    model, hist = tl.train_peak_and_stop(segs, epochs=120, batch_size=64, device=DEV, seed=2, model_dir=str(tmp_path))
+    assert hist[-1] < 0.5 * hist[0]
+    m2 = PeakAndStopPredictor(device=DEV)
+    m2.load_state_dict(torch.load(os.path.join(str(tmp_path), "best_peak_and_stop.pth")))
+    x = torch.tensor(np.stack([s["concentrations"][-20:] for s in segs]) / 100.0, dtype=torch.float32, device=DEV)
+    peak, stop = m2(x)
+    assert float(stop[0::2].mean()) > float(stop[1::2].mean()) + 0.3
+    assert abs(float(peak[0::2].mean()) - 0.955) < 0.15                           # the peak head regresses the last concentration / 100

@@ -57,3 +57,33 @@ def test_dropout_masks_of_ones_are_eval_mode(gold):
     ones = {"l0": torch.ones(5, x.shape[1], H), "l1": torch.ones(5, x.shape[1], H), "head": torch.ones(5, 64)}
     with torch.no_grad():
         assert torch.equal(lt.predictor_forward(params, x, None), lt.predictor_forward(params, x, ones))
+
+
+# ---- V2.1 variant (PPOV2.1/train_lstm.py): TrajectoryDataset + MSE/BCE loop body
+GOLD21 = os.path.join(os.path.dirname(__file__), "golden", "train_lstm_v21.npz")
+
+
+def segments_of(g):
+    return [{"positions": g["positions"][i], "concentrations": g["concentrations"][i], "source_pos": g["source_pos"][i]}
+            for i in range(int(g["n_seg"]))]
+
+
+def test_trajectory_dataset_matches_reference():
+    import random
+    g = np.load(GOLD21, allow_pickle=False)
+    X, labels = lt.trajectory_dataset(segments_of(g), stop_radius=10, window_size=int(g["window"]), rng=random.Random(5))
+    assert X.shape[0] == 60 and np.array_equal(X[:, :, 0], g["X"]) and np.array_equal(labels, g["labels"])
+    assert 0 < labels[:, 1].sum() < 30 and (labels[0::2, 1] == 0).all()       # negatives first of each pair; both stop labels occur
+
+
+def test_peak_stop_three_steps_match_reference():
+    g = np.load(GOLD21, allow_pickle=False)
+    params = {k[5:]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith("init/")}
+    opt = lt.AdamWState(params, lr=1e-3, weight_decay=1e-4)
+    x = torch.tensor(g["X"][:32], dtype=torch.float32)[:, :, None]
+    y = torch.tensor(g["labels"][:32], dtype=torch.float32)
+    for k in range(3):
+        loss, gn = lt.peak_stop_train_step(params, opt, x, y)
+        assert np.isclose(loss, g["losses"][k], rtol=2e-6) and np.isclose(gn, g["gnorms"][k], rtol=2e-5)
+    for k, v in params.items():
+        assert np.allclose(v.numpy(), g["post/" + k], rtol=1e-4, atol=2e-7), k

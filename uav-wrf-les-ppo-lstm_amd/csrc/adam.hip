@@ -115,3 +115,31 @@ extern "C" int uav_smooth_l1(uav_ctx* ctx, const float* pred, const float* targe
     UAV_LAUNCH_CHECK();
     return 0;
 }
+
+// PPOV2.1/train_lstm.py:110-113: loss = MSELoss(peak, y_peak) + BCELoss(sigmoid(stop_logit), y_stop), both means.
+// out [n][2] = (peak, stop_logit); target [n][2]; dout [n][2] = d(loss)/d(out).  BCELoss clamps its logs at -100 (torch).
+__global__ __launch_bounds__(256) void mse_bce_kernel(const float* __restrict__ out, const float* __restrict__ target, int64_t n,
+                                                      double* __restrict__ loss_mean, float* __restrict__ dout) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const float d = out[2 * i] - target[2 * i];
+        const float z = out[2 * i + 1], yb = target[2 * i + 1];
+        const float p = 1.0f / (1.0f + expf(-z));
+        const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);
+        s += (double)d * d - ((double)yb * lp + (1.0 - (double)yb) * lq);
+        dout[2 * i] = 2.0f * d * inv_n;
+        dout[2 * i + 1] = (p - yb) * inv_n;
+    }
+    const double r = block256_sum(s, sm);
+    if (threadIdx.x == 0) loss_mean[0] = r / (double)n;
+}
+
+extern "C" int uav_mse_bce(uav_ctx* ctx, const float* out, const float* target, int64_t n, double* loss_mean, float* dout,
+                           uav_stream stream) {
+    UAV_REQUIRE(ctx && out && target && loss_mean && dout && n > 0, "uav_mse_bce: bad argument");
+    hipLaunchKernelGGL(mse_bce_kernel, dim3(1), dim3(256), 0, as_stream(stream), out, target, n, loss_mean, dout);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}

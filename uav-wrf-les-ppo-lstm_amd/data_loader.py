@@ -1,5 +1,5 @@
-"""data_loader.py -- counterpart of the reference's PPOV2.0/data_loader.py:5-22: concentration sequences and source
-concentrations of the logged episodes.  Reads the reference's netCDF file when netCDF4 is installed, or an .npz with the
+"""data_loader.py -- counterpart of the reference's PPOV2.0/data_loader.py:5-22 (concentration sequences and source
+concentrations of the logged episodes) and of load_trajectory_segments, PPOV2.1/model.py:68-90 (sliding windows).  Reads the reference's netCDF file when netCDF4 is installed, or an .npz with the
 same variable names (x, concentration, source_concentration; NaN = unused step) otherwise."""
 import numpy as np
 
@@ -24,3 +24,31 @@ def load_raw_sequences(nc_path):
         sequences.append(conc[ep, :steps[-1] + 1].tolist())
         source_concs.append(src[ep])
     return sequences, np.array(source_concs)
+
+
+def load_trajectory_segments(nc_path, tail_steps=60, window_size=20):
+    """PPOV2.1/model.py:68-90: every length-`window_size` sliding window of every episode with at least that many logged
+    steps (tail_steps is accepted and unused, as in the reference)."""
+    if str(nc_path).endswith(".npz"):
+        d = np.load(nc_path)
+        get = lambda k: d[k] if k in d.files else None
+    else:
+        from netCDF4 import Dataset
+        with Dataset(nc_path, "r") as nc:
+            held = {k: np.ma.filled(nc[k][:], np.nan) for k in ("x", "y", "concentration", "source_x", "source_y", "gaussian_sigma")
+                    if k in nc.variables}
+        get = held.get
+    x, y, conc, sx, sy, sig = (get(k) for k in ("x", "y", "concentration", "source_x", "source_y", "gaussian_sigma"))
+    segments = []
+    for ep in range(x.shape[0]):
+        steps = np.where(~np.isnan(x[ep]))[0]
+        if len(steps) < window_size:
+            continue
+        xs, ys, cs = x[ep, steps], y[ep, steps], conc[ep, steps]
+        source_pos = np.array([sx[ep], sy[ep]])
+        sigma = sig[ep] if sig is not None else 15.0
+        for i in range(0, len(steps) - window_size + 1):
+            segments.append({"positions": np.column_stack((xs[i:i + window_size], ys[i:i + window_size])),
+                             "concentrations": cs[i:i + window_size], "source_pos": source_pos, "sigma": sigma})
+    print(f"Generated {len(segments)} segments (window_size={window_size})")
+    return segments

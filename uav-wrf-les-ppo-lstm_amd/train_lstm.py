@@ -7,6 +7,10 @@ uav_lstm_bwd / uav_lstm_wgrad (one call per layer, dx handed down), the head thr
 the loss through uav_smooth_l1 and the update through uav_clip_adamw on one flat parameter buffer.  Dropout (0.3
 between LSTM layers, 0.1 in the head) is applied as explicit masks drawn from a torch generator on the device, so a
 training step is reproducible and comparable with the oracle given the same masks.  No CPU fallback.
+
+The PPOV2.1 variant of the same stage (PPOV2.1/train_lstm.py) is here too: TrajectoryDataset (:11-74), and train() (:76-125)
+as train_peak_and_stop(): PeakAndStopPredictor, MSELoss + BCELoss (uav_mse_bce), clip, AdamW(1e-3, wd 1e-4), plateau
+scheduler (factor 0.1, patience 5), 100 epochs, batch 64, best checkpoint kept.
 """
 from __future__ import annotations
 
@@ -16,7 +20,7 @@ import numpy as np
 import torch
 
 from config import TRAINING_SIZE
-from evaluate_with_lstm import ConcentrationThresholdPredictor
+from evaluate_with_lstm import ConcentrationThresholdPredictor, PeakAndStopPredictor
 from uavppo import ops
 
 F32 = torch.float32
@@ -185,6 +189,123 @@ def train_lstm(sequences=None, source_concs=None, epochs=150, batch_size=64, dev
         os.makedirs(model_dir, exist_ok=True)
         torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(model_dir, "lstm_threshold_predictor.pth"))
         np.save(os.path.join(model_dir, "scaler_params.npy"), ds.data_min_)        # as the reference does (:98)
+    return model, history
+
+
+class TrajectoryDataset:
+    """PPOV2.1/train_lstm.py:11-74.  One negative (first window, stop label 0) and one positive (last window, stop label =
+    final position within stop_radius of the source) sample from the first segment of up to 1000 randomly chosen episodes;
+    concentrations / 100.  Episodes are drawn with the `random` module, as in the reference (seed it for repeatability)."""
+
+    def __init__(self, segments, stop_radius=10, window_size=20, rng=None):
+        import random
+        from config import GRID_SIZE
+        self.grid_size, self.stop_radius, self.window_size, self.segments = GRID_SIZE, stop_radius, window_size, segments
+        self.max_sigma = max([seg.get("sigma", 15.0) for seg in segments]) if segments else 50.0
+        self.max_peak = max([seg["concentrations"][-1] for seg in segments]) if segments else 100.0
+        rng = rng or random
+        episodes = {}
+        for seg in segments:
+            episodes.setdefault(tuple(seg["source_pos"]), []).append(seg)
+        feats, labels = [], []
+        for segs in rng.sample(list(episodes.values()), min(1000, len(episodes))):
+            seg = segs[0]
+            conc = np.asarray(seg["concentrations"])
+            if len(conc) < window_size:
+                continue
+            feats.append(conc[:window_size].reshape(-1, 1) / 100.0)
+            labels.append([conc[window_size - 1] / 100.0, 0.0])
+            feats.append(conc[-window_size:].reshape(-1, 1) / 100.0)
+            near = np.linalg.norm(np.asarray(seg["positions"][-1]) - np.asarray(seg["source_pos"])) <= stop_radius
+            labels.append([conc[-1] / 100.0, 1.0 if near else 0.0])
+        self.features, self.labels = feats, np.array(labels)
+        print(f"samples collected: {len(labels)} (positive + negative)")
+
+    def __len__(self):
+        return len(self.labels)
+
+    def __getitem__(self, idx):
+        return torch.as_tensor(self.features[idx], dtype=F32), torch.as_tensor(self.labels[idx], dtype=F32)
+
+
+class PeakStopTrainer:
+    """Forward + backward + AdamW for a PeakAndStopPredictor (single-layer LSTM, two linear heads sharing one GEMM)."""
+
+    def __init__(self, model: PeakAndStopPredictor, lr=1e-3, weight_decay=1e-4):
+        self.model, self.lr, self.wd, self.step_count = model, lr, weight_decay, 0
+        dev = model.device
+        names = [(f"lstm.{k}", v) for k, v in model.lstm.p.items()] + [("heads_w", model.heads_w), ("heads_b", model.heads_b)]
+        total = sum(v.numel() for _, v in names)
+        self.flat = torch.empty(total, dtype=F32, device=dev)
+        self.grad = torch.zeros(total, dtype=F32, device=dev)
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.g, o = {}, 0
+        for name, v in names:
+            n = v.numel()
+            self.flat[o:o + n].copy_(v.reshape(-1))
+            view = self.flat[o:o + n].view(v.shape)
+            if name.startswith("lstm."):
+                model.lstm.p[name[5:]] = view
+            else:
+                setattr(model, name, view)
+            self.g[name] = self.grad[o:o + n].view(v.shape)
+            o += n
+        self.gnorm = torch.zeros(1, dtype=F32, device=dev)
+
+    def train_step(self, x, y, max_norm=1.0):
+        """x [B, T, 1], y [B, 2] = (peak, stop) labels on the device.  Returns the loss (f64[1] tensor)."""
+        m, p, g = self.model, self.model.lstm.p, self.g
+        B, T, _ = x.shape
+        H = m.lstm.hidden_size
+        z0 = torch.zeros(B, H, dtype=F32, device=x.device)
+        x = x.contiguous()
+        yl, _, _, st = ops.lstm_fwd(x, None, z0, z0, p["weight_ih_l0"], p["weight_hh_l0"], p["bias_ih_l0"], p["bias_hh_l0"])
+        h = yl[:, T - 1].contiguous()
+        out = ops.gemm(h, m.heads_w, trans_b=True, bias=m.heads_b)              # [B, 2] = (peak, stop logit)
+        loss, dout = ops.mse_bce(out, y.contiguous())
+        ops.gemm(dout, h, trans_a=True, out=g["heads_w"])
+        ops.colsum(dout, out=g["heads_b"])
+        dy = torch.zeros(B, T, H, dtype=F32, device=x.device)
+        dy[:, T - 1] = ops.gemm(dout, m.heads_w)
+        ops.lstm_bwd(x, None, st, p["weight_ih_l0"], p["weight_hh_l0"], yl, z0, dy=dy, need_dx=False,
+                     dw_ih=g["lstm.weight_ih_l0"], dw_hh=g["lstm.weight_hh_l0"], db=g["lstm.bias_ih_l0"], want_dstate=False)
+        g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
+        self.step_count += 1
+        ops.clip_adamw(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, weight_decay=self.wd,
+                       max_norm=max_norm, gnorm_out=self.gnorm)
+        return loss
+
+
+def train_peak_and_stop(segments=None, epochs=100, batch_size=64, device="cuda", seed=0, nc_path="training_data.nc",
+                        model_dir="model"):
+    """train() of PPOV2.1/train_lstm.py:76-125.  segments default to load_trajectory_segments(nc_path, tail_steps=60)."""
+    if segments is None:
+        from data_loader import load_trajectory_segments
+        segments = load_trajectory_segments(nc_path, tail_steps=60)
+    ds = TrajectoryDataset(segments, window_size=20)
+    model = PeakAndStopPredictor(input_dim=1, device=device, seed=seed)
+    tr = PeakStopTrainer(model, lr=1e-3, weight_decay=1e-4)
+    sched = ReduceLROnPlateau(1e-3, factor=0.1, patience=5)                       # torch's defaults, as the reference (:104)
+    X = torch.as_tensor(np.stack(ds.features), dtype=F32).to(device)
+    Y = torch.as_tensor(ds.labels, dtype=F32).to(device)
+    perm_gen = torch.Generator().manual_seed(seed)
+    best, history = float("inf"), []
+    for epoch in range(epochs):
+        order = torch.randperm(len(ds), generator=perm_gen).to(device)
+        total, nb = 0.0, 0
+        for s in range(0, len(ds), batch_size):
+            idx = order[s:s + batch_size]
+            total += float(tr.train_step(X[idx].contiguous(), Y[idx].contiguous()).item())
+            nb += 1
+        avg = total / max(nb, 1)
+        tr.lr = sched.step(avg)
+        history.append(avg)
+        if avg < best:
+            best = avg
+            if model_dir:
+                os.makedirs(model_dir, exist_ok=True)
+                torch.save({k: v.cpu() for k, v in model.state_dict().items()}, os.path.join(model_dir, "best_peak_and_stop.pth"))
+        print(f"Epoch {epoch + 1:03d} | Loss: {avg:.4f} | LR: {tr.lr:.2e}")
     return model, history
 
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P]),
     "uav_clip_adamw": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),
+    "uav_mse_bce": (I32, [P, P, P, I64, P, P, P]),
     "uav_gemm_f32": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P]),
     "uav_colsum": (I32, [P, P, I64, I32, P, P]),
     "uav_ln_relu": (I32, [P, P, P, P, P, P, I64, I32, P]),

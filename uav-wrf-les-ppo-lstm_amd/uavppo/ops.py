@@ -410,6 +410,16 @@ def smooth_l1(pred, target, beta):
     return loss, dpred
 
 
+def mse_bce(out, target):
+    """MSE on column 0 + BCE(sigmoid(column 1)) (PPOV2.1/train_lstm.py:110-113): returns (loss f64[1], dout [n, 2])."""
+    n = out.shape[0]
+    loss = torch.zeros(1, dtype=F64, device=out.device)
+    dout = torch.empty(n, 2, dtype=F32, device=out.device)
+    check(lib().uav_mse_bce(_h(out), _p(out, F32, (n, 2), "out"), _p(target, F32, (n, 2), "target"), n, _p(loss, F64),
+                            _p(dout, F32), _stream()), "uav_mse_bce")
+    return loss, dout
+
+
 def clip_adamw(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, max_norm=1.0,
                gnorm_out=None):
     """clip_grad_norm_(max_norm) + torch.optim.AdamW step on flat buffers (train_lstm.py:67,91-92)."""
