@@ -233,9 +233,10 @@ int uav_env_materialise(uav_ctx* ctx, const void* state, int n_env, const uav_en
  * after the last step, for UAV_GAE_STANDARD).  forced_act i32 [N][T] / noise f64 [N][T][2] are
  * NULL outside parity tests.  stash [N][T][6H] + y_out [N][T][H] (both or neither): the BPTT stash of
  * uav_lstm_fwd for exactly this rollout, so the first PPO epoch (same parameters) skips its forward.
- * info (or NULL) f32 [N][T][8]: the five reward parts of environment.py:161-167 (concentration, explore,
- * move, tke, boundary), obs[2] of the step and agent_pos (x, y) after the move -- what train_ppo2.0.py:166-183,203
- * accumulates / logs per episode.
+ * info (or NULL) f32 [N][T][10]: the five reward parts of environment.py:161-167 (concentration, explore,
+ * move, tke, boundary), obs[2] of the step, agent_pos (x, y) after the move -- what train_ppo2.0.py:166-183,203
+ * accumulates / logs per episode -- and source_pos (x, y) of the episode the step belongs to (gaussian_params mu_x / mu_y,
+ * which PPOV2.1/train_ppo2.0.py:222-232 logs for every episode).
  * heads (or NULL) f32 [N][T][n_act+1]: logits | value of every step (with y_out: epoch 0 of the update needs no
  * forward pass and no head product). */
 int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg /*host*/,

@@ -5,6 +5,8 @@ __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
                                   as plain arrays (NaN / 0 fills; the last step's x, y replaced by the source coordinates)
   load_raw_sequences              PPOV2.0/data_loader.py:5-22 on those arrays
   RadiusTrackerOracle             train_ppo2.0.py:90-108
+  (sigma=, peak=)                 PPOV2.1's writer (model.py:355-423): gaussian_sigma / peak_concentration per episode
+  load_trajectory_segments        PPOV2.1/model.py:68-90 on those arrays (every sliding window of every long-enough episode)
 
 Pinning: RadiusTracker against the reference's own class (tests/golden/curriculum.npz gets a `tracker_*` trace from
 oracle/gen_golden.py curriculum).  The writer / loader are PARITY UNPINNED: they need netCDF4, which this image lacks, so
@@ -18,10 +20,11 @@ def writer_arrays(max_episodes, max_steps):
     return {"x": np.full((E, S), np.nan, np.float32), "y": np.full((E, S), np.nan, np.float32),
             "concentration": np.full((E, S), np.nan, np.float32), "is_source": np.zeros((E, S), np.int8),
             "source_concentration": np.full(E, np.nan, np.float32), "source_x": np.full(E, np.nan, np.float32),
-            "source_y": np.full(E, np.nan, np.float32)}
+            "source_y": np.full(E, np.nan, np.float32), "gaussian_sigma": np.full(E, np.nan, np.float32),
+            "peak_concentration": np.full(E, np.nan, np.float32)}
 
 
-def write_episode(a, episode_idx, steps, x, y, conc, source_x, source_y, source_conc):
+def write_episode(a, episode_idx, steps, x, y, conc, source_x, source_y, source_conc, sigma=None, peak=None):
     a["x"][episode_idx, :steps] = x
     a["y"][episode_idx, :steps] = y
     a["concentration"][episode_idx, :steps] = conc
@@ -31,6 +34,24 @@ def write_episode(a, episode_idx, steps, x, y, conc, source_x, source_y, source_
     a["source_concentration"][episode_idx] = source_conc
     a["source_x"][episode_idx] = source_x
     a["source_y"][episode_idx] = source_y
+    if sigma is not None:
+        a["gaussian_sigma"][episode_idx] = sigma
+    if peak is not None:
+        a["peak_concentration"][episode_idx] = peak
+
+
+def load_trajectory_segments(a, window_size=20):
+    segs = []
+    for ep in range(a["x"].shape[0]):
+        valid = np.where(~np.isnan(a["x"][ep]))[0]
+        if len(valid) < window_size:
+            continue
+        xs, ys, cs = a["x"][ep, valid], a["y"][ep, valid], a["concentration"][ep, valid]
+        src = np.array([a["source_x"][ep], a["source_y"][ep]])
+        for i in range(0, len(valid) - window_size + 1):
+            segs.append({"positions": np.column_stack((xs[i:i + window_size], ys[i:i + window_size])),
+                         "concentrations": cs[i:i + window_size], "source_pos": src, "sigma": a["gaussian_sigma"][ep]})
+    return segs
 
 
 def load_raw_sequences(a):

@@ -229,8 +229,13 @@ def test_vectorised_trajectory_log_matches_oracle_simulation():
         def write_episode_data(self, *a):
             self.calls.append(a)
 
-    rec = Rec()
+    class Rec21(Rec):
+        def write_episode_data(self, *a, **kw):
+            self.calls.append((a, kw))
+
+    rec, rec21 = Rec(), Rec21()
     log = TrajectoryLogger(N, rec)
+    log21 = TrajectoryLogger(N, rec21, gaussian=(15.0, 100.0))     # PPOV2.1's script: every episode, true source position
     ora = OracleVecEnv(N, bank, "v2.0", radius=60.0)
     ora.reset()
     rng = np.random.RandomState(3)
@@ -252,7 +257,7 @@ def test_vectorised_trajectory_log_matches_oracle_simulation():
                 o, r_, d_, s_, inf = e.step(int(a[i]), noise[i, t])
                 part[i][0].append(float(e.pos[0])); part[i][1].append(float(e.pos[1])); part[i][2].append(float(o[2]) * 100.0)
                 if d_:
-                    ended.append((i, t, [np.asarray(v) for v in part[i]], bool(s_)))
+                    ended.append((i, t, [np.asarray(v) for v in part[i]], bool(s_), np.array(e.source, np.float64)))
                     part[i] = ([], [], [])
                     ora.episode[i] += 1
                     ora._begin(i)
@@ -260,15 +265,25 @@ def test_vectorised_trajectory_log_matches_oracle_simulation():
         want += ended
         tr.collect(forced_act=torch.from_numpy(acts).to("cuda:0"), noise=torch.from_numpy(noise).to("cuda:0"))
         log.add_rollout(tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy(), tr.radius)
+        log21.add_rollout(tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy(), tr.radius)
         tr.iteration += 1
     succ = [w for w in want if w[3]]
     assert len(want) >= 6 and len(succ) >= 3 and log.count == len(want)
     assert len(rec.calls) == len(succ)                      # one radius only: every success is written
-    for call, (i, t, (xs, ys, cs), ok) in zip(rec.calls, succ):
+    for call, (i, t, (xs, ys, cs), ok, _src) in zip(rec.calls, succ):
         ep_idx, steps, x, y, c, sx, sy, sc = call
         assert steps == len(xs) and np.array_equal(np.asarray(x, np.float32), xs.astype(np.float32))       # positions bit-exact
         assert np.array_equal(np.asarray(y, np.float32), ys.astype(np.float32))
         assert np.allclose(c, cs, atol=1e-4) and sx == float(np.float32(xs[-1])) and np.isclose(sc, cs[-1], atol=1e-4)
+    # PPOV2.1 form: the last write of EVERY episode carries the true source position, peak as source_conc, sigma and peak
+    last = {}
+    for a_, kw in rec21.calls:
+        last[a_[0]] = (a_, kw)
+    assert len(last) == len(want) and len(rec21.calls) == len(want) + len(succ) and log21.written == [(k, w[2][0].size) for k, w in enumerate(want)]
+    for k, (i, t, (xs, ys, cs), ok, src) in enumerate(want):
+        (ep_idx, steps, x, y, c, sx, sy, sc), kw = last[k]
+        assert steps == len(xs) and np.array_equal(np.asarray(x, np.float32), xs.astype(np.float32))
+        assert (sx, sy) == (float(np.float32(src[0])), float(np.float32(src[1]))) and sc == 100.0 and kw == {"sigma": 15.0, "peak": 100.0}
     # and the arrays that reach the file follow the writer oracle
     a = to.writer_arrays(log.count + 1, 1000)
     for call in rec.calls:

@@ -66,3 +66,32 @@ def test_product_writer_and_loader_agree_with_the_oracle(tmp_path):
     seqs, concs = load_raw_sequences(path)
     oseqs, oconcs = to.load_raw_sequences(a)
     assert len(seqs) == 2 and all(np.allclose(s, o) for s, o in zip(seqs, oseqs)) and np.allclose(concs, oconcs)
+
+
+def test_v21_writer_fields_and_segment_loader(tmp_path):
+    """PPOV2.1's extra per-episode variables and load_trajectory_segments (model.py:68-90): product (npz back end) == oracle."""
+    sys.path.insert(0, ROOT)
+    try:
+        from data_loader import load_trajectory_segments
+        from netcdf_writer import NetCDFWriter
+    finally:
+        sys.path.remove(ROOT)
+    path = str(tmp_path / "training_data.npz")
+    w = NetCDFWriter(path, 500, max_episodes=4, max_steps=40)
+    a = to.writer_arrays(4, 40)
+    rng = np.random.RandomState(2)
+    for ep, steps in ((0, 19), (1, 20), (3, 27)):
+        x, y, c = rng.rand(steps) * 499, rng.rand(steps) * 499, rng.rand(steps) * 100
+        args = (ep, steps, x, y, c, 40.0 + ep, 50.0 + ep, 100.0)
+        w.write_episode_data(*args, sigma=15.0, peak=100.0)
+        to.write_episode(a, *args, sigma=15.0, peak=100.0)
+    w.close()
+    d = np.load(path)
+    for k in a:
+        assert np.array_equal(d[k], a[k], equal_nan=True), k
+    segs, osegs = load_trajectory_segments(path, tail_steps=60), to.load_trajectory_segments(a)
+    assert len(segs) == len(osegs) == 1 + 8                                   # 19 steps: none; 20: one; 27: eight windows
+    for s_, o in zip(segs, osegs):
+        assert np.array_equal(s_["positions"], o["positions"]) and np.array_equal(s_["concentrations"], o["concentrations"])
+        assert np.array_equal(s_["source_pos"], o["source_pos"]) and s_["sigma"] == o["sigma"] == np.float32(15.0)
+    assert np.array_equal(segs[-1]["positions"][-1], [43.0, 53.0])              # the last logged step carries the source position

@@ -49,7 +49,7 @@ struct RolloutBufs {
     float* cur_obs; float* h; float* c;
     float* obs; int32_t* act; float* rew; float* val; float* logp; float* done; uint8_t* flags; float* keep;
     float* last_val; const int32_t* forced_act; const double* noise; int32_t* nan_count;
-    float* info;                // optional [N][T][8]: the 5 reward parts of environment.py:161-167, obs[2] and agent_pos of the step
+    float* info;                // optional [N][T][10]: 5 reward parts of environment.py:161-167, obs[2], agent_pos, source_pos of the step
     float* heads;               // optional [N][T][NA+1]: logits | value of the step
     float* stash; float* y;     // optional: BPTT stash [N][T][6H] + y [N][T][H], so PPO epoch 0 skips its forward pass
 };
@@ -395,6 +395,8 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     for (int f = 0; f < 6; ++f) ob_old[f] = xbuf[lane * 8 + f];
 #pragma unroll
                     for (int f = 0; f < 6; ++f) trs[RMT * 8 + lane * 8 + f] = ob_old[f];
+                    trs[RMT * 8 + lane * 8 + 6] = (float)es.sx;           // source of the episode this step belongs to
+                    trs[RMT * 8 + lane * 8 + 7] = (float)es.sy;
                     if (so.done) {
                         es.episode += 1;
                         env_begin_episode(P, eg, es, myvis);
@@ -417,7 +419,9 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                         B.keep[row] = tq[6];
                         if (B.info) {
 #pragma unroll
-                            for (int f = 0; f < 8; ++f) B.info[row * 8 + f] = trs[2 * RMT * 8 + lane * 8 + f];
+                            for (int f = 0; f < 8; ++f) B.info[row * 10 + f] = trs[2 * RMT * 8 + lane * 8 + f];
+                            B.info[row * 10 + 8] = trs[RMT * 8 + lane * 8 + 6];
+                            B.info[row * 10 + 9] = trs[RMT * 8 + lane * 8 + 7];
                         }
                     }
                 }

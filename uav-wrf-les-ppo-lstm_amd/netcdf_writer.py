@@ -5,7 +5,8 @@ Same constructor, variables (episode, step, x, y, concentration, is_source, sour
 dtypes, fill values and write_episode_data() semantics (the last step's x / y are overwritten with the source coordinates
 and flagged in is_source).  With netCDF4 installed and a filename not ending in .npz the file is a real NETCDF4 file written
 through the reference's own calls; otherwise (this image has no netCDF4) the arrays are kept in memory and close() writes
-an .npz with the same variable names."""
+an .npz with the same variable names.  PPOV2.1 keeps the same class in model.py:355-423 with two more per-episode variables,
+gaussian_sigma and peak_concentration, and two more write_episode_data() arguments: both are here, optional."""
 from __future__ import annotations
 
 import numpy as np
@@ -37,6 +38,8 @@ class NetCDFWriter:
             self.source_conc_var = mk("source_concentration", np.float32, ("episode",), np.nan)
             self.source_x_var = mk("source_x", np.float32, ("episode",), np.nan)
             self.source_y_var = mk("source_y", np.float32, ("episode",), np.nan)
+            self.sigma_var = nc.createVariable("gaussian_sigma", np.float32, ("episode",))
+            self.peak_var = nc.createVariable("peak_concentration", np.float32, ("episode",))
         else:
             self.episode_var = np.zeros(E, np.int32)
             self.step_var = np.zeros(S, np.int32)
@@ -47,9 +50,11 @@ class NetCDFWriter:
             self.source_conc_var = np.full(E, np.nan, np.float32)
             self.source_x_var = np.full(E, np.nan, np.float32)
             self.source_y_var = np.full(E, np.nan, np.float32)
+            self.sigma_var = np.full(E, np.nan, np.float32)
+            self.peak_var = np.full(E, np.nan, np.float32)
 
-    def write_episode_data(self, episode_idx, steps, x, y, conc, source_x, source_y, source_conc):
-        """netcdf_writer.py:87-110 (called for successful episodes only)."""
+    def write_episode_data(self, episode_idx, steps, x, y, conc, source_x, source_y, source_conc, sigma=None, peak=None):
+        """netcdf_writer.py:87-110 (called for successful episodes only); sigma / peak: PPOV2.1/model.py:405-419."""
         self.x_var[episode_idx, :steps] = x
         self.y_var[episode_idx, :steps] = y
         self.conc_var[episode_idx, :steps] = conc
@@ -59,6 +64,10 @@ class NetCDFWriter:
         self.source_conc_var[episode_idx] = source_conc
         self.source_x_var[episode_idx] = source_x
         self.source_y_var[episode_idx] = source_y
+        if sigma is not None:
+            self.sigma_var[episode_idx] = sigma
+        if peak is not None:
+            self.peak_var[episode_idx] = peak
 
     def close(self):
         if self._nc is not None:
@@ -67,4 +76,5 @@ class NetCDFWriter:
         np.savez_compressed(self.filename, episode=self.episode_var, step=self.step_var, x=self.x_var, y=self.y_var,
                             concentration=self.conc_var, is_source=self.source_var,
                             source_concentration=self.source_conc_var, source_x=self.source_x_var,
-                            source_y=self.source_y_var, GRID_SIZE=np.int64(self.grid_size))
+                            source_y=self.source_y_var, gaussian_sigma=self.sigma_var, peak_concentration=self.peak_var,
+                            GRID_SIZE=np.int64(self.grid_size))

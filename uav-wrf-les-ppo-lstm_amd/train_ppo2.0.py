@@ -133,7 +133,9 @@ def train_ppo_vectorised(iterations=200, csv_path="training_results2_0.csv", mod
     if nc_path:                      # the reference's trajectory log (train_ppo2.0.py:119-125,216-227,259)
         from netcdf_writer import NetCDFWriter
         from uavppo.episode_log import TrajectoryLogger
-        traj = TrajectoryLogger(NUM_ENVS, NetCDFWriter(nc_path, GRID_SIZE, max_episodes=2000, max_steps=MAX_STEPS))
+        from config import GAUSSIAN_RADIUS, PEAK_CONCENTRATION
+        traj = TrajectoryLogger(NUM_ENVS, NetCDFWriter(nc_path, GRID_SIZE, max_episodes=2000, max_steps=MAX_STEPS),
+                                gaussian=(GAUSSIAN_RADIUS, PEAK_CONCENTRATION) if ENV_VARIANT == "v2.1" else None)
     for it in range(iterations):
         radius = tr.radius
         tr.train_iteration()

@@ -67,12 +67,17 @@ class RadiusTracker:
 class TrajectoryLogger:
     """Per-episode trajectories of the vectorised trainer for the reference's NetCDF log (train_ppo2.0.py:166-175,200-227):
     x, y = agent_pos after every step, conc = conc_field at that cell, and for a successful episode the position /
-    concentration it stopped at.  Consumes the fused rollout's info [N,T,8] (columns 5,6,7 = obs[2], x, y) and flags;
+    concentration it stopped at.  Consumes the fused rollout's info [N,T,10] (columns 5..9 = obs[2], x, y, source x, y) and flags;
     episodes may span rollouts, so per-env partial trajectories are carried.  Episodes are numbered in (iteration, env,
     time) order like EpisodeLogger's rows; an episode is written when it succeeded and its radius is one of the tracker's
-    two smallest (the reference's rule at :216-227)."""
+    two smallest (the reference's rule at :216-227).
 
-    def __init__(self, num_envs, writer=None, tracker=None):
+    `gaussian` = (sigma, peak) switches to the PPOV2.1 script's behaviour (PPOV2.1/train_ppo2.0.py:205-232): the
+    conditional write carries sigma / peak, and EVERY finished episode is then written (again) with the true source position
+    and source_conc = peak -- the file PPOV2.1's load_trajectory_segments / TrajectoryDataset are fed from."""
+
+    def __init__(self, num_envs, writer=None, tracker=None, gaussian=None):
+        self.gaussian = gaussian
         self.partial = [([], [], []) for _ in range(num_envs)]
         self.writer, self.tracker = writer, tracker if tracker is not None else RadiusTracker()
         self.count = 0
@@ -96,10 +101,16 @@ class TrajectoryLogger:
                   "source_x": float(xs[-1]) if success else 0.0, "source_y": float(ys[-1]) if success else 0.0,
                   "source_conc": float(cs[-1]) if success else 0.0}
             self.tracker.update(radius, ep, success)
-            if success and radius in self.tracker.radius_history and self.writer is not None \
-                    and self.count < self.writer.max_episodes:
+            room = self.writer is not None and self.count < self.writer.max_episodes
+            extra = {} if self.gaussian is None else {"sigma": self.gaussian[0], "peak": self.gaussian[1]}
+            if success and radius in self.tracker.radius_history and room:
                 self.writer.write_episode_data(self.count, ep["steps"], ep["x"], ep["y"], ep["conc"], ep["source_x"],
-                                               ep["source_y"], ep["source_conc"])
+                                               ep["source_y"], ep["source_conc"], **extra)
+                if self.gaussian is None:
+                    self.written.append((self.count, ep["steps"]))
+            if self.gaussian is not None and room:
+                self.writer.write_episode_data(self.count, ep["steps"], ep["x"], ep["y"], ep["conc"], float(info[n, t, 8]),
+                                               float(info[n, t, 9]), self.gaussian[1], **extra)
                 self.written.append((self.count, ep["steps"]))
             self.count += 1
         for n in range(N):

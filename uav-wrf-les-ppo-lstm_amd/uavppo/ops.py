@@ -454,7 +454,7 @@ def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h,
                             _p(last_val, F32, (N,), "last_val"), _p(forced_act, I32, (N, T), "forced_act"),
                             _p(noise, F64, (N, T, 2), "noise"), _p(nan_count, I32, (1,), "nan_count"),
                             _p(stash, F32, (N, T, 6 * hidden), "stash"), _p(y, F32, (N, T, hidden), "y"),
-                            _p(info, F32, (N, T, 8), "info"), _p(heads, F32, (N, T, 6), "heads"), _stream()),
+                            _p(info, F32, (N, T, 10), "info"), _p(heads, F32, (N, T, 6), "heads"), _stream()),
           "uav_rollout")
     if _t is not None:
         _t.record()

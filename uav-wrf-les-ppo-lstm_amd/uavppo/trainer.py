@@ -51,7 +51,7 @@ class VecPPOTrainer:
                     "done": torch.zeros(N, T, **f32), "flags": torch.zeros(N, T, dtype=torch.uint8, device=d),
                     "keep": torch.ones(N, T, **f32)}
         # optional per-step reward parts (for the reference's per-episode CSV columns, train_ppo2.0.py:129-135)
-        self.info = torch.zeros(N, T, 8, **f32) if log_info else None     # reward parts | obs[2] | agent x, y
+        self.info = torch.zeros(N, T, 10, **f32) if log_info else None    # reward parts | obs[2] | agent x, y | source x, y
         self.adv = torch.zeros(N, T, **f32)
         self.adv_n = torch.zeros(N, T, **f32)
         self.ret = torch.zeros(N, T, **f32)
@@ -159,12 +159,16 @@ class VecPPOTrainer:
             if self.info is not None and "info" not in st:
                 st["info"] = torch.zeros(self.N, 5, dtype=torch.float32, device=self.device)
                 st["term"] = torch.zeros(self.N, self.obs_dim, dtype=torch.float32, device=self.device)
+                st["src"] = torch.zeros(self.N, 2, dtype=torch.float64, device=self.device)
+            if self.info is not None:
+                ops.env_peek(self.env_state, self.N, source=st["src"])           # source of the episode this step belongs to
             ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, st["rew"], st["done"], st["flags"], noise=nz,
                          info=st.get("info"), term_obs=st.get("term"))
             if self.info is not None:
                 self.info[:, t, :5] = st["info"]
                 self.info[:, t, 5] = st["term"][:, 2]
                 self.info[:, t, 6:8] = st["term"][:, :2] * 500.0       # step-wise path: position from the observation
+                self.info[:, t, 8:10] = st["src"]
             b["rew"][:, t] = st["rew"]
             b["done"][:, t] = st["done"]
             b["flags"][:, t] = st["flags"]
@@ -197,12 +201,16 @@ class VecPPOTrainer:
             if self.info is not None and "info" not in tmp:
                 tmp["info"] = torch.zeros(self.N, 5, dtype=torch.float32, device=self.device)
                 tmp["term"] = torch.zeros(self.N, self.obs_dim, dtype=torch.float32, device=self.device)
+                tmp["src"] = torch.zeros(self.N, 2, dtype=torch.float64, device=self.device)
+            if self.info is not None:
+                ops.env_peek(self.env_state, self.N, source=tmp["src"])           # source of the episode this step belongs to
             ops.env_step(self.env_state, self.N, cfg, act, self.cur_obs, tmp["rew"], tmp["done"], tmp["flags"], noise=nz,
                          info=tmp.get("info"), term_obs=tmp.get("term"))
             if self.info is not None:
                 self.info[:, t, :5] = tmp["info"]
                 self.info[:, t, 5] = tmp["term"][:, 2]
                 self.info[:, t, 6:8] = tmp["term"][:, :2] * 500.0
+                self.info[:, t, 8:10] = tmp["src"]
             b["rew"][:, t] = tmp["rew"]
             b["done"][:, t] = tmp["done"]
             b["flags"][:, t] = tmp["flags"]
