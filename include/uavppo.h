@@ -14,7 +14,8 @@
  *   - return 0 on success, non-zero on error (uav_last_error() gives the text); the Python
  *     side raises RuntimeError, the reference's error convention (model.py:47-49);
  *   - rollout buffers are (env, T, feat) row-major: x[n][t][f];
- *   - thread-compatible: one caller thread per handle.
+ *   - thread-compatible: one caller thread per handle; a handle owns ONE scratch workspace, so the calls made on it
+ *     must be ordered on the device (one stream, or events between streams) -- use one handle per concurrent stream.
  */
 #ifndef UAVPPO_H
 #define UAVPPO_H
