@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams P, EnvBlob b, i
     int a = act[i];
     a = a < 0 ? 0 : (a > 4 ? 4 : a);
     StepOut o;
-    env_step_core(P, eg, s, vis, a, z0, z1, o);
+    double tx, ty;
+    env_step_wind(s, z0, z1, tx, ty);
+    env_step_core(P, eg, s, vis, a, tx, ty, o);
     const int od = 6 + P.trend_k;
     if (term_obs) for (int k = 0; k < od; ++k) term_obs[(size_t)i * od + k] = o.obs[k];
     if (info) for (int k = 0; k < 5; ++k) info[(size_t)i * 5 + k] = (float)o.info[k];

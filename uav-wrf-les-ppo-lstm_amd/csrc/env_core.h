@@ -159,9 +159,18 @@ struct StepOut {
     double info[5];      // concentration_reward, explore_reward, move_penalty, tke_penalty, boundary_penalty
 };
 
-// E4.  z0,z1: the two normals of environment.py:101.
+// The wind displacement of a step from its two normals z0, z1 (environment.py:100-101).  It does not depend on the action,
+// so the fused rollout computes it before the action is known.
+__device__ __forceinline__ void env_step_wind(const EnvState& s, double z0, double z1, double& tx, double& ty) {
+    constexpr double MOVE = GRID * 0.05;
+    const double k = (MOVE * 0.2);
+    tx = k * (z0 * s.tke / 9.0);
+    ty = k * (z1 * s.tke / 9.0);
+}
+
+// E4.  tx, ty: env_step_wind() of the state before the step.
 __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global, EnvState& s, unsigned short* vis,
-                                              int action, double z0, double z1, StepOut& out) {
+                                              int action, double tx, double ty, StepOut& out) {
     s.steps += 1;
     const double prev_conc = s.conc;                                  // :86-88 (cell of the f32 position), already /100
     constexpr double MOVE = GRID * 0.05;                              // :91
@@ -169,8 +178,6 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
     if (action == 1) dy = MOVE; else if (action == 2) dy = -MOVE; else if (action == 3) dx = MOVE; else if (action == 4) dx = -MOVE;
     const double norm_d = (action == 0) ? 0.0 : MOVE;
     const double move_pen = (action == 0) ? -0.15 : -0.0;            // -0.15*(1 - |d|/25), :94-95
-    const double k = (MOVE * 0.2);
-    const double tx = k * (z0 * s.tke / 9.0), ty = k * (z1 * s.tke / 9.0);   // :100-101
     double nx = ((double)s.px + dx) + tx, ny = ((double)s.py + dy) + ty;    // :104
     nx = fmin(fmax(nx, 0.0), P.clip_hi);                              // :105
     ny = fmin(fmax(ny, 0.0), P.clip_hi);

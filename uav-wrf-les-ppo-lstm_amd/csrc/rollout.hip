@@ -25,6 +25,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, EnvParams& P);
 
 constexpr int RMT = 16;
+
+#ifdef UAV_X6_PROFILE
+// phase timing of wave 0 (instrumented build only, tools/build_prof.sh): cycles summed over the rollout by workgroup 0
+__device__ unsigned long long g_roll_prof[8];
+#define R_PROF_DECL unsigned long long pm_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl_ = __builtin_readcyclecounter()
+#define R_PROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pm_[i] += n_ - pl_; pl_ = n_; } while (0)
+#define R_PROF_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_roll_prof[i_] = pm_[i_]; } while (0)
+extern "C" int uav_roll_prof_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_roll_prof), sizeof(g_roll_prof)) == hipSuccess ? 0 : 1;
+}
+#else
+#define R_PROF_DECL
+#define R_PROF_MARK(i)
+#define R_PROF_FLUSH()
+#endif
 constexpr float R_F32_EPS = 1.1920928955078125e-07f;
 
 #define r_sigmoid fast_sigmoid
@@ -79,7 +94,8 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     __shared__ float hd[RMT * 16];
     __shared__ unsigned short vis[RMT * NVIS];
     __shared__ EnvState es_s[RMT];
-    __shared__ float trs[3 * RMT * 8];                            // parked transitions (see the env block)
+    __shared__ float trs[4 * RMT * 8];                            // the step's transition, parked by wave 0, stored by the last gate wave
+    __shared__ __attribute__((aligned(16))) f32x4 acc0[4 * 64];  // wave 0's next-step accumulators, computed by the gate waves
 
     const float* w_ih = params;
     const float* w_hh = w_ih + 4 * H * I;
@@ -217,6 +233,33 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
         recurrent([&](int q, int s) { return wb[q][s][0]; }, [&](int q, int s) { return wb[q][s][1]; },
                   [&](int q, int s) { return (q < QL) ? wpk[(q * NS + s) * 64] : wb2[q < QL ? 0 : q - QL][s]; });
     };
+    // Wave 0's share of the recurrent product (units 0..15 of the four gates), computed by the gate waves from the
+    // LDS copy of its weights while they would otherwise wait at barrier 2 for the env step: tile q goes to wave
+    // 1 + q % (NW - 1).  Same operand fragments and accumulation order as recurrent(), so the bits do not change.
+    auto recurrent_for_wave0 = [&]() {
+        const bf16x8* const wf = reinterpret_cast<const bf16x8*>(w0p) + lane;
+        const unsigned short* hrow = hpl + j * RS + 8 * kq;
+        for (int q = w - 1; q < 4; q += NW - 1) {
+            const float4 bv = *reinterpret_cast<const float4*>(bl + q * H + 4 * kq);
+            f32x4 e = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(hrow + 32 * s);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(hrow + PLANE + 32 * s);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(hrow + 2 * PLANE + 32 * s);
+                const bf16x8 p0 = wf[((q * NS + s) * 3 + 0) * 64], p1 = wf[((q * NS + s) * 3 + 1) * 64],
+                             p2 = wf[((q * NS + s) * 3 + 2) * 64];
+                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, a2, e, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, a1, e, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p2, a0, e, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, a1, e, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, a0, e, 0, 0, 0);
+                e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, a0, e, 0, 0, 0);
+                asm volatile("" ::: "memory");
+            }
+            acc0[q * 64 + lane] = e;
+        }
+    };
     auto recurrent_lds = [&]() {
         recurrent([&](int q, int s) { return w0f[((q * NS + s) * 3 + 0) * 64]; },
                   [&](int q, int s) { return w0f[((q * NS + s) * 3 + 1) * 64]; },
@@ -272,6 +315,38 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
         }
     };
 
+    // The transition of step t leaves for HBM from the last gate wave, not from wave 0 (whose heads -> action -> env chain
+    // paces the kernel): wave 0 parks it in trs ([action, reward, V, logp, done, flags, keep, -] | [obs 6, source x, y] |
+    // [info 8] | [logits 5]) and the last gate wave stores it right after barrier 2.  trs is rewritten only after barrier 1
+    // of the next step, which that wave passes after its reads have completed.  (Spreading the stores over three gate
+    // waves measured slower, 792 vs 773 us per rollout.)
+    auto store_transition = [&](int t) {
+        if (lane < RMT && n0 + lane < N) {
+            const size_t row = (size_t)(n0 + lane) * T + t;
+            const float* tq = trs + lane * 8;
+#pragma unroll
+            for (int f = 0; f < 6; ++f) B.obs[row * 6 + f] = trs[RMT * 8 + lane * 8 + f];
+            B.act[row] = __float_as_int(tq[0]);
+            B.rew[row] = tq[1];
+            B.val[row] = tq[2];
+            B.logp[row] = tq[3];
+            B.done[row] = tq[4];
+            B.flags[row] = (uint8_t)__float_as_int(tq[5]);
+            B.keep[row] = tq[6];
+            if (B.heads) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a) B.heads[row * NH + a] = trs[3 * RMT * 8 + lane * 8 + a];
+                B.heads[row * NH + NA] = tq[2];
+            }
+            if (B.info) {
+#pragma unroll
+                for (int f = 0; f < 8; ++f) B.info[row * 10 + f] = trs[2 * RMT * 8 + lane * 8 + f];
+                B.info[row * 10 + 8] = trs[RMT * 8 + lane * 8 + 6];
+                B.info[row * 10 + 9] = trs[RMT * 8 + lane * 8 + 7];
+            }
+        }
+    };
+
     const int steps = T + (B.last_val ? 1 : 0);   // one extra value-only pass for V(s_T)
     if (!is_env_wave) {
         // ------------------------------------------------------------------ gate waves
@@ -281,18 +356,44 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
             const bool value_only = (t == T);
             finish_cell(t, value_only);
             lds_barrier();                       // barrier 1: h_t visible
-            if (!value_only && t + 1 < steps) recurrent_regs();     // bias + W_hh h_t for step t+1
+            if (!value_only && t + 1 < steps) {
+                recurrent_regs();                // bias + W_hh h_t for step t+1
+                recurrent_for_wave0();
+            }
             lds_barrier();                       // barrier 2: x_{t+1}, keep_{t+1} visible; reads of h_t done
-            if (!value_only) keep_fixup(t);
+            if (!value_only) {
+                keep_fixup(t);
+                if (w == NW - 1) store_transition(t);
+            }
         }
     } else {
         // ------------------------------------------------------------------ wave 0: gate wave + env role
         recurrent_lds();
         lds_barrier();
+        float bh[NH];                            // head biases: read once (a load inside the loop could not be hoisted past the stores)
+#pragma unroll
+        for (int a = 0; a < NH; ++a) bh[a] = b_hd[a];
+        R_PROF_DECL;
         for (int t = 0; t < steps; ++t) {
             const bool value_only = (t == T);
+            R_PROF_MARK(7);
             finish_cell(t, value_only);
+            R_PROF_MARK(0);
+            // the step's action-independent part (sampling uniform, the wind displacement from its two normals), computed
+            // while the other waves finish their cells: off the heads -> action -> env chain that paces the kernel
+            uint32_t u_act = 0;
+            double wind_x = 0.0, wind_y = 0.0;
+            if (lane < RMT && !value_only) {
+                double z0, z1;
+                const int eg = P.env_offset + my_env;
+                const size_t row = (size_t)min(my_env, N - 1) * T + t;
+                if (!B.forced_act) u_act = philox4x32_10(P.seed, (uint32_t)t, (uint32_t)eg, (uint32_t)iter, RNG_ACTION).x;
+                if (B.noise) { z0 = B.noise[2 * row]; z1 = B.noise[2 * row + 1]; }
+                else env_step_noise(P, eg, es_s[lane], z0, z1);
+                env_step_wind(es_s[lane], z0, z1, wind_x, wind_y);
+            }
             lds_barrier();                       // barrier 1: h_t visible
+            R_PROF_MARK(1);
             // heads of h_t: D[head 4 kq + r][env j] = W_head h_t^T, six piece products per slab
             f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb2 = ha;
             {
@@ -319,11 +420,12 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
             for (int r = 0; r < 4; ++r) hd[j * 16 + 4 * kq + r] = ha[r];
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the hd tile is written (single wave)
             __builtin_amdgcn_wave_barrier();
+            R_PROF_MARK(2);
             if (lane < RMT) {
                 float z[NA], p[NA];
 #pragma unroll
-                for (int a = 0; a < NA; ++a) z[a] = hd[lane * 16 + a] + b_hd[a];
-                const float V = hd[lane * 16 + NA] + b_hd[NA];
+                for (int a = 0; a < NA; ++a) z[a] = hd[lane * 16 + a] + bh[a];
+                const float V = hd[lane * 16 + NA] + bh[NA];
                 if (value_only) {
                     if (env_lane) B.last_val[my_env] = V;
                 } else {
@@ -345,8 +447,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     if (B.forced_act) {
                         a_sel = B.forced_act[row];
                     } else {
-                        const Philox4 rr = philox4x32_10(P.seed, (uint32_t)t, (uint32_t)eg, (uint32_t)iter, RNG_ACTION);
-                        const float target = u01_f32(rr.x) * psum;
+                        const float target = u01_f32(u_act) * psum;
                         float cdf = 0.f;
                         a_sel = NA - 1;
                         bool found = false;
@@ -357,19 +458,18 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                         }
                     }
                     a_sel = a_sel < 0 ? 0 : (a_sel > NA - 1 ? NA - 1 : a_sel);
-                    float qa = 0.f;
+                    float psel = 0.f;
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) if (a == a_sel) qa = p[a] / psum;
+                    for (int a = 0; a < NA; ++a) if (a == a_sel) psel = p[a];
+                    const float qa = psel / psum;
                     const float lp = __logf(fminf(fmaxf(qa, R_F32_EPS), 1.0f - R_F32_EPS));
+                    R_PROF_MARK(3);
                     // environment step (f64, env_core.h) + auto reset
                     EnvState es = es_s[lane];
-                    double z0, z1;
-                    if (B.noise) { z0 = B.noise[2 * row]; z1 = B.noise[2 * row + 1]; }
-                    else env_step_noise(P, eg, es, z0, z1);
                     StepOut so;
-                    env_step_core(P, eg, es, myvis, a_sel, z0, z1, so);
-                    // park the transition in LDS; the global stores are issued at the very end of the env block so
-                    // that no later scratch reload / load wait (vmcnt counts stores too) stalls on their HBM acks
+                    env_step_core(P, eg, es, myvis, a_sel, wind_x, wind_y, so);
+                    R_PROF_MARK(4);
+                    // park the transition in LDS for store_transition()
                     float* tr = trs + lane * 8;
                     tr[0] = __int_as_float(a_sel);
                     tr[1] = (float)so.reward;
@@ -378,10 +478,9 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     tr[4] = so.done ? 1.f : 0.f;
                     tr[5] = __int_as_float((so.done ? 1 : 0) | (so.reached ? 2 : 0));
                     tr[6] = kbuf[lane];
-                    if (B.heads && env_lane) {
+                    if (B.heads) {
 #pragma unroll
-                        for (int a = 0; a < NA; ++a) B.heads[row * NH + a] = z[a];
-                        B.heads[row * NH + NA] = V;
+                        for (int a = 0; a < NA; ++a) trs[3 * RMT * 8 + lane * 8 + a] = z[a];
                     }
                     if (B.info) {
 #pragma unroll
@@ -406,30 +505,18 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                     for (int f = 0; f < 6; ++f) xbuf[lane * 8 + f] = so.obs[f];
                     es_s[lane] = es;
                     kbuf[lane] = so.done ? 0.f : 1.f;
-                    if (env_lane) {
-                        const float* tq = trs + lane * 8;
-#pragma unroll
-                        for (int f = 0; f < 6; ++f) B.obs[row * 6 + f] = trs[RMT * 8 + lane * 8 + f];
-                        B.act[row] = __float_as_int(tq[0]);
-                        B.rew[row] = tq[1];
-                        B.val[row] = tq[2];
-                        B.logp[row] = tq[3];
-                        B.done[row] = tq[4];
-                        B.flags[row] = (uint8_t)__float_as_int(tq[5]);
-                        B.keep[row] = tq[6];
-                        if (B.info) {
-#pragma unroll
-                            for (int f = 0; f < 8; ++f) B.info[row * 10 + f] = trs[2 * RMT * 8 + lane * 8 + f];
-                            B.info[row * 10 + 8] = trs[RMT * 8 + lane * 8 + 6];
-                            B.info[row * 10 + 9] = trs[RMT * 8 + lane * 8 + 7];
-                        }
-                    }
                 }
             }
-            if (!value_only && t + 1 < steps) recurrent_lds();      // bias + W_hh h_t for step t+1
-            lds_barrier();                       // barrier 2
+            R_PROF_MARK(5);
+            lds_barrier();                       // barrier 2: the gate waves have left bias + W_hh h_t of this wave's units in acc0
+            if (!value_only && t + 1 < steps) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = acc0[q * 64 + lane];
+            }
+            R_PROF_MARK(6);
             if (!value_only) keep_fixup(t);
         }
+        R_PROF_FLUSH();
     }
     // ------------------------------------------------------------------ write back persistent state
     if (live) *reinterpret_cast<float4*>(B.c + (size_t)(n0 + j) * H + uo) = float4{c_reg[0], c_reg[1], c_reg[2], c_reg[3]};
