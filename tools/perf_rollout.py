@@ -1,6 +1,5 @@
 """Rollout kernel timing; with the instrumented build (tools/build_prof.sh, UAVPPO_LIB=tools/libuavppo_prof.so) also the
-phase split of wave 0 per step: finish_cell | barrier 1 | heads | softmax+sample | noise+env step | park+obs+stores |
-recurrent share | barrier 2 + fixup."""
+phase split of wave 0 per step."""
 import ctypes
 import os
 import sys
@@ -27,7 +26,7 @@ L = _lib.lib()
 if hasattr(L, "uav_roll_prof_read"):
     buf = (ctypes.c_ulonglong * 8)()
     L.uav_roll_prof_read(buf)
-    names = ["finish_cell", "barrier1", "heads", "softmax+sample", "noise+env", "park+obs+stores", "recurrent_lds", "barrier2+fixup"]
+    names = ["finish_cell", "barrier1 wait", "heads", "softmax+sample", "env step", "park+reset+obs", "rng+wind (shadow)", "barrier2+acc0+fixup"]
     tot = sum(buf)
     for n, v in zip(names, buf):
         print(f"  {n:18s} {v / (T + 1):8.0f} cycles/step  {100.0 * v / tot:5.1f} %")

@@ -196,10 +196,16 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     lds_barrier();
 
     f32x4 acc[4];
+    // One LDS address register for the four bias rows (+ q * H floats as the ds_read immediate): with a transparent lane offset
+    // the compiler folds bl's > 64 KB offset into four separate address VGPRs, one of which the gate waves then spill and
+    // reload inside the time loop -- and a scratch reload means s_waitcnt vmcnt(0), i.e. waiting for the stash stores.
+    int bo = uo;
+    asm volatile("" : "+v"(bo));
+    const float* blu = bl + bo;
     auto bias_acc = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(bl + q * H + uo);
+            const float4 v = *reinterpret_cast<const float4*>(blu + q * H);
             acc[q] = f32x4{v.x, v.y, v.z, v.w};
         }
     };
@@ -392,6 +398,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
                 else env_step_noise(P, eg, es_s[lane], z0, z1);
                 env_step_wind(es_s[lane], z0, z1, wind_x, wind_y);
             }
+            R_PROF_MARK(6);
             lds_barrier();                       // barrier 1: h_t visible
             R_PROF_MARK(1);
             // heads of h_t: D[head 4 kq + r][env j] = W_head h_t^T, six piece products per slab
@@ -513,7 +520,6 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = acc0[q * 64 + lane];
             }
-            R_PROF_MARK(6);
             if (!value_only) keep_fixup(t);
         }
         R_PROF_FLUSH();
