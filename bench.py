@@ -190,7 +190,7 @@ def main():
         ach = bytes_bwd / sec / 1e9
         traffic = None
         kname = "lstm_bwd_x6k_kernel<%d>" % H
-        tf = os.path.join(ROOT, "profiles", "r01_g_hbm_traffic_pmc.json")
+        tf = os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")
         if args.config == "c3" and os.path.exists(tf):
             traffic = json.load(open(tf)).get(kname, {}).get("hbm_total_bytes")
         roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
