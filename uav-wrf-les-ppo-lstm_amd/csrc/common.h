@@ -68,6 +68,22 @@ __device__ __forceinline__ void split3(float a, __bf16& p0, __bf16& p1, __bf16& 
 }
 __device__ __forceinline__ unsigned short bf_bits(__bf16 v) { return __builtin_bit_cast(unsigned short, v); }
 
+// ---- split-fp16 ("h3") arithmetic: an f32 value as TWO fp16 pieces, a = p0 + 2^-11 p1 with p0 = fp16(a) and
+// p1 = fp16((a - p0) * 2^11): the residual is scaled back into fp16's normal range, so a is carried to 2^-24 |a| (its last
+// f32 bit).  a b = p0 q0 + 2^-11 (p0 q1 + p1 q0) + O(2^-24 |a b|): the main product and the two cross products go to two
+// f32 accumulators (v_mfma_f32_16x16x32_f16), combined once per dot product as acc0 + 2^-11 acc1.  Three products
+// instead of the bf16 split's six, two pieces instead of three (the weights keep their f32 register footprint), and on a
+// K=128 dot product a SMALLER error against f64 than either the bf16 split or the exact-f32 MFMA chain (rms 1.06e-7 vs
+// 1.50e-7 vs 2.05e-7 of the terms' rms sum: fewer accumulator roundings; tools/f16x3_probe.hip).  fp16's range is the
+// caller's business: |a| < 65504, and operands with a wide dynamic range (gradients) are block-scaled by a power of two.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float H3_LO = 1.0f / 2048.0f;          // weight of the cross-product accumulator
+__device__ __forceinline__ void split2h(float a, _Float16& p0, _Float16& p1) {
+    p0 = (_Float16)a;
+    p1 = (_Float16)((a - (float)p0) * 2048.0f);
+}
+__device__ __forceinline__ unsigned short h_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+
 // ---- wave / block reductions (deterministic: fixed tree, no atomics) -------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -41,6 +41,7 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 // UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split-bf16 ones)
 static bool f32_mfma_requested() { return getenv("UAV_LSTM_F32_MFMA") != nullptr; }   // read per call: tests toggle it
+static bool bf16x6_requested() { return getenv("UAV_LSTM_BF16X6") != nullptr; }        // the predecessor of the fp16 split
 constexpr int TC = 32;      // time steps staged per chunk
 
 #define sigmoidf_ fast_sigmoid
@@ -499,6 +500,269 @@ __global__ __launch_bounds__(H * 4) void lstm_fwd_x6_kernel(
                 c_reg[r] = (t == T - 1) ? cc[r] : cc[r] * kn;            // cn is the unmasked final cell state
             }
             put_h(hpl + (cur ^ 1) * 3 * PLANE, hh);
+            kcur = kn;
+            if (live) {
+                *reinterpret_cast<float4*>(y + row * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
+                if (stash) {
+                    *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
+                    if (I > 6 && t + 1 < T)                              // h_prev of step t+1 (generic wgrad path)
+                        *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hm[0], hm[1], hm[2], hm[3]};
+                }
+                if (t == T - 1) {
+                    *reinterpret_cast<float4*>(hn + (size_t)n * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
+                    *reinterpret_cast<float4*>(cn + (size_t)n * H + uo) = float4{c_reg[0], c_reg[1], c_reg[2], c_reg[3]};
+                }
+            }
+            cur ^= 1;
+            X6_PROF_MARK(2);
+            lds_barrier();
+            X6_PROF_MARK(3);
+        }
+        if (ch + 1 < nchunk) {
+            stage_commit(xb ^ 1);
+            lds_barrier();
+        }
+    }
+    if (heads && w == NW - 1) emit_heads(cur, T - 1);                     // planes `cur` hold h_{T-1}
+    X6_PROF_FLUSH();
+}
+
+
+// ------------------------------------------------------------------------- forward, split-fp16 MFMA ("h3")
+// The same kernel with the recurrent product as THREE fp16 MFMA products per K = 32 slab (common.h, split2h): W_hh and
+// h_t are carried as two fp16 pieces each, main and cross products accumulate separately and are combined once per step.
+// Half the matrix instructions of the bf16 split, the weight pieces take exactly the f32 weights' 128 VGPRs (no LDS
+// slab), two h planes instead of three -- and a smaller error (tools/f16x3_probe.hip).  h is in (-1, 1) and the
+// weights are O(1), far inside fp16's range; values below its normal range lose relative, not absolute, accuracy
+// (absolute error <= 2^-36), which is what a dot product needs.
+template <int H>
+struct FwdH3Geom {
+    static constexpr int NS = H / 32;
+    static constexpr int RS = H + 8;
+    static constexpr int PLANE = MT * RS;
+    static constexpr int TCX = 8;
+    static constexpr int XPT = (MT * TCX * 8 + H * 4 - 1) / (H * 4);
+    static constexpr int HPL = 8 * RS;
+    static constexpr size_t LDS = (2 * 2 * PLANE + 2 * HPL) * sizeof(unsigned short) +
+                                  (2 * TCX * MT * 8 + 2 * TCX * MT + (H / 16) * 8 * 64 + 4 * H + 8) * sizeof(float);
+};
+
+template <int H, bool FUSE_X>
+__global__ __launch_bounds__(H * 4) void lstm_fwd_h3_kernel(
+    const float* __restrict__ x, const float* __restrict__ keep, const float* __restrict__ h0,
+    const float* __restrict__ c0, const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+    const float* __restrict__ b_ih, const float* __restrict__ b_hh, int N, int T, int I,
+    float* __restrict__ y, float* __restrict__ hn, float* __restrict__ cn, float* __restrict__ stash,
+    const float* __restrict__ w_head, const float* __restrict__ b_head, int NHD, float* __restrict__ heads) {
+    using G = FwdH3Geom<H>;
+    constexpr int NS = G::NS, RS = G::RS, PLANE = G::PLANE, TC = G::TCX, XPT = G::XPT;
+    constexpr int NT = H * 4, HPL = G::HPL, NW = H / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* hpl = reinterpret_cast<unsigned short*>(smem);       // [2][2 pieces][MT][RS] fp16
+    float* xbuf = reinterpret_cast<float*>(hpl + 2 * 2 * PLANE);         // [2][TC][MT][8]
+    float* kbuf = xbuf + 2 * TC * MT * 8;                                // [2][TC][MT]: keep[t + 1] of the chunk's steps
+    float* wxl = kbuf + 2 * TC * MT;                                     // [waves][4 gates][2 k-steps][64 lanes]
+    float* bl = wxl + (H / 16) * 512;                                    // [4H] b_ih + b_hh | [8] head bias
+    unsigned short* whp = reinterpret_cast<unsigned short*>(bl + 4 * H + 8);   // [2 pieces][8 heads][RS] fp16
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int j = lane & 15, kq = lane >> 4;
+    const int uw = 16 * w + j;                 // unit whose weight row this lane holds (A operand row)
+    const int uo = 16 * w + 4 * kq;            // first of this lane's four output units; its env is j
+    const int n0 = blockIdx.x * MT;
+    const int n = min(n0 + j, N - 1);
+    const bool live = n0 + j < N;
+
+    // A fragments of 16x16x32: lane (j, kq) holds k = 32 s + 8 kq .. + 7 of unit uw, per gate q and piece p
+    f16x8 wb[4][NS][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float* src = w_hh + (size_t)(q * H + uw) * H + 32 * s + 8 * kq;
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                _Float16 p0, p1;
+                split2h(v[i], p0, p1);
+                wb[q][s][0][i] = p0; wb[q][s][1][i] = p1;
+            }
+        }
+    float* const wxw = wxl + w * 512 + lane;                             // this lane's W_ih fragments: + (2 q + s) * 64
+    if (FUSE_X) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * kq + s;
+                wxw[(2 * q + s) * 64] = (k < I) ? w_ih[(size_t)(q * H + uw) * I + k] : 0.f;
+            }
+        for (int idx = threadIdx.x; idx < 4 * H; idx += NT) bl[idx] = b_ih[idx] + b_hh[idx];
+    }
+    if (heads) {                                                         // actor / critic head rows as fp16 piece planes
+        for (int idx = threadIdx.x; idx < 8 * H; idx += NT) {
+            const int hdx = idx / H, uu = idx % H;
+            _Float16 p0, p1;
+            split2h((hdx < NHD) ? w_head[(size_t)hdx * H + uu] : 0.f, p0, p1);
+            unsigned short* d = whp + hdx * RS + uu;
+            d[0] = h_bits(p0); d[HPL] = h_bits(p1);
+        }
+        if (threadIdx.x < 8) bl[4 * H + threadIdx.x] = (int)threadIdx.x < NHD ? b_head[threadIdx.x] : 0.f;
+    }
+    // heads of the h held in plane set `buf` (= h_t, UNMASKED): D[head 4kq + r][env j] = W_head h^T + b, stored to
+    // heads[env][t][NHD].  One wave does it, beside its own recurrent MFMAs of the next step.
+    auto emit_heads = [&](int buf, int t) {
+        f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb = ha;
+        const unsigned short* hrow = hpl + buf * 2 * PLANE + j * RS + 8 * kq;
+        const unsigned short* wrow = whp + (j & 7) * RS + 8 * kq;
+        auto hp = [&](int pc, int s) { return *reinterpret_cast<const f16x8*>(hrow + pc * PLANE + 32 * s); };
+        auto wp = [&](int pc, int s) { return *reinterpret_cast<const f16x8*>(wrow + pc * HPL + 32 * s); };
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            hb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp(1, s), hp(0, s), hb, 0, 0, 0);
+            hb = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp(0, s), hp(1, s), hb, 0, 0, 0);
+            ha = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp(0, s), hp(0, s), ha, 0, 0, 0);
+            asm volatile("" ::: "memory");               // one slab's fragments at a time
+        }
+        if (live && kq < 2) {
+            float* dst = heads + ((size_t)n * T + t) * NHD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < NHD) dst[4 * kq + r] = (ha[r] + H3_LO * hb[r]) + bl[4 * H + 4 * kq + r];
+        }
+    };
+    auto put_h = [&](unsigned short* plane0, const float (&hv)[4]) {     // split and park h[env j][uo .. uo+3]
+        unsigned short b[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            _Float16 p0, p1;
+            split2h(hv[r], p0, p1);
+            b[0][r] = h_bits(p0); b[1][r] = h_bits(p1);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            uint2 v;
+            v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+            v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+            *reinterpret_cast<uint2*>(plane0 + pc * PLANE + j * RS + uo) = v;
+        }
+    };
+
+    // chunk staging through registers: chunk c + 1 is loaded while chunk c runs, committed to the other buffer
+    float xr[XPT], kr = 1.f;
+    auto stage_load = [&](int t0) {
+        if (FUSE_X) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int idx = threadIdx.x + i * NT;                    // (e, tt, f) with f fastest
+                const int e = min(idx / (TC * 8), MT - 1), tt = (idx >> 3) % TC, f = idx & 7;
+                const int ne = min(n0 + e, N - 1), t = min(t0 + tt, T - 1);
+                xr[i] = (f < I) ? x[((size_t)ne * T + t) * I + f] : 0.f;
+            }
+        }
+        if (threadIdx.x < TC * MT) {
+            const int e = threadIdx.x / TC, tt = threadIdx.x % TC;
+            const int ne = min(n0 + e, N - 1), t = t0 + tt + 1;
+            kr = (keep && t < T) ? keep[(size_t)ne * T + t] : 1.f;
+        }
+    };
+    auto stage_commit = [&](int buf) {
+        if (FUSE_X) {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int idx = threadIdx.x + i * NT;
+                const int e = idx / (TC * 8), tt = (idx >> 3) % TC, f = idx & 7;
+                if (e < MT) xbuf[((buf * TC + tt) * MT + e) * 8 + f] = xr[i];
+            }
+        }
+        if (threadIdx.x < TC * MT) kbuf[(buf * TC + threadIdx.x % TC) * MT + threadIdx.x / TC] = kr;
+    };
+
+    float c_reg[4];
+    {
+        const float k0 = keep ? keep[(size_t)n * T] : 1.f;
+        const float4 cv = *reinterpret_cast<const float4*>(c0 + (size_t)n * H + uo);
+        const float4 hv4 = *reinterpret_cast<const float4*>(h0 + (size_t)n * H + uo);
+        c_reg[0] = cv.x * k0; c_reg[1] = cv.y * k0; c_reg[2] = cv.z * k0; c_reg[3] = cv.w * k0;
+        const float hv[4] = {hv4.x * k0, hv4.y * k0, hv4.z * k0, hv4.w * k0};
+        put_h(hpl, hv);
+        if (stash && I > 6 && live)                                      // h_prev of step 0 (generic wgrad path)
+            *reinterpret_cast<float4*>(stash + ((size_t)n * T) * (6 * H) + 5 * H + uo) = float4{hv[0], hv[1], hv[2], hv[3]};
+    }
+    stage_load(0);
+    stage_commit(0);
+    int cur = 0;
+    float kcur = 1.f;            // keep of the step about to run (the mask on the incoming h); h0 is masked above
+    X6_PROF_DECL;
+    lds_barrier();
+
+    const int nchunk = (T + TC - 1) / TC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int t0 = ch * TC, tc = min(TC, T - t0), xb = ch & 1;
+        if (ch + 1 < nchunk) stage_load(t0 + TC);
+        for (int tt = 0; tt < tc; ++tt) {
+            const int t = t0 + tt;
+            const size_t row = (size_t)n * T + t;
+            X6_PROF_MARK(0);
+            if (heads && w == NW - 1 && t > 0) emit_heads(cur, t - 1);   // heads of h_{t-1}, while no accumulator is live
+            // the planes hold h_{t-1} UNMASKED (the heads need it so); the episode mask k_t is a per-env scalar, so it
+            // is applied to the finished h-part of the accumulator: acc = k_t (W_hh h_{t-1}) + bias + W_ih x_t
+            f32x4 acc[4], acl[4];                                         // main products | cross products (x 2^-11)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = acl[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned short* hrow = hpl + cur * 2 * PLANE + j * RS + 8 * kq;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(hrow + 32 * s);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(hrow + PLANE + 32 * s);
+                // eight independent accumulators between dependent MFMAs
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acl[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[q][s][1], a0, acl[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[q][s][0], a0, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acl[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[q][s][0], a1, acl[q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = FUSE_X ? *reinterpret_cast<const float4*>(bl + q * H + uo)
+                                        : *reinterpret_cast<const float4*>(stash + row * (6 * H) + q * H + uo);
+                acc[q] = (acc[q] + acl[q] * H3_LO) * kcur + f32x4{v.x, v.y, v.z, v.w};
+            }
+            if (FUSE_X) {       // K = I <= 8 input projection: two exact-f32 k-steps
+                const float2 ax = *reinterpret_cast<const float2*>(&xbuf[((xb * TC + tt) * MT + j) * 8 + 2 * kq]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q) * 64], ax.x, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxw[(2 * q + 1) * 64], ax.y, acc[q], 0, 0, 0);
+                }
+            }
+            X6_PROF_DEP(acc[0][0]); X6_PROF_DEP(acc[1][1]); X6_PROF_DEP(acc[2][2]); X6_PROF_DEP(acc[3][3]);
+            X6_PROF_MARK(1);
+            const float kn = kbuf[(xb * TC + tt) * MT + j];              // keep of step t+1 (1 past the end)
+            float gi[4], gf[4], gg[4], go[4], cp[4], hh[4], hm[4], cc[4];
+            float* sp = stash + row * (6 * H) + uo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gi[r] = sigmoidf_(acc[0][r]); gf[r] = sigmoidf_(acc[1][r]); gg[r] = tanhf_(acc[2][r]);
+                cp[r] = c_reg[r];
+                cc[r] = gf[r] * cp[r] + gi[r] * gg[r];
+            }
+            if (live && stash) {
+                *reinterpret_cast<float4*>(sp) = float4{gi[0], gi[1], gi[2], gi[3]};
+                *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
+                *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
+                *reinterpret_cast<float4*>(sp + 4 * H) = float4{cp[0], cp[1], cp[2], cp[3]};
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                go[r] = sigmoidf_(acc[3][r]);
+                hh[r] = go[r] * tanhf_(cc[r]);
+                hm[r] = hh[r] * kn;
+                c_reg[r] = (t == T - 1) ? cc[r] : cc[r] * kn;            // cn is the unmasked final cell state
+            }
+            put_h(hpl + (cur ^ 1) * 2 * PLANE, hh);
             kcur = kn;
             if (live) {
                 *reinterpret_cast<float4*>(y + row * H + uo) = float4{hh[0], hh[1], hh[2], hh[3]};
@@ -1322,7 +1586,27 @@ static int launch_fwd(bool fuse, const float* x, const float* keep, const float*
                       float* y, float* hn, float* cn, float* stash, const float* w_head, const float* b_head, int NHD,
                       float* heads, bool* heads_done, hipStream_t st) {
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
-    if (!f32_mfma_requested()) {         // default: split-bf16 products on the bf16 matrix pipe (f32 accuracy)
+    if (!f32_mfma_requested() && !bf16x6_requested()) {   // default: three fp16 piece products on the matrix pipe (f32 accuracy)
+        const size_t lx = FwdH3Geom<H>::LDS;
+        static bool attr_set = false;
+        if (!attr_set) {
+            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_h3_kernel<H, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
+            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_h3_kernel<H, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
+            attr_set = true;
+        }
+        if (fuse)
+            hipLaunchKernelGGL((lstm_fwd_h3_kernel<H, true>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
+                               b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, NHD, heads);
+        else
+            hipLaunchKernelGGL((lstm_fwd_h3_kernel<H, false>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
+                               b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, NHD, heads);
+        *heads_done = heads != nullptr;
+        UAV_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!f32_mfma_requested()) {         // UAV_LSTM_BF16X6=1: the six-product bf16 split
         const size_t lx = FwdX6Geom<H>::LDS;
         static bool attr_set = false;
         if (!attr_set) {
