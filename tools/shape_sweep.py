@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Robustness sweep: random (N, T, H) shapes through rollout + one PPO gradient with the default (split-bf16) kernels and
-with the exact-f32 kernels (UAV_LSTM_F32_MFMA=1, read per call); the two gradients must agree to f32 noise and be finite."""
+"""Robustness sweep: random (N, T, H) shapes through rollout + one PPO gradient with the default (split-fp16) kernels and
+with the exact-f32 kernels (UAV_LSTM_F32_MFMA=1, read per call); the two gradients must agree to f32 noise and be finite.
+(With a handful of samples the value gradient is (V_recomputed - V_rollout), pure rounding noise of whichever forward
+produced it, so the relative test gets an absolute floor of 1e-7 / sqrt(samples).)"""
 import os
 import sys
 
@@ -44,8 +46,9 @@ def main():
         os.environ.pop("UAV_LSTM_F32_MFMA", None)
         # the rollout's own heads / stash against the recomputed forward
         hr = tr.work["heads"].reshape(n, 6) if tr._rollout_forward_valid else None
-        rel = float((gs[0] - gs[1]).norm() / (gs[1].norm() + 1e-30))
-        ok = np.isfinite(rel) and rel < 5e-5 and bool(torch.isfinite(gs[0]).all())
+        dn = float((gs[0] - gs[1]).norm())
+        rel = dn / (float(gs[1].norm()) + 1e-30)
+        ok = np.isfinite(rel) and dn <= 5e-5 * float(gs[1].norm()) + 1e-7 / np.sqrt(n) and bool(torch.isfinite(gs[0]).all())
         if hr is not None:
             okh = bool(torch.allclose(hr, heads, atol=3e-5, rtol=1e-4))
             ok = ok and okh

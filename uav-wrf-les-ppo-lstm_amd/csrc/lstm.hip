@@ -1529,6 +1529,244 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_x6k_kernel(
     }
 }
 
+// lstm_bwd_h3k_kernel: the K-split backward with the recurrent product as three fp16 MFMA products (common.h, split2h)
+// instead of the bf16 split's six: W_hh as two fp16 pieces in exactly the f32 weights' 128 VGPRs (no LDS slab), and this
+// step's gate gradients block-scaled per env by a power of two before the split (below).
+template <int H>
+struct BwdH3Geom {
+    static constexpr int NW = H / 16;
+    static constexpr int SLOT = 5 * MT * 16;                         // floats per wave in the stash ring (one slot)
+    static constexpr int SMALL = 128;                                // floats per small slot: dheads[16][6] | keep[16]
+    static constexpr size_t LDS = (NW * NW * 64 * 4 /*partials*/ + NW * SLOT + 2 * SMALL) * sizeof(float);
+};
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_bwd_h3k_kernel(
+    const float* __restrict__ keep, const float* __restrict__ stash, const float* __restrict__ w_hh,
+    const float* __restrict__ dheads, const float* __restrict__ w_head, int NH, const float* __restrict__ dhn,
+    const float* __restrict__ dcn, int N, int T, float* __restrict__ dgates, float* __restrict__ dh0,
+    float* __restrict__ dc0) {
+    using G = BwdH3Geom<H>;
+    constexpr int SLOT = G::SLOT, NW = G::NW, SMALL = G::SMALL;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* part = reinterpret_cast<f32x4*>(smem);                           // [tile m][wave w][64 lanes]
+    float* ring = smem + NW * NW * 64 * 4;                                  // [NW][SLOT]
+    float* small = ring + NW * SLOT;                                        // [2 slots][SMALL]
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int uw = 16 * w + j;                 // A row of the dy product (head weights of unit uw)
+    const int uo = 16 * w + 4 * kq;            // first of this lane's four units; its env is j
+    const int n0 = blockIdx.x * MT;
+    const int n = min(n0 + j, N - 1);
+    const bool live = n0 + j < N;
+
+    // A fragments: tile m (units 16m..16m+15), slab sb (gates 2sb, 2sb+1): lane (i = j, kq), element e holds
+    // W_hh[(2sb + e/4) H + 16w + 4kq + e%4][16m + j] -- the k order of this wave's own gate gradients
+    f16x8 wa[NW][2][2];                                                      // two fp16 pieces: the f32 weights' 128 VGPRs
+#pragma unroll
+    for (int m = 0; m < NW; ++m)
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = (2 * sb + e / 4) * H + 16 * w + 4 * kq + (e % 4);
+                _Float16 p0, p1;
+                split2h(w_hh[(size_t)k * H + 16 * m + j], p0, p1);
+                wa[m][sb][0][e] = p0; wa[m][sb][1][e] = p1;
+            }
+        }
+    float whb[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) whb[a] = (4 * a + kq < NH) ? w_head[(size_t)(4 * a + kq) * H + uw] : 0.f;
+
+    float dh_rec[4], dc_next[4];
+    {
+        const float4 a4 = dhn ? *reinterpret_cast<const float4*>(dhn + (size_t)n * H + uo) : float4{0.f, 0.f, 0.f, 0.f};
+        const float4 c4 = dcn ? *reinterpret_cast<const float4*>(dcn + (size_t)n * H + uo) : float4{0.f, 0.f, 0.f, 0.f};
+        dh_rec[0] = a4.x; dh_rec[1] = a4.y; dh_rec[2] = a4.z; dh_rec[3] = a4.w;
+        dc_next[0] = c4.x; dc_next[1] = c4.y; dc_next[2] = c4.z; dc_next[3] = c4.w;
+    }
+    const size_t srow = (size_t)n * T;
+
+    // ---- LDS-DMA (inline asm, see lstm_bwd_dma_kernel): stash gather [q][env lane/4][units 4 (lane%4) ..]
+    typedef __attribute__((address_space(3))) float lds_f;
+    const int e_d = lane >> 2, g4 = lane & 3;
+    const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)(ring + w * SLOT)));
+    const unsigned small_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)small));
+    auto issue = [&](int t) {
+        const float* src = stash + (drow + t) * (6 * H) + 16 * w + 4 * g4;
+        unsigned m0save;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0save)
+            : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(ring_base)
+            : "memory");
+    };
+    // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)].
+    // The lane's element of step 0 and its per-step stride are fixed: only `+ t * stride` is left in the loop
+    // (the division by NH used to run every step on the two waves everybody waits for).
+    const float* small_at0;
+    unsigned small_stride;
+    {
+        const int e = w * 64 + lane;
+        if (e < 16 * NH) { small_at0 = dheads + (size_t)min(n0 + e / NH, N - 1) * T * NH + e % NH; small_stride = (unsigned)NH; }
+        else if (e >= 112 && keep) { small_at0 = keep + (size_t)min(n0 + e - 112, N - 1) * T; small_stride = 1u; }
+        else { small_at0 = w_hh + (lane & 15); small_stride = 0u; }         // padding: any readable dwords
+    }
+    auto issue_small = [&](int t, int slot) {
+        const float* src = small_at0 + (size_t)((unsigned)t * small_stride);
+        const unsigned dst = small_base + (unsigned)((slot * SMALL + w * 64) * 4);
+        unsigned m0save;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(m0save) : "v"(src), "s"(dst) : "memory");
+    };
+    const bool small_wave = w < 2;
+    // vector-memory operations of this wave, in issue order (all retire in order):
+    //   prologue  ring(T-1) [small(T-1)] [small(T-2)]
+    //   step t    wait . ring(t-1) . 4 dG stores . [small(t-2)]
+    // so at the top of step t everything but the 4 stores (and one small piece) of step t+1 must have landed
+    issue(T - 1);
+    if (small_wave) {
+        issue_small(T - 1, (T - 1) & 1);
+        issue_small(T >= 2 ? T - 2 : 0, (T - 2) & 1);
+    }
+    bool first = true;
+    X6_PROF_DECL;
+    for (int t = T - 1; t >= 0; --t) {
+        X6_PROF_MARK(0);
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (small_wave) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        first = false;
+        const float* sl = ring + w * SLOT + j * 16 + 4 * kq;
+        float4 pf[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pf[q] = *reinterpret_cast<const float4*>(sl + q * 256);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the slot is in registers: refill it with step t-1
+        issue(t >= 1 ? t - 1 : 0);
+        X6_PROF_MARK(1);
+        lds_barrier();           // b2: the partials of step t+1 have been summed by everyone; small image of step t landed
+        X6_PROF_MARK(2);
+        const float* sm = small + (t & 1) * SMALL;
+        f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
+        {
+            const float d0 = (kq < NH) ? sm[j * NH + kq] : 0.f;
+            const float d1 = (4 + kq < NH) ? sm[j * NH + 4 + kq] : 0.f;
+            dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(whb[0], d0, dyacc, 0, 0, 0);
+            dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(whb[1], d1, dyacc, 0, 0, 0);
+        }
+        const float kp = keep ? sm[112 + j] : 1.f;                           // keep[env j][t]
+        const float gi[4] = {pf[0].x, pf[0].y, pf[0].z, pf[0].w}, gf[4] = {pf[1].x, pf[1].y, pf[1].z, pf[1].w};
+        const float gg[4] = {pf[2].x, pf[2].y, pf[2].z, pf[2].w}, go[4] = {pf[3].x, pf[3].y, pf[3].z, pf[3].w};
+        const float cp[4] = {pf[4].x, pf[4].y, pf[4].z, pf[4].w};
+        float dg[4][4];                                                      // [gate][unit r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = dyacc[r] + dh_rec[r];
+            const float c = gf[r] * cp[r] + gi[r] * gg[r];
+            const float tch = tanhf_(c);
+            const float dc = dh * go[r] * (1.0f - tch * tch) + dc_next[r];
+            dg[0][r] = dc * gg[r] * gi[r] * (1.0f - gi[r]);
+            dg[1][r] = dc * cp[r] * gf[r] * (1.0f - gf[r]);
+            dg[2][r] = dc * gi[r] * (1.0f - gg[r] * gg[r]);
+            dg[3][r] = dh * tch * go[r] * (1.0f - go[r]);
+            dc_next[r] = dc * gf[r] * kp;
+        }
+        // Gate gradients span many binades, fp16 does not: each env's 64 values of this wave are scaled by a power of two
+        // that puts their largest magnitude in [2^13, 2^14) (exact), and the env's column of the partial tiles -- it sits
+        // in these same lanes -- is scaled back.  max over the lane's 16 values, then over the four kq rows of env j with
+        // the two gfx950 row-swap instructions.
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(dg[q][r]));
+        {
+            const unsigned u = __builtin_bit_cast(unsigned, mx);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+            const unsigned v = __builtin_bit_cast(unsigned, mx);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+        }
+        int ex = 14 - __builtin_amdgcn_frexp_expf(mx);                      // mx = f 2^e, f in [0.5, 1)  ->  mx 2^ex in [2^13, 2^14)
+        ex = mx > 0.f ? min(max(ex, -100), 100) : 0;
+        const float unscale = __builtin_amdgcn_ldexpf(1.0f, -ex);
+        // this wave's 64 gate gradients as B fragments: slab sb = gates 2sb, 2sb+1; element e = (gate 2sb + e/4, unit e%4)
+        f16x8 bp[2][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                _Float16 p0, p1;
+                split2h(__builtin_amdgcn_ldexpf(dg[q][r], ex), p0, p1);
+                bp[q >> 1][0][4 * (q & 1) + r] = p0; bp[q >> 1][1][4 * (q & 1) + r] = p1;
+            }
+            if (live)
+                *reinterpret_cast<float4*>(dgates + (srow + t) * (4 * H) + q * H + uo) =
+                    float4{dg[q][0], dg[q][1], dg[q][2], dg[q][3]};
+        }
+        X6_PROF_DEP(bp[1][1]); X6_PROF_DEP(bp[0][0]);
+        X6_PROF_MARK(3);
+        // partial dh^T tiles: D_m[unit 16m + 4kq + r][env j] over this wave's K range
+#pragma unroll
+        for (int m = 0; m < NW; ++m) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[m][sb][1], bp[sb][0], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[m][sb][0], bp[sb][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[m][sb][0], bp[sb][1], a1, 0, 0, 0);
+            }
+            part[(m * NW + w) * 64 + lane] = (a0 + a1 * H3_LO) * unscale;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        X6_PROF_MARK(4);
+        lds_barrier();           // b1: all partials written; nobody reads the small image of step t any more
+        X6_PROF_MARK(5);
+        if (small_wave) issue_small(t >= 2 ? t - 2 : 0, t & 1);
+        f32x4 sum = part[(w * NW) * 64 + lane];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) sum += part[(w * NW + ww) * 64 + lane];      // fixed order: deterministic
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh_rec[r] = sum[r] * kp;
+        X6_PROF_DEP(dh_rec[3]);
+        X6_PROF_MARK(6);
+    }
+    X6_PROF_FLUSH8();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the clamped tail DMAs before the LDS is released
+    if (live) {
+        if (dh0) *reinterpret_cast<float4*>(dh0 + (size_t)n * H + uo) = float4{dh_rec[0], dh_rec[1], dh_rec[2], dh_rec[3]};
+        if (dc0) *reinterpret_cast<float4*>(dc0 + (size_t)n * H + uo) = float4{dc_next[0], dc_next[1], dc_next[2], dc_next[3]};
+    }
+}
+
+template <int H>
+static int launch_bwd_h3k(const float* keep, const float* stash, const float* w_hh, const float* dheads,
+                          const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
+                          float* dh0, float* dc0, hipStream_t st) {
+    const dim3 grid((N + MT - 1) / MT), block(H * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_h3k_kernel<H>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdH3Geom<H>::LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((lstm_bwd_h3k_kernel<H>), grid, block, BwdH3Geom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
+                       NH, dhn, dcn, N, T, dgates, dh0, dc0);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int H>
 static int launch_bwd_x6k(const float* keep, const float* stash, const float* w_hh, const float* dheads,
                           const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
@@ -1663,7 +1901,13 @@ __global__ void add2_kernel(const float* a0, const float* a1, float* b, int n) {
 static int lstm_bwd_seq(const float* keep, const float* stash, const float* w_hh, const float* dy,
                         const float* dheads, const float* w_head, int NH, const float* dhn, const float* dcn, int N,
                         int T, int H, float* dgates, float* dh0, float* dc0, hipStream_t st) {
-    if (dheads && NH <= 7 && !f32_mfma_requested() && !getenv("UAV_BWD_NSPLIT")) {   // the PPO path: split-bf16, K split over waves
+    if (dheads && NH <= 7 && !f32_mfma_requested() && !bf16x6_requested() && !getenv("UAV_BWD_NSPLIT")) {   // the PPO path: split-fp16, K split over waves
+        switch (H) {
+            case 64: return launch_bwd_h3k<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+            case 128: return launch_bwd_h3k<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
+        }
+    }
+    if (dheads && NH <= 7 && !f32_mfma_requested() && !getenv("UAV_BWD_NSPLIT")) {   // UAV_LSTM_BF16X6=1: split-bf16, K split over waves
         switch (H) {
             case 64: return launch_bwd_x6k<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
             case 128: return launch_bwd_x6k<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
