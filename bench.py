@@ -36,7 +36,7 @@ CONFIGS = {   # BASELINE.json configs (per-GPU env count; SURVEY 8 shorthand)
     "c5": dict(num_envs=4096, horizon=256, hidden=256, layers=2, variant="v2.1", trend_k=2),
 }
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s (the split-bf16 kernels issue 6 products)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA ~2.5 PFLOP/s (the split-fp16 kernels issue 3 products)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -173,8 +173,8 @@ def main():
     env_steps = N * T * world * args.steps
     value = env_steps / dt
     opt_steps = tr.hp["epochs"] * tr.num_minibatches
-    # roofline of the dominant kernel, the BPTT sequence kernel lstm_bwd_x6k_kernel.  With its dh = dG W_hh product
-    # on the bf16 matrix pipe (3-way operand split, f32 accuracy) it sits under the HBM roof, not the MFMA one:
+    # roofline of the dominant kernel, the BPTT sequence kernel lstm_bwd_h3k_kernel.  With its dh = dG W_hh product
+    # on the fp16 matrix pipe (two-piece operand split, three products, f32 accuracy) it sits under the HBM roof, not the MFMA one:
     # algorithmic bytes per (env, step) = 5H stash values read + 4H gate gradients written + NH dheads + keep,
     # x N*T per launch (DESIGN.md "Kernels"), over its average launch duration timed live with HIP events on the
     # launch stream.  `traffic` = HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction +
@@ -189,23 +189,24 @@ def main():
         sec = bwd["avg_ms"] * 1e-3
         ach = bytes_bwd / sec / 1e9
         traffic = None
-        kname = "lstm_bwd_x6k_kernel<%d>" % H
-        tf = os.path.join(ROOT, "profiles", "r01_h_hbm_traffic_pmc.json")
+        kname = "lstm_bwd_h3k_kernel<%d>" % H
+        tf = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic_pmc.json")
         if args.config == "c3" and os.path.exists(tf):
             traffic = json.load(open(tf)).get(kname, {}).get("hbm_total_bytes")
         roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                     "frac": ach / PEAK_HBM_GBPS, "traffic": traffic, "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
                     "algorithmic_bytes": bytes_bwd,
-                    "mfma": {"f32_equiv_tflops": fl_bwd / sec / 1e12, "executed_bf16_tflops": 6 * fl_bwd / sec / 1e12,
-                             "bf16_peak_tflops": PEAK_BF16_MFMA_TFLOPS, "frac": 6 * fl_bwd / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
+                    "mfma": {"f32_equiv_tflops": fl_bwd / sec / 1e12, "executed_fp16_tflops": 3 * fl_bwd / sec / 1e12,
+                             "fp16_peak_tflops": PEAK_BF16_MFMA_TFLOPS, "frac": 3 * fl_bwd / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
     out = {
         "metric": f"env-steps/sec (rollout + GAE + {tr.hp['epochs']}-epoch PPO update), {N} envs x {T} T per GPU, LSTM h={H}",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
-        "arithmetic": "f32 results throughout; the LSTM matrix products are evaluated as six bf16 piece products per f32 "
-                      "product (exact 3-way operand split) with f32 accumulation -- same error vs f64 as the exact-f32 MFMA "
-                      "chain (tests/test_gpu_lstm.py::test_split_bf16_kernels_have_f32_accuracy); env arithmetic in f64",
+        "arithmetic": "f32 results throughout; the recurrent LSTM products are evaluated as three fp16 piece products per f32 "
+                      "product (two-piece operand split carrying 24 bits, gradients block-scaled by powers of two), the weight "
+                      "gradients as six bf16 piece products, all with f32 accumulation -- error vs f64 no larger than the "
+                      "exact-f32 MFMA chain's (tests/test_gpu_lstm.py::test_split_kernels_have_f32_accuracy); env arithmetic in f64",
         "config": {"workload": f"BASELINE config {args.config.upper()}: PPO{cfg['variant'].upper()}, {N} envs/GPU x T={T}, "
                                f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs {6 + cfg.get('trend_k', 0)}, "
                                f"5 actions, reference_exact GAE, {tr.hp['epochs']} epochs x {tr.num_minibatches} minibatch "

@@ -130,11 +130,18 @@ def test_lstm_generic_hidden_sizes(ops, T, N, I, H):
         _close(g[k], want)
 
 
+@pytest.mark.parametrize("split", ["fp16x3", "bf16x6"])
 @pytest.mark.parametrize("N,T,H", [(64, 32, 128), (128, 16, 64), (48, 64, 128)])
-def test_split_bf16_kernels_have_f32_accuracy(ops, N, T, H, monkeypatch):
-    """The default LSTM kernels multiply on the bf16 matrix pipe (3-way operand split, six products).  Claim: the
-    result is an f32 computation -- against an f64 LSTM their error is that of the exact-f32-MFMA kernels
-    (UAV_LSTM_F32_MFMA=1 selects those), for forward, backward and weight gradients (shapes with full 32-row slabs)."""
+def test_split_kernels_have_f32_accuracy(ops, N, T, H, split, monkeypatch):
+    """The default LSTM kernels multiply on the 16-bit matrix pipe: forward / backward with a two-piece fp16 operand split
+    and three products (common.h split2h), the weight gradients -- and everything with UAV_LSTM_BF16X6=1 -- with a
+    three-piece bf16 split and six products.  Claim: the result is an f32 computation -- against an f64 LSTM their error
+    is that of the exact-f32-MFMA kernels (UAV_LSTM_F32_MFMA=1 selects those), for forward, backward and weight
+    gradients (shapes with full 32-row slabs)."""
+    if split == "bf16x6":
+        monkeypatch.setenv("UAV_LSTM_BF16X6", "1")
+    else:
+        monkeypatch.delenv("UAV_LSTM_BF16X6", raising=False)
     torch.manual_seed(N + T)
     I, A = 6, 6
     ref = torch.nn.LSTM(I, H, 1).double()
@@ -169,9 +176,39 @@ def test_split_bf16_kernels_have_f32_accuracy(ops, N, T, H, monkeypatch):
     monkeypatch.setenv("UAV_LSTM_F32_MFMA", "1")
     e_f32 = errs(run())
     monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    monkeypatch.delenv("UAV_LSTM_BF16X6", raising=False)
     for k in want:
         assert e_x6[k] < 5e-6, (k, e_x6)                                 # f32-level agreement with the f64 reference
         assert e_x6[k] <= 2.0 * e_f32[k] + 2e-7, (k, e_x6[k], e_f32[k])   # ... and no worse than the exact-f32 MFMA chain
+
+
+@pytest.mark.parametrize("H", [128, 64])
+def test_split_fp16_backward_keeps_f32_accuracy_over_40_decades(ops, H):
+    """fp16 has 5 exponent bits, gradients do not care: the backward scales each env's gate gradients by a power of two
+    per step before the split.  Envs whose loss gradients differ by up to 1e25 (and vary by 1e6 along their own
+    sequence) must each come out with f32 relative accuracy -- measured per env against an f64 LSTM."""
+    torch.manual_seed(H)
+    N, T, I, A = 40, 24, 6, 6
+    ref = torch.nn.LSTM(I, H, 1).double()
+    w_ih, w_hh, b_ih, b_hh = [p.detach().clone().requires_grad_(True) for p in ref.parameters()]
+    x = torch.randn(T, N, I, dtype=torch.float64)
+    h0 = (torch.randn(N, H, dtype=torch.float64) * 0.3).requires_grad_(True)
+    c0 = (torch.randn(N, H, dtype=torch.float64) * 0.3).requires_grad_(True)
+    w_head = torch.randn(A, H, dtype=torch.float64) * 0.2
+    env_scale = 10.0 ** torch.linspace(-25, 0, N, dtype=torch.float64)
+    time_scale = 10.0 ** (-6.0 * torch.rand(T, 1, dtype=torch.float64))
+    dheads = torch.randn(T, N, A, dtype=torch.float64) * env_scale[None, :, None] * time_scale[:, :, None]
+    y, hn, cn = po.lstm_layer_forward(x, h0, c0, w_ih, w_hh, b_ih, b_hh, None)
+    ((y @ w_head.T) * dheads).sum().backward()
+    d = lambda t: t.detach().float().to(DEV).contiguous()
+    xg = d(x.transpose(0, 1))
+    yg, _, _, stash = ops.lstm_fwd(xg, None, d(h0), d(c0), d(w_ih), d(w_hh), d(b_ih), d(b_hh))
+    g = ops.lstm_bwd(xg, None, stash, d(w_ih), d(w_hh), yg, d(h0), dheads=d(dheads.transpose(0, 1)), w_head=d(w_head))
+    for k, want in (("dh0", h0.grad), ("dc0", c0.grad)):
+        got = g[k].cpu().double()
+        rel = (got - want).abs().amax(1) / want.abs().amax(1)                 # per env, against its own magnitude
+        assert float(rel.max()) < 5e-6, (k, rel)
+        assert float(want.abs().amax(1).min()) < 1e-20 < 1e-4 < float(want.abs().amax(1).max())   # the span is real
 
 
 @pytest.mark.parametrize("N,T,I,H", [(37, 21, 6, 128), (16, 9, 6, 64), (5, 1, 6, 128), (7, 6, 6, 256), (9, 12, 64, 128)])

@@ -11,9 +11,11 @@
 //   * the i,f,g,o pre-activations of one (env, unit) land in ONE lane's accumulators, so the gate pointwise and the
 //     cell state never leave registers; h_t / the gate gradients are exchanged through LDS, one or two barriers a step.
 // Kernel families in this file (dispatch: launch_fwd, lstm_bwd_seq):
-//   DEFAULT  lstm_fwd_x6_kernel, lstm_bwd_x6k_kernel (and its predecessor lstm_bwd_x6_kernel): the matrix products on
-//            the bf16 pipe at f32 accuracy (three-piece operand split, common.h), weights-as-A orientation (a lane owns
-//            one env and four consecutive units: dwordx4 stores), stash by LDS-DMA in the backward;
+//   DEFAULT  lstm_fwd_h3_kernel, lstm_bwd_h3k_kernel: the matrix products on the fp16 pipe at f32 accuracy (two-piece
+//            operand split, three products, common.h split2h; gate gradients block-scaled per env), weights-as-A
+//            orientation (a lane owns one env and four consecutive units: dwordx4 stores), stash by LDS-DMA in the backward;
+//   BF16 SPLIT lstm_fwd_x6_kernel, lstm_bwd_x6k_kernel (and its predecessor lstm_bwd_x6_kernel): the same kernels with a
+//            three-piece bf16 split and six products (no range limits, twice the matrix work); UAV_LSTM_BF16X6=1;
 //   EXACT-F32 lstm_fwd_kernel, lstm_bwd_kernel (plain dy; stacked layers), lstm_bwd_dma_kernel: v_mfma_f32_16x16x4_f32
 //            with 128 weight VGPRs per lane; selected by UAV_LSTM_F32_MFMA=1 and for the plain-dy backward.
 //   (A half-step stagger of waves 4-7 against 0-3 was built and measured on the exact-f32 forward: no gain,
@@ -39,7 +41,7 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
                      float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
-// UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split-bf16 ones)
+// UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split ones)
 static bool f32_mfma_requested() { return getenv("UAV_LSTM_F32_MFMA") != nullptr; }   // read per call: tests toggle it
 static bool bf16x6_requested() { return getenv("UAV_LSTM_BF16X6") != nullptr; }        // the predecessor of the fp16 split
 constexpr int TC = 32;      // time steps staged per chunk
