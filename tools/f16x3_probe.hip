@@ -107,7 +107,7 @@ int main() {
     float *dA, *dB, *dC;
     hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&dC, 1024);
     const char* names[4] = {"f32 mfma", "bf16 x6", "fp16 x3", "fp16 x4"};
-    for (int kind = 0; kind < 2; ++kind) {
+    for (int kind = 0; kind < 3; ++kind) {
         double emax[4] = {0, 0, 0, 0}, esq[4] = {0, 0, 0, 0}, mag2 = 0;
         long cnt = 0;
         srand(7 + kind);
@@ -116,11 +116,12 @@ int main() {
             for (auto& v : A) v = (float)((urand() * 2 - 1) * 0.09);                       // weights
             for (auto& v : B) {
                 if (kind == 0) v = (float)(urand() * 2 - 1);                               // h
-                else v = (float)((urand() * 2 - 1) * 1e-6 * exp2(-20.0 * urand() * urand()));  // gradients, ~20 binades
+                else if (kind == 1) v = (float)((urand() * 2 - 1) * 1e-6 * exp2(-20.0 * urand() * urand()));  // gradients, ~20 binades
+                else v = (float)((urand() * 2 - 1) * 3e-5);       // all below fp16's smallest normal (6.1e-5), NOT scaled: subnormal pieces
                 bmax = fmaxf(bmax, fabsf(v));
             }
             int e; frexpf(bmax, &e);
-            const float bscale = kind == 0 ? 1.0f : ldexpf(1.0f, 14 - e);                  // max |B| -> [2^13, 2^14)
+            const float bscale = kind != 1 ? 1.0f : ldexpf(1.0f, 14 - e);                  // max |B| -> [2^13, 2^14)
             hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
             hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
             std::vector<double> ref(256), mag(256);
@@ -142,7 +143,8 @@ int main() {
             cnt += 256;
         }
         (void)mag2;
-        printf("%s operands, K=%d, %ld outputs: error / sqrt(sum (a b)^2)\n", kind == 0 ? "LSTM-like" : "gradient-like (block-scaled)", K, cnt);
+        printf("%s operands, K=%d, %ld outputs: error / sqrt(sum (a b)^2)\n",
+               kind == 0 ? "LSTM-like" : kind == 1 ? "gradient-like (block-scaled)" : "B below fp16's normal range, unscaled (do the MFMAs honour fp16 subnormals?)", K, cnt);
         for (int mode = 0; mode < 4; ++mode)
             printf("  %-9s max %.3e  rms %.3e\n", names[mode], emax[mode], sqrt(esq[mode] / cnt));
     }
