@@ -190,7 +190,7 @@ def main():
         ach = bytes_bwd / sec / 1e9
         traffic = None
         kname = "lstm_bwd_h3k_kernel<%d>" % H
-        tf = os.path.join(ROOT, "profiles", "r01_i_hbm_traffic_pmc.json")
+        tf = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic_pmc.json")
         if args.config == "c3" and os.path.exists(tf):
             traffic = json.load(open(tf)).get(kname, {}).get("hbm_total_bytes")
         roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -204,8 +204,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
         "arithmetic": "f32 results throughout; the recurrent LSTM products are evaluated as three fp16 piece products per f32 "
-                      "product (two-piece operand split carrying 24 bits, gradients block-scaled by powers of two), the weight "
-                      "gradients as six bf16 piece products, all with f32 accumulation -- error vs f64 no larger than the "
+                      "product (two-piece operand split carrying 24 bits, gradients block-scaled by powers of two), weight gradients "
+                      "included, all with f32 accumulation -- error vs f64 no larger than the "
                       "exact-f32 MFMA chain's (tests/test_gpu_lstm.py::test_split_kernels_have_f32_accuracy); env arithmetic in f64",
         "config": {"workload": f"BASELINE config {args.config.upper()}: PPO{cfg['variant'].upper()}, {N} envs/GPU x T={T}, "
                                f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs {6 + cfg.get('trend_k', 0)}, "

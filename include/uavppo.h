@@ -178,7 +178,11 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
  * dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev with Hprev[n][t] = y[n][t-1]*keep[n][t]
  * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh) and -- when dheads != NULL (top layer) --
  * dw_head [n_heads][H] = dheads^T y.  dx [N][T][I] = dG W_ih when non-NULL.  y [N][T][H] is this
- * layer's forward output.  I > 6 (stacked layers) takes generic split-K GEMMs and needs `stash`. */
+ * layer's forward output.  I > 6 (stacked layers) takes generic split-K GEMMs and needs `stash`.
+ * Range note: the default kernels of uav_lstm_fwd / _bwd / _wgrad / uav_rollout evaluate their matrix products as fp16
+ * piece products at f32 accuracy (csrc/common.h, split2h); they assume |w| < 65504 for the recurrent and head weights and,
+ * in the I <= 6 weight-gradient kernel, |x| < 64 (observations are O(1)).  UAV_LSTM_BF16X6=1 selects bf16 piece products
+ * (f32's exponent range, twice the matrix work), UAV_LSTM_F32_MFMA=1 the exact-f32 MFMA kernels. */
 int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* y,
                    const float* stash, const float* dgates, const float* w_ih, const float* dheads,
                    int n_heads, int N, int T, int I, int H, float* dw_ih, float* dw_hh, float* db,

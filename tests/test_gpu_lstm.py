@@ -265,3 +265,56 @@ def test_lstm_bwd_fused_path_fuzz_against_dy_path(ops):
             a, bb = g2[k].double().cpu(), g1[k].double().cpu()
             scale = bb.abs().max().item() + 1e-12
             assert (a - bb).abs().max().item() <= 2e-5 * max(scale, 1.0) + 1e-4 * scale, (case, N, T, H, k)
+
+
+@pytest.mark.parametrize("H", [128, 64])
+def test_split_fp16_weight_gradients_over_a_wide_dynamic_range(ops, H):
+    """The weight-gradient kernel's fp16 split keeps ONE accumulator per tile (unscaled residuals) under a running
+    power-of-two scale PER GATE ROW that is lowered, and that row of the accumulators rescaled, when larger gradients
+    arrive.  Checked against f64 sums: (a) gate rows up to 2^31 below the largest row of their wave all come out at f32
+    relative accuracy, (c) gradients that grow by 2^40 along the samples (many rescales) and (d) that start with all-zero
+    slabs are handled.  (A single scale per wave, tried first, left rows 2^24 below the largest at 6e-5 and rows 2^31
+    below at 1e-2 of their own magnitude.)"""
+    torch.manual_seed(H + 1)
+    N, T, I = 32, 64, 6
+    g = torch.Generator().manual_seed(H)
+    x = torch.rand(N, T, I, generator=g, dtype=torch.float64)
+    y = torch.rand(N, T, H, generator=g, dtype=torch.float64) * 2 - 1
+    h0 = torch.rand(N, H, generator=g, dtype=torch.float64) * 2 - 1
+    keep = (torch.rand(N, T, generator=g) > 0.1).double()
+    dheads = torch.randn(N, T, 6, generator=g, dtype=torch.float64) * 1e-3
+    hprev = torch.cat([h0[:, None], y[:, :-1]], 1) * keep[..., None]
+    stash = torch.zeros(N, T, 6 * H)                                         # the I <= 6 fast path does not read it
+    d = lambda t: t.float().to(DEV).contiguous()
+
+    def check(dg, tag, row_tol):
+        want_hh = torch.einsum("ntm,ntu->mu", dg, hprev)
+        want_ih = torch.einsum("ntm,nti->mi", dg, x)
+        want_b = dg.sum((0, 1))
+        got = ops.lstm_wgrad(d(x), d(keep), d(h0), d(y), stash.to(DEV), d(dg), torch.zeros(4 * H, I, device=DEV), dheads=d(dheads))
+        dgf, hpf, xf = dg.float().double(), hprev.float().double(), x.float().double()      # what the kernel is given
+        want_hh, want_ih, want_b = (torch.einsum("ntm,ntu->mu", dgf, hpf), torch.einsum("ntm,nti->mi", dgf, xf), dgf.sum((0, 1)))
+        big = float(want_hh.abs().max())
+        for name, w_, g_ in (("dw_hh", want_hh, got["dw_hh"]), ("dw_ih", want_ih, got["dw_ih"])):
+            err = (g_.cpu().double() - w_).abs()
+            assert float(err.max()) <= 5e-7 * float(w_.abs().max()), (tag, name, float(err.max()), big)
+            rel = err.amax(1) / w_.abs().amax(1).clamp_min(1e-300)            # per gate row, against its own magnitude
+            for lo, hi, tol in row_tol:
+                assert float(rel[lo:hi].max()) < tol, (tag, name, lo, hi, float(rel[lo:hi].max()))
+        # the bias gradient is a single signed sum per row: measured against the sum of magnitudes (no cancellation)
+        errb = (got["db"].cpu().double() - want_b).abs() / dgf.abs().sum((0, 1)).clamp_min(1e-300)
+        assert float(errb.max()) < 3e-7, (tag, "db", float(errb.max()))
+        want_head = torch.einsum("nta,ntu->au", dheads.float().double(), y.float().double())
+        assert float((got["dw_head"].cpu().double() - want_head).abs().max()) < 3e-6 * float(want_head.abs().max())
+
+    base = torch.randn(N, T, 4 * H, generator=g, dtype=torch.float64) * 1e-5
+    # (a)+(b): within every wave's 64 gate rows, row r is scaled by 2^-(r % 32) ... 2^-31
+    scale = 2.0 ** -(torch.arange(4 * H) % 32).double()
+    check(base * scale, "rows", [(0, 4 * H, 5e-6)])          # every row has its own scale: 31 binades below the largest changes nothing
+    # (c): magnitudes growing by 2^40 over the row index (n, t) -> the running scale is lowered again and again
+    grow = 2.0 ** (40.0 * torch.arange(N * T).double() / (N * T) - 40.0).reshape(N, T, 1)
+    check(base * grow, "growing", [(0, 4 * H, 5e-6)])
+    # (d): the first quarter of the rows is exactly zero
+    z = base.clone()
+    z[: N // 4] = 0.0
+    check(z, "zeros first", [(0, 4 * H, 5e-6)])

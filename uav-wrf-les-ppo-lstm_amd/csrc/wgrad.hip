@@ -575,6 +575,300 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_x6_kernel(
     for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
 }
 
+// ------------------------------------------------------------------------------ split-fp16 variant
+// lstm_wgrad_x6_kernel with the gate-gradient products as THREE fp16 MFMA products (common.h, split2h) instead of six bf16
+// ones.  Differences from the forward / backward kernels' use of the split, forced by the 37 accumulator tiles per wave:
+// the residual pieces are kept UNscaled (a = p0 + p1, p1 = fp16(a - p0)) so that main and cross products can share one
+// accumulator, and both operands are block-scaled up by powers of two so that those residuals stay in fp16's normal
+// range -- [Hprev | x, 1] by 2^10 (|h| < 1; |x| < 64 is assumed), dG by a running scale per gate row (below).
+// The head tile (dheads^T Y, one of 37) stays on the bf16 split.
+constexpr float WGH_BSCALE = 1024.0f;
+
+template <int H>
+struct WGH {
+    static constexpr int NW = H / 16, NT = H * 4;
+    static constexpr int NT_ = H / 16 + 1, NC = H + 16;
+    static constexpr int KP = KS6 + 8;
+    static constexpr int BPL = NC * KP, YPL = H * KP, DPL = 16 * KP;
+    static constexpr int BUF = 2 * BPL + 3 * (YPL + DPL);            // 16-bit elements per buffer
+    static constexpr size_t LDS = 2 * BUF * sizeof(unsigned short);
+    static constexpr int XV = 16 * KS6 / NT;
+    static constexpr int DV = (8 * KS6 + NT - 1) / NT;
+};
+
+__device__ __forceinline__ void split2u(float a, _Float16& p0, _Float16& p1) {
+    p0 = (_Float16)a;
+    p1 = (_Float16)(a - (float)p0);
+}
+__device__ __forceinline__ void split8u(const float (&v)[8], f16x8& p0, f16x8& p1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 a, b;
+        split2u(v[i], a, b);
+        p0[i] = a; p1[i] = b;
+    }
+}
+
+template <int H, bool HEADS>
+__global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
+    const float* __restrict__ dgates, const float* __restrict__ y, const float* __restrict__ keep,
+    const float* __restrict__ h0, const float* __restrict__ x, int I, const float* __restrict__ dheads, int NH,
+    int N, int T, int rows_per_block, float* __restrict__ slabs) {
+    using G = WGH<H>;
+    constexpr int NT_ = G::NT_, KP = G::KP, BPL = G::BPL, YPL = G::YPL, DPL = G::DPL, BUF = G::BUF, NT = G::NT;
+    constexpr int XV = G::XV, DV = G::DV, NW = G::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = w >= NW / 2;                 // waves w and w + NW/2 share a SIMD
+    const int j = lane & 15, kq = lane >> 4;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int nslab = rows_per_block / KS6;
+
+    // staging coordinates: column c, row group rg (wave-uniform) -> rows 8 rg .. 8 rg + 7 of the slab
+    const int c = tid % H;
+    const int rg = __builtin_amdgcn_readfirstlane(tid / H);
+
+    f32x4 acc[4][NT_];
+    f32x4 acch = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // heads 8..15 of the dheads^T image are never written: zero both buffers once
+    for (int idx = tid; idx < 2 * 3 * DPL; idx += NT) {
+        const int b = idx / (3 * DPL), rem = idx % (3 * DPL);
+        sm16[b * BUF + 2 * BPL + 3 * YPL + rem] = 0;
+    }
+
+    // ---- A operand: raw dG values of this lane, [tile mi][row 8 kq + e]; tile 2p+m <-> gate rows 64w + 32p + 2i + m
+    float raw[4][8];
+    auto load_a = [&](int slab, int pair) {
+        slab = slab < nslab ? slab : nslab - 1;                       // clamped: the tail issues harmless reloads
+        // 32-bit element offsets from the (scalar) base pointer: the launch checks N*T*4H < 2^30
+        const unsigned off = (unsigned)(r_begin + slab * KS6 + 8 * kq) * (4 * H) + 64 * w + 32 * pair + 2 * j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float2 t2 = *reinterpret_cast<const float2*>(dgates + (off + (unsigned)e * (4 * H)));
+            raw[2 * pair][e] = t2.x;
+            raw[2 * pair + 1][e] = t2.y;
+        }
+    };
+    // ---- B / Y / x / dheads staging registers (one slab ahead)
+    constexpr int NV = HEADS ? 9 : 8;                                // Y = the same rows of y, shifted by one
+    float v[NV], hz = 0.f, xv[XV], dv[DV];
+    float kv = 1.f;                                                  // keep[q0 + (lane & 7)]: read back by v_readlane
+    int i_start = -1;                                                // row of this thread's group with t == 0
+    auto load_b = [&](int slab) {
+        slab = slab < nslab ? slab : nslab - 1;
+        const int q0 = r_begin + slab * KS6 + 8 * rg;                 // first row of this thread's group (uniform)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int rr = q0 - 1 + i;
+            v[i] = y[(unsigned)(rr < 0 ? 0 : rr) * H + c];
+        }
+        const int tq = q0 % T;                                        // T >= 8: at most one sequence start in 8 rows
+        i_start = (tq == 0) ? 0 : (tq + 7 >= T ? T - tq : -1);
+        if (i_start >= 0) hz = h0[(unsigned)((q0 + i_start) / T) * H + c];
+        // a vector load, NOT a scalar one: s_load returns through lgkmcnt, so every LDS fragment wait behind it
+        // would also wait out its HBM latency
+        kv = keep ? keep[q0 + (lane & 7)] : 1.f;
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int idx = tid + k * NT, q = idx >> 4, f = idx & 15;
+            const unsigned r = (unsigned)(r_begin + slab * KS6 + q);
+            xv[k] = (f < I) ? x[r * I + f] : (f == 6 ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < DV; ++k) {
+            const int idx = tid + k * NT, q = idx >> 3, a = idx & 7;
+            const unsigned r = (unsigned)(r_begin + slab * KS6 + (q < KS6 ? q : 0));
+            dv[k] = (HEADS && a < NH && q < KS6) ? dheads[r * NH + a] : 0.f;
+        }
+    };
+    auto commit_b = [&](int buf) {
+        unsigned short* bp = sm16 + buf * BUF;
+        unsigned short* yp = bp + 2 * BPL;
+        unsigned short* dp = yp + 3 * YPL;
+        float hp[8], yy[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float kpi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, kv), i));
+            hp[i] = ((i == i_start) ? hz : v[i]) * (kpi * WGH_BSCALE);
+            yy[i] = HEADS ? v[i + 1 < NV ? i + 1 : 0] : 0.f;
+        }
+        {
+            f16x8 q0, q1;
+            split8u(hp, q0, q1);
+            *reinterpret_cast<f16x8*>(bp + c * KP + 8 * rg) = q0;
+            *reinterpret_cast<f16x8*>(bp + BPL + c * KP + 8 * rg) = q1;
+        }
+        if (HEADS) {
+            bf16x8 p0, p1, p2;
+            split8(yy, p0, p1, p2);
+            *reinterpret_cast<bf16x8*>(yp + c * KP + 8 * rg) = p0;
+            *reinterpret_cast<bf16x8*>(yp + YPL + c * KP + 8 * rg) = p1;
+            *reinterpret_cast<bf16x8*>(yp + 2 * YPL + c * KP + 8 * rg) = p2;
+        }
+#pragma unroll
+        for (int k = 0; k < XV; ++k) {
+            const int idx = tid + k * NT, q = idx >> 4, f = idx & 15;
+            _Float16 a, b;
+            split2u(xv[k] * WGH_BSCALE, a, b);
+            unsigned short* d = bp + (H + f) * KP + q;
+            d[0] = h_bits(a);
+            d[BPL] = h_bits(b);
+        }
+        if (HEADS) {
+#pragma unroll
+            for (int k = 0; k < DV; ++k) {
+                const int idx = tid + k * NT, q = idx >> 3, a = idx & 7;
+                if (q < KS6) {
+                    __bf16 pa, pb, pc;
+                    split3(dv[k], pa, pb, pc);
+                    unsigned short* d = dp + a * KP + q;
+                    d[0] = __builtin_bit_cast(unsigned short, pa);
+                    d[DPL] = __builtin_bit_cast(unsigned short, pb);
+                    d[2 * DPL] = __builtin_bit_cast(unsigned short, pc);
+                }
+            }
+        }
+    };
+    // three fp16 piece products into one accumulator (unscaled residuals), smallest first
+    auto mac3 = [&](f32x4& d, const f16x8 (&a)[2], const f16x8 (&b)[2]) {
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], d, 0, 0, 0);
+    };
+    // six bf16 piece products (the head tile: dheads^T Y), smallest first
+    auto mac6 = [&](f32x4& d, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], d, 0, 0, 0);
+    };
+    // A pieces of the current tile pair.  dG spans many binades, fp16 does not: every gate ROW keeps its own power-of-two
+    // scale (lane (i, kq) holds row i of tiles 2p, 2p+1; the four kq lanes agree on it through the two gfx950 row swaps),
+    // lowered -- and that row of the tile's NT_ accumulators rescaled, exactly -- whenever a slab's largest magnitude in
+    // the row would leave [.., 2^14).  The residual is kept unscaled so that main and cross products share ONE
+    // accumulator (there is no room for a second set beside 37 tiles): full relative precision for elements within 2^16
+    // of their row's running maximum, an absolute error below 2^-39 of it for smaller ones.  Accumulator register r of
+    // lane (j, kq) belongs to row 4 kq + r, whose scale lives in lanes i = 4 kq + r: fetched by ds_bpermute when (rarely,
+    // after the first slabs) some row's scale changes.
+    f16x8 ap[2][2];
+    unsigned exr4 = 0xe4e4e4e4u;                                      // the four tiles' row exponents, one biased byte each (100 + 128)
+    auto exr_get = [&](int mi) { return (int)((exr4 >> (8 * mi)) & 255u) - 128; };
+    auto exr_set = [&](int mi, int v) { exr4 = (exr4 & ~(255u << (8 * mi))) | ((unsigned)(v + 128) << (8 * mi)); };
+    auto row_max4 = [&](float m) {                                   // max over the four kq lanes of the same i
+        const unsigned u = __builtin_bit_cast(unsigned, m);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        m = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+        const unsigned v2 = __builtin_bit_cast(unsigned, m);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(v2, v2, false, false);
+        return fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+    };
+    auto split_pair = [&](int sl, int pair) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int mi = 2 * pair + m;
+            float mx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(raw[mi][e]));
+            mx = row_max4(mx);
+            const int eo = exr_get(mi);
+            const int ne = mx > 0.f ? min(min(14 - __builtin_amdgcn_frexp_expf(mx), 100), eo) : eo;
+            const int delta = eo - ne;                                 // >= 0, the same in the four kq lanes of row i
+            if (__builtin_amdgcn_ballot_w64(delta != 0)) {             // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int dr = __builtin_amdgcn_ds_bpermute((4 * kq + r) * 4, delta);
+                    const float f = __builtin_amdgcn_ldexpf(1.0f, -dr);
+#pragma unroll
+                    for (int ni = 0; ni < NT_; ++ni) acc[mi][ni][r] *= f;
+                }
+                exr_set(mi, ne);
+            }
+            float sc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc[e] = __builtin_amdgcn_ldexpf(raw[mi][e], ne);
+            split8u(sc, ap[m][0], ap[m][1]);
+        }
+        load_a(sl + 1, pair);
+    };
+    auto mfma_pair = [&](int buf, int pair) {
+        const unsigned short* bp = sm16 + buf * BUF;
+#pragma unroll
+        for (int ni = 0; ni < NT_; ++ni) {
+            f16x8 bb[2];
+            const unsigned short* src = bp + (16 * ni + j) * KP + 8 * kq;
+            bb[0] = *reinterpret_cast<const f16x8*>(src);
+            bb[1] = *reinterpret_cast<const f16x8*>(src + BPL);
+            mac3(acc[2 * pair][ni], ap[0], bb);
+            mac3(acc[2 * pair + 1][ni], ap[1], bb);
+            if (HEADS) asm volatile("" ::: "memory");              // one tile of B fragments in flight: room for the head tile and the row scales
+        }
+        if (HEADS && pair == 1) {                         // dW_head tile of this wave: dheads^T Y[:, 16w .. 16w+16)
+            const unsigned short* yp = bp + 2 * BPL;
+            const unsigned short* dp = yp + 3 * YPL;
+            bf16x8 da[3], yb[3];
+            const unsigned short* sa = dp + j * KP + 8 * kq;
+            const unsigned short* sb = yp + (16 * w + j) * KP + 8 * kq;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                da[pc] = *reinterpret_cast<const bf16x8*>(sa + pc * DPL);
+                yb[pc] = *reinterpret_cast<const bf16x8*>(sb + pc * YPL);
+            }
+            mac6(acch, da, yb);
+        }
+    };
+
+    load_b(0);
+    load_a(0, 0);
+    load_a(0, 1);
+    commit_b(0);
+    load_b(1);
+    split_pair(0, 0);
+    lds_barrier();
+    WX_PROF_DECL;
+    // one body for both groups -- mfma0 commit split1 mfma1 split0(next) -- and the group decides where in it the
+    // slab barrier sits: EARLY waves wait before split0(next), LATE waves after it, so after every barrier the
+    // LATE wave of a SIMD streams MFMAs while the EARLY one still splits, and so on round the slab
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        WX_PROF_MARK(0);
+        mfma_pair(buf, 0);
+        WX_PROF_DEP(acc[0][NT_ - 1]); WX_PROF_DEP(acc[1][NT_ - 1]); WX_PROF_MARK(2);
+        commit_b(buf ^ 1);                                // planes of slab sl + 1 (a clamped copy on the last slab)
+        load_b(sl + 2);
+        WX_PROF_MARK(5);
+        split_pair(sl, 1);
+        WX_PROF_DEP(ap[0][0]); WX_PROF_DEP(ap[1][1]); WX_PROF_MARK(3);
+        mfma_pair(buf, 1);
+        WX_PROF_DEP(acc[2][NT_ - 1]); WX_PROF_DEP(acc[3][NT_ - 1]); WX_PROF_MARK(4);
+        if (!late) { lds_barrier(); WX_PROF_MARK(7); }
+        split_pair(sl + 1, 0);                            // pair 0 of the NEXT slab (raw loaded one slab ago)
+        WX_PROF_DEP(ap[0][0]); WX_PROF_DEP(ap[1][1]); WX_PROF_MARK(1);
+        if (late) { lds_barrier(); WX_PROF_MARK(7); }
+    }
+    WX_PROF_FLUSH();
+    float* slab = slabs + (size_t)blockIdx.x * WG<H>::SLAB;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int er = __builtin_amdgcn_ds_bpermute((4 * kq + r) * 4, exr_get(mi));   // scale of row 4 kq + r of tile mi
+            const float usc = __builtin_amdgcn_ldexpf(1.0f / WGH_BSCALE, -er);
+#pragma unroll
+            for (int ni = 0; ni < NT_; ++ni)
+                slab[(size_t)(64 * w + 32 * (mi >> 1) + 2 * (4 * kq + r) + (mi & 1)) * G::NC + 16 * ni + j] = acc[mi][ni][r] * usc;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
+}
+
 // sum the slabs in block order and scatter into dW_hh / dW_ih / db / dW_head
 template <int H>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nb, int I, int NH,
@@ -639,7 +933,24 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX::LDS));
                 attr3 = true;
             }
-            if (dheads)
+            const bool h3 = !getenv("UAV_LSTM_BF16X6") && !getenv("UAV_WGRAD_BF16X6");
+            if (h3) {
+                using GH = WGH<H>;
+                static bool attr4 = false;
+                if (!attr4) {
+                    UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_h3_kernel<H, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GH::LDS));
+                    UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_h3_kernel<H, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GH::LDS));
+                    attr4 = true;
+                }
+                if (dheads)
+                    hipLaunchKernelGGL((lstm_wgrad_h3_kernel<H, true>), dim3(nbx), dim3(H * 4), GH::LDS, st, dgates, y_prev_src,
+                                       keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
+                else
+                    hipLaunchKernelGGL((lstm_wgrad_h3_kernel<H, false>), dim3(nbx), dim3(H * 4), GH::LDS, st, dgates, y_prev_src,
+                                       keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
+            } else if (dheads)
                 hipLaunchKernelGGL((lstm_wgrad_x6_kernel<H, true>), dim3(nbx), dim3(H * 4), GX::LDS, st, dgates, y_prev_src,
                                    keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
             else

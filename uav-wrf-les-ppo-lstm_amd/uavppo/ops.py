@@ -329,6 +329,26 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
     return y, hn, cn, stash
 
 
+def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):
+    """The weight-gradient pass alone, from given gate gradients: dW_ih, dW_hh, db (and dW_head = dheads^T y)."""
+    N, T, I = x.shape
+    H = y.shape[-1]
+    dev = x.device
+    nh = 0 if dheads is None else dheads.shape[-1]
+    dw_ih = torch.empty(4 * H, I, dtype=F32, device=dev)
+    dw_hh = torch.empty(4 * H, H, dtype=F32, device=dev)
+    db = torch.empty(4 * H, dtype=F32, device=dev)
+    dw_head = torch.empty(nh, H, dtype=F32, device=dev) if nh else None
+    check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"), _p(h0, F32, (N, H), "h0"),
+                               _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"),
+                               _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                               _p(dheads, F32, (N, T, nh), "dheads"), nh, N, T, I, H,
+                               _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
+                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nh, H), "dw_head"), _p(None), _stream()),
+          "uav_lstm_wgrad")
+    return {"dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dw_head": dw_head}
+
+
 def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
              dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None):
     """BPTT sequence kernel + fused weight-gradient pass of one layer.  y, h0: the layer's forward
