@@ -20,10 +20,17 @@ __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g
     if (threadIdx.x == 0) partial[blockIdx.x] = q;
 }
 
-// scal[0] = clip coefficient, scal[1] = pre-clip norm
-__global__ __launch_bounds__(256) void norm_final(const double* __restrict__ partial, int nb, float max_norm,
-                                                  float* __restrict__ scal, float* __restrict__ gnorm_out) {
+// decay = 1 - lr * weight_decay (torch.optim.AdamW: param.mul_(decay) before the Adam update; 1 for plain Adam).
+// Every block first finishes the norm itself from the (<= 256) partial sums -- the same fixed-order reduction in each, so
+// all blocks get the same bits -- instead of a one-block kernel launch in between; block 0 publishes the norm.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   const double* __restrict__ partial, int nb, float max_norm,
+                                                   float* __restrict__ gnorm_out, float b1, float b2,
+                                                   float step_size, float sqrt_bc2, float eps, float decay) {
+#pragma clang fp contract(off)
     __shared__ double sm[4];
+    __shared__ float coef_s;
     double q = 0.0;
     for (int i = threadIdx.x; i < nb; i += 256) q += partial[i];
     q = block256_sum(q, sm);
@@ -32,19 +39,11 @@ __global__ __launch_bounds__(256) void norm_final(const double* __restrict__ par
         float coef = max_norm / (norm + 1e-6f);        // torch clip_grad_norm_
         coef = coef > 1.0f ? 1.0f : coef;
         if (!(max_norm > 0.f)) coef = 1.0f;            // max_norm <= 0: clipping disabled
-        scal[0] = coef;
-        scal[1] = norm;
-        if (gnorm_out) *gnorm_out = norm;
+        coef_s = coef;
+        if (gnorm_out && blockIdx.x == 0) *gnorm_out = norm;
     }
-}
-
-// decay = 1 - lr * weight_decay (torch.optim.AdamW: param.mul_(decay) before the Adam update; 1 for plain Adam)
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   const float* __restrict__ scal, float b1, float b2,
-                                                   float step_size, float sqrt_bc2, float eps, float decay) {
-#pragma clang fp contract(off)
-    const float coef = scal[0];
+    __syncthreads();
+    const float coef = coef_s;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * coef;
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1-beta1)
@@ -61,11 +60,9 @@ static int clip_adam_impl(uav_ctx* ctx, float* param, const float* grad, float* 
                           float* gnorm_out, uav_stream stream) {
     UAV_REQUIRE(ctx && param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "uav_clip_adam: bad argument");
     double* partial = (double*)ctx->ws;
-    float* scal = (float*)((char*)ctx->ws + 4096);
     int nb = (int)((n + 1023) / 1024);
     if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
     hipLaunchKernelGGL(sumsq_partial, dim3(nb), dim3(256), 0, as_stream(stream), grad, n, partial);
-    hipLaunchKernelGGL(norm_final, dim3(1), dim3(256), 0, as_stream(stream), partial, nb, max_norm, scal, gnorm_out);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
@@ -73,7 +70,7 @@ static int clip_adam_impl(uav_ctx* ctx, float* param, const float* grad, float* 
     int ab = (int)((n + 255) / 256);
     if (ab > 2048) ab = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(ab), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
-                       scal, beta1, beta2, step_size, sqrt_bc2, eps, 1.0f - lr * weight_decay);
+                       partial, nb, max_norm, gnorm_out, beta1, beta2, step_size, sqrt_bc2, eps, 1.0f - lr * weight_decay);
     UAV_LAUNCH_CHECK();
     return 0;
 }
