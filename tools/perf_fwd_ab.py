@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times uav_lstm_fwd / bwd / wgrad at the C3 shape and prints the max difference against a torch f64 LSTM
-(run twice, with and without UAV_LSTM_F32_MFMA=1, to A/B the split-bf16 kernels against the exact-f32 ones)."""
+(run with and without UAV_LSTM_F32_MFMA=1 / UAV_LSTM_BF16X6=1 to A/B the split-fp16 kernels against the exact-f32 and
+split-bf16 ones)."""
 import os
 import sys
 
@@ -57,7 +58,7 @@ def main():
             cd = torch.sigmoid(f_) * cd + torch.sigmoid(i_) * torch.tanh(g_)
             hd = torch.sigmoid(o_) * torch.tanh(cd)
             err = max(err, float((y[:M, t].double() - hd).abs().max()))
-        mode = "f32-mfma" if os.environ.get("UAV_LSTM_F32_MFMA") else "bf16x6"
+        mode = "f32-mfma" if os.environ.get("UAV_LSTM_F32_MFMA") else ("bf16x6" if os.environ.get("UAV_LSTM_BF16X6") else "fp16x3")
         print(f"[{mode}] N={N} T={T} H={H}: max |y - f64| = {err:.3e}")
         print("   fwd (stash)  : %.3f ms (min %.3f)" % timeit(lambda: ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=stash, y=y)))
         from uavppo import _lib
