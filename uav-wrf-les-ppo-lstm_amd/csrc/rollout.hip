@@ -229,12 +229,15 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
         recurrent([&](int q, int s) { return wb[q][s][0]; }, [&](int q, int s) { return wb[q][s][1]; });
     };
     // Wave 0's share of the recurrent product (units 0..15 of the four gates), computed by the gate waves from the
-    // LDS copy of its weights while they would otherwise wait at barrier 2 for the env step: tile q goes to wave
-    // 1 + q % (NW - 1).  Same operand fragments and accumulation order as recurrent(), so the bits do not change.
+    // LDS copy of its weights while they would otherwise wait at barrier 2 for the env step.  Tile q goes to wave
+    // 1 + q % (NW - 1), except that wave NW/2 -- wave 0's SIMD partner, whose MFMAs would serialise with the env chain's
+    // VALU work (tools/simd_overlap_probe.hip) -- hands its tile to the next wave.  Same operand fragments and
+    // accumulation order as recurrent(), so the bits do not change.
     auto recurrent_for_wave0 = [&]() {
         const f16x8* const wf = reinterpret_cast<const f16x8*>(w0p) + lane;
         const unsigned short* hrow = hpl + j * RS + 8 * kq;
-        for (int q = w - 1; q < 4; q += NW - 1) {
+        const int q0 = (NW == 8) ? (w < 4 ? w - 1 : (w == 5 ? 3 : 4)) : w - 1;
+        for (int q = q0; q < 4; q += NW - 1) {
             const float4 bv = *reinterpret_cast<const float4*>(bl + q * H + 4 * kq);
             f32x4 e = {bv.x, bv.y, bv.z, bv.w}, el = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
