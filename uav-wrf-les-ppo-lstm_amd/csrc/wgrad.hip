@@ -580,9 +580,11 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_x6_kernel(
 // ones.  Differences from the forward / backward kernels' use of the split, forced by the 37 accumulator tiles per wave:
 // the residual pieces are kept UNscaled (a = p0 + p1, p1 = fp16(a - p0)) so that main and cross products can share one
 // accumulator, and both operands are block-scaled up by powers of two so that those residuals stay in fp16's normal
-// range -- [Hprev | x, 1] by 2^10 (|h| < 1; |x| < 64 is assumed), dG by a running scale per gate row (below).
-// The head tile (dheads^T Y, one of 37) stays on the bf16 split.
-constexpr float WGH_BSCALE = 1024.0f;
+// range -- the Hprev columns by 2^10 (|h| < 1), the x | 1 columns by 2^4 (|x| < 4096 is assumed; a column scale is undone
+// per output column), dG by a running scale per gate row (below).  The head tile (dheads^T Y, one of 37) stays on the bf16
+// split.
+constexpr float WGH_BSCALE = 1024.0f;      // Hprev columns
+constexpr float WGH_XSCALE = 16.0f;        // x | 1 columns (the last 16-column tile)
 
 template <int H>
 struct WGH {
@@ -715,7 +717,7 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
         for (int k = 0; k < XV; ++k) {
             const int idx = tid + k * NT, q = idx >> 4, f = idx & 15;
             _Float16 a, b;
-            split2u(xv[k] * WGH_BSCALE, a, b);
+            split2u(xv[k] * WGH_XSCALE, a, b);
             unsigned short* d = bp + (H + f) * KP + q;
             d[0] = h_bits(a);
             d[BPL] = h_bits(b);
@@ -863,7 +865,8 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
             const float usc = __builtin_amdgcn_ldexpf(1.0f / WGH_BSCALE, -er);
 #pragma unroll
             for (int ni = 0; ni < NT_; ++ni)
-                slab[(size_t)(64 * w + 32 * (mi >> 1) + 2 * (4 * kq + r) + (mi & 1)) * G::NC + 16 * ni + j] = acc[mi][ni][r] * usc;
+                slab[(size_t)(64 * w + 32 * (mi >> 1) + 2 * (4 * kq + r) + (mi & 1)) * G::NC + 16 * ni + j] =
+                    acc[mi][ni][r] * (ni == NT_ - 1 ? usc * (WGH_BSCALE / WGH_XSCALE) : usc);
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
