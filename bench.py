@@ -2,6 +2,7 @@
 """Headline benchmark: env-steps/sec (+ PPO updates/sec) of the PPOV2.0 hot path on MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8                      # spawns 8 fresh rank processes itself (RCCL), rank 0 prints the line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,11 +10,18 @@ One "step" = one full training iteration of BASELINE.json's headline config (C3)
 rollout of 4096 envs x 128 steps per GPU over the procedural Gaussian-plume environment with the
 LSTM(h=128) actor-critic, the GAE scan + whole-buffer normalisation, 5 epochs of the clipped-PPO
 update (forward, loss, BPTT, weight gradients, grad all-reduce, clip+Adam) and the curriculum
-update.  Weak scaling: every rank owns 4096 envs; value = all ranks' env-steps / max-over-ranks time.
+update.
+
+--scaling weak (default): every rank owns the config's env count (4096 at C3); value = all ranks' env-steps /
+max-over-ranks time.  With more than one rank the same run ALSO times the strong-scaling shape (the config's env
+count split over the ranks, SURVEY 8d "strong scaling for C3") and reports it under "strong_scaling".
+--scaling strong: the split shape is the headline value.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,32 +31,75 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 CONFIGS = {   # BASELINE.json configs (per-GPU env count; SURVEY 8 shorthand)
     "c2": dict(num_envs=256, horizon=64, hidden=64, layers=1, variant="v2.0"),
     "c3": dict(num_envs=4096, horizon=128, hidden=128, layers=1, variant="v2.0"),
     # C4: 8192 envs over 8 GPUs = 1024 per GPU, sigma=15 (PPOV2.1), materialised bank of F=64 fields in HBM
     "c4": dict(num_envs=1024, horizon=128, hidden=128, layers=1, variant="v2.1", bank_fields=64),
     # C5: 32768 envs over 8 GPUs = 4096 per GPU, T=256, LSTM h=256 stacked x2, obs 6 + 2 trend channels
-    # (generic per-step LSTM path + step-wise rollout: correct, launch-bound)
     "c5": dict(num_envs=4096, horizon=256, hidden=256, layers=2, variant="v2.1", trend_k=2),
+    # the reference's own policy (MLP 6-256-128, model.py:17-53) at the C3 buffer shape
+    "mlp": dict(num_envs=4096, horizon=128, hidden=0, layers=0, variant="v2.0", policy="mlp"),
 }
-PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA ~2.5 PFLOP/s (the split-fp16 kernels issue 3 products)
-PEAK_HBM_GBS = 8000.0
+PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: exact-f32 MFMA = the f32 vector rate
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA ~2.5 PFLOP/s
+NHEADS = 6                       # 5 logits + value
+# algorithmic bytes per env-step: rollout write 44, GAE 20 (12 read + 8 written), update 44 read per epoch
+ALG_ROLLOUT_B, ALG_GAE_B, ALG_UPDATE_B = 44, 20, 44
 
 
-def lstm_flops_per_env_step(I, H, A=5):
-    """LSTM layer fwd 2*4H*(I+H); training = 3x fwd."""
-    return 2 * 4 * H * (I + H)
+# ------------------------------------------------------------------------------------------------ rank launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
+def spawn_ranks(n, cmd, extra_env=None, timeout=None):
+    """Start `cmd` n times as FRESH child processes (one per rank, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment), wait for all, return the largest exit code.  The caller must not have touched the GPU: a rank
+    process initialises HIP itself, nothing is re-exec'ed from a process that already did.  If one rank fails the
+    others are terminated (by PID) so a dead peer never leaves the rest waiting in a collective."""
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e))
+    t0 = time.time()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0:
+                    rc = max(rc, abs(code) or 1)
+        if rc or (timeout and time.time() - t0 > timeout):
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
 def cpu_baseline(seconds=12.0):
-    """Reference-faithful CPU loop (variant (i) of BASELINE.md 3): 1 env, batch-1 MLP forward per
+    """Reference-faithful CPU loop (variant (i) of SURVEY 8d): 1 env, batch-1 MLP forward per
     step, 256-step buffer, GAE + 5 full-batch Adam steps -- the oracle ('port'), rank 0 only."""
     import numpy as np
+    import torch
     from oracle import ppo_oracle as po
     from oracle.env_oracle import OracleEnv
     # batch-1 forwards and 256-sample updates do not scale with threads; the box's default (128 threads on a
@@ -98,21 +149,259 @@ def cpu_baseline(seconds=12.0):
             "updates_per_s": updates / dt}
 
 
+def host_cores(cap=16):
+    """Host threads this process may actually use: the affinity mask, cut by the cgroup CPU quota when there is one,
+    and by `cap` (a one-GPU box's CPU share is 16; more torch threads than that oversubscribe and run slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline_vectorised(T=128, H=128, n_sample=1024, n_full=4096, epochs=5, bank_fields=8):
+    """Variant (ii) of SURVEY 8d: the SAME iteration as the GPU run (vectorised envs, LSTM(h) actor-critic, GAE,
+    whole-buffer normalisation, `epochs` full-batch Adam steps) in numpy / torch-CPU batch operations on all host
+    cores.  Bounded sample: n_sample of the n_full envs for the full T steps and all epochs (CPU cost per env-step
+    does not depend on N at these sizes); fields from a materialised bank built outside the timed region."""
+    import numpy as np
+    import torch
+    from oracle import ppo_oracle as po
+    from oracle.env_oracle import FieldBank
+    from oracle.vec_env_oracle import NumpyVecEnv
+    threads = host_cores()
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    N = n_sample
+    bank = FieldBank.from_seed(bank_fields, "v2.0", seed=0)
+    env = NumpyVecEnv(N, bank, "v2.0")
+    p = po.init_lstm_policy(6, H, 1, seed=0)
+    adam = po.AdamState(p)
+    gen = torch.Generator().manual_seed(0)
+    rng = np.random.RandomState(0)
+    obs = env.reset()
+    h = torch.zeros(1, N, H)
+    c = torch.zeros(1, N, H)
+    t0 = time.perf_counter()
+    # ---- rollout (train_ppo2.0.py:157-198 for N envs)
+    B = {k: [] for k in ("obs", "act", "rew", "val", "logp", "done", "keep")}
+    keep = np.ones(N, np.float32)
+    h0, c0 = h.clone(), c.clone()
+    with torch.no_grad():
+        for t in range(T):
+            probs, value, _, (h, c) = po.lstm_policy_forward(p, torch.from_numpy(obs)[None], h, c,
+                                                             keep=torch.from_numpy(keep)[None])
+            a = torch.multinomial(probs[0], 1, generator=gen).squeeze(1)
+            lp = po.categorical_logp(probs[0], a)
+            B["obs"].append(obs)
+            B["act"].append(a.numpy())
+            B["val"].append(value[0].numpy())
+            B["logp"].append(lp.numpy())
+            B["keep"].append(keep)
+            obs, rew, done, _, _, _ = env.step(a.numpy(), rng.randn(N, 2))
+            B["rew"].append(rew.astype(np.float32))
+            B["done"].append(done.astype(np.float32))
+            keep = 1.0 - done.astype(np.float32)
+    t_roll = time.perf_counter() - t0
+    S = {k: np.stack(v) for k, v in B.items()}          # time-major [T, N, ...]
+    # ---- GAE (train_ppo2.0.py:18-32), vectorised over the envs
+    rew, val, dn = S["rew"], S["val"], S["done"]
+    adv = np.zeros((T, N), np.float32)
+    last = np.zeros(N, np.float32)
+    g, gl = np.float32(0.99), np.float32(0.99 * 0.95)
+    for t in range(T - 1, -1, -1):
+        nnt = 1 - (dn[t] if t == T - 1 else dn[t + 1])
+        nv = (val[t] if t == T - 1 else val[t + 1]) * nnt
+        last = (rew[t] + g * nv - val[t]) + gl * nnt * last
+        adv[t] = last
+    adv_n, ret = po.normalise(adv, val)
+    x = torch.from_numpy(S["obs"])
+    k = torch.from_numpy(S["keep"])
+    act, lp_old, v_old = (torch.from_numpy(S[n]).reshape(-1) for n in ("act", "logp", "val"))
+    # ---- EPOCHS full-batch optimiser steps (train_ppo2.0.py:43-88)
+    for _ in range(epochs):
+        leaf = {n: v.detach().clone().requires_grad_(True) for n, v in p.items()}
+        probs, value, _, _ = po.lstm_policy_forward(leaf, x, h0, c0, keep=k)
+        total, _, _, _ = po.ppo_losses(probs.reshape(T * N, -1), value.reshape(-1), act, lp_old, adv_n, ret, v_old)
+        total.backward()
+        grads = {n: leaf[n].grad for n in p}
+        po.clip_grads(grads)
+        adam.step(p, grads)
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(prev_threads)
+    return {"value": N * T / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"ONE iteration of {N} of the {n_full} envs x {T} steps (LSTM h={H} rollout {t_roll:.1f} s + GAE + "
+                      f"{epochs} full-batch epochs, {dt:.1f} s) in numpy / torch-CPU batch ops, {threads} threads; "
+                      f"materialised bank of {bank_fields} fields built outside the timed region",
+            "rollout_env_steps_per_s": N * T / t_roll, "seconds": dt}
+
+
+# ------------------------------------------------------------------------------------------------ measurement
+def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
+    """`warmup` untimed iterations, then exactly `steps` timed ones between barrier + synchronize pairs;
+    returns (max-over-ranks seconds, rollout ms per iteration, kernel timers)."""
+    import torch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        tr.train_iteration()
+    if timers:
+        ops.KERNEL_TIMER.enable(timers)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        tr.collect()
+        ev[k][1].record()
+        tr.update()
+        tr.update_curriculum()
+        tr.iteration += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    summary = ops.KERNEL_TIMER.summary() if timers else {}
+    ops.KERNEL_TIMER.disable()
+    tr.losses()     # raises (on every rank) if any NaN probability was seen (reference convention)
+    roll_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    return dt, roll_ms, summary
+
+
+def load_traffic(tag_glob="r0*_hbm_traffic_pmc.json"):
+    """Newest committed PMC summary under profiles/ (a profiler cannot run inside the timed region)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob)))
+    if not files:
+        return None, None
+    f = files[-1]
+    d = json.load(open(f))
+    meta = d.get("_meta", {})
+    return d, {"file": os.path.relpath(f, ROOT), "git_commit": meta.get("git_commit"), "shape": meta.get("shape"),
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950 "
+                         "correction, MI355X_MICROARCH.md HBM), KB -> bytes, averaged per launch"}
+
+
+def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind):
+    """Dominant kernel + whole iteration against both roofs, with SURVEY 8(d)'s algorithmic figures AND the
+    implementation's own traffic / executed flops side by side."""
+    L = max(cfg["layers"], 1)
+    units = N * T
+    traffic, src = load_traffic()
+    out = None
+    bwd = timers.get("lstm_bwd")
+    if bwd and kind == "lstm":
+        sec = bwd["avg_ms"] * 1e-3
+        kname = "lstm_bwd_h3k_kernel<%d>" % H
+        alg_b = ALG_UPDATE_B * units                                   # 8(d): 44 B read per unit per epoch
+        impl_b = units * (5 * H + 4 * H + NHEADS + 1) * 4              # stash 5H read + dgates 4H written + dheads + keep
+        fl = units * 2 * 4 * H * H                                     # dh_{t-1} = dG W_hh: one forward-equivalent product
+        pmc = None
+        if traffic and cfg is CONFIGS["c3"]:
+            pmc = traffic.get(kname, {}).get("hbm_total_bytes")
+        out = {"kernel": kname, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+               "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": pmc, "traffic_source": src,
+               "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
+               "note": "achieved = ALGORITHMIC f32 flops per launch (2*4H*H per env-step) / live HIP-event duration, priced "
+                       "at the dense f32 MFMA peak (dtype f32; SURVEY 8d classes the LSTM as MFMA-bound).  The products are "
+                       "EXECUTED as 3 fp16 MFMA products each: see mfma.executed_*.  hbm.* prices the same launch at the HBM "
+                       "roof, on 8(d)'s algorithmic bytes and on the implementation's own stash/dgates traffic",
+               "mfma": {"algorithmic_f32_tflops": fl / sec / 1e12, "f32_peak_tflops": PEAK_F32_MFMA_TFLOPS,
+                        "frac_f32_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "executed_fp16_tflops": 3 * fl / sec / 1e12, "fp16_peak_tflops": PEAK_F16_MFMA_TFLOPS,
+                        "frac_fp16_peak": 3 * fl / sec / 1e12 / PEAK_F16_MFMA_TFLOPS},
+               "hbm": {"algorithmic_bytes": alg_b, "implementation_bytes": impl_b, "implementation_over_algorithmic": impl_b / alg_b,
+                       "achieved_GBps_algorithmic": alg_b / sec / 1e9, "achieved_GBps_implementation": impl_b / sec / 1e9,
+                       "peak_GBps": PEAK_HBM_GBPS, "frac_algorithmic": alg_b / sec / 1e9 / PEAK_HBM_GBPS,
+                       "frac_implementation": impl_b / sec / 1e9 / PEAK_HBM_GBPS,
+                       "pmc_over_algorithmic": (pmc / alg_b) if pmc else None}}
+    # whole iteration (per GPU): 8(d) per env-step figures x units, against the measured iteration time
+    I = 6 + cfg.get("trend_k", 0)
+    if kind == "lstm":
+        fwd_fl = 2 * 4 * H * (I + H) + (L - 1) * 2 * 4 * H * (H + H) + 2 * H * NHEADS
+        # implementation bytes: rollout stash (6H + H + heads + 44 B) once, then per epoch fwd 7H written (minus the reused one),
+        # bwd 5H + 4H, wgrad 4H + H (+x), all f32
+        impl_it = units * 4 * L * ((6 * H + H) + (epochs - (1 if reused_fwd else 0)) * 7 * H + epochs * (9 * H + 5 * H)) \
+            + units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)
+    else:
+        fwd_fl = 2 * (I * 256 + 256 * 128 + 128 * NHEADS)
+        impl_it = None
+    alg_it = units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)
+    fl_it = units * fwd_fl * (1 + 3 * epochs)
+    whole = {"algorithmic_bytes": alg_it, "algorithmic_GBps": alg_it / dt_iter / 1e9,
+             "frac_hbm_algorithmic": alg_it / dt_iter / 1e9 / PEAK_HBM_GBPS,
+             "implementation_bytes_formula": impl_it,
+             "implementation_over_algorithmic": (impl_it / alg_it) if impl_it else None,
+             "implementation_GBps": (impl_it / dt_iter / 1e9) if impl_it else None,
+             "algorithmic_f32_tflops": fl_it / dt_iter / 1e12, "frac_f32_mfma_peak": fl_it / dt_iter / 1e12 / PEAK_F32_MFMA_TFLOPS,
+             "executed_fp16_tflops": (3 * fl_it / dt_iter / 1e12) if kind == "lstm" and H in (64, 128) and L == 1 else None,
+             "frac_fp16_mfma_peak": (3 * fl_it / dt_iter / 1e12 / PEAK_F16_MFMA_TFLOPS) if kind == "lstm" and H in (64, 128) and L == 1 else None}
+    if traffic and cfg is CONFIGS["c3"]:
+        def tb(prefix):
+            return sum(v["hbm_total_bytes"] for k, v in traffic.items() if k.startswith(prefix))
+        pm = tb("rollout_lstm_kernel") + (epochs - (1 if reused_fwd else 0)) * tb("lstm_fwd_h3_kernel") \
+            + epochs * (tb("lstm_bwd_h3k_kernel") + tb("lstm_wgrad_h3_kernel") + tb("ppo_loss_kernel") + tb("wgrad_reduce_kernel"))
+        whole["pmc_bytes_big_kernels"] = pm
+        whole["pmc_over_algorithmic"] = pm / alg_it
+        whole["pmc_GBps"] = pm / dt_iter / 1e9
+    if out is None:
+        out = {"kernel": None, "bound": "mfma", "achieved": fl_it / dt_iter / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+               "frac": fl_it / dt_iter / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "traffic_source": None,
+               "note": "whole-iteration algorithmic f32 flops (this configuration has no single dominant sequence kernel timed live)"}
+    out["iteration"] = whole
+    return out
+
+
+def build_trainer(cfg, N, rank, world, dev, ops):
+    import torch
+    from uavppo.trainer import VecPPOTrainer
+    bank = bank_src = None
+    if cfg.get("bank_fields"):
+        # synthetic bank generated with E3's formula by the procedural sampler itself (env_materialise kernel)
+        from uavppo.vec_env import VecMethaneEnv
+        F = cfg["bank_fields"]
+        gen = VecMethaneEnv(F, cfg["variant"], dev, seed=4321)
+        gen.reset()
+        bank = torch.stack([ops.env_materialise(gen.state, F, gen.cfg(), f) for f in range(F)])
+        bank_src = gen.peek()[1]
+    kind = cfg.get("policy", "lstm")
+    return VecPPOTrainer(N, cfg["horizon"], kind, hidden=cfg["hidden"] or 128, layers=cfg["layers"] or 1,
+                         variant=cfg["variant"], device=dev, seed=1234, rank=rank, world_size=world, bank=bank,
+                         bank_sources=bank_src, trend_k=cfg.get("trend_k", 0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above touched the GPU (no torch import yet),
+        # every rank is a fresh process; rank 0 prints the one JSON line.
+        raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share one GPU (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -124,104 +413,62 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from uavppo import ops
-    from uavppo.trainer import VecPPOTrainer
     cfg = CONFIGS[args.config]
-    N, T, H = cfg["num_envs"], cfg["horizon"], cfg["hidden"]
-    bank = bank_src = None
-    if cfg.get("bank_fields"):
-        # synthetic bank generated with E3's formula by the procedural sampler itself (env_materialise kernel)
-        from uavppo.vec_env import VecMethaneEnv
-        F = cfg["bank_fields"]
-        gen = VecMethaneEnv(F, cfg["variant"], dev, seed=4321)
-        gen.reset()
-        bank = torch.stack([ops.env_materialise(gen.state, F, gen.cfg(), f) for f in range(F)])
-        bank_src = gen.peek()[1]
-    tr = VecPPOTrainer(N, T, "lstm", hidden=H, layers=cfg["layers"], variant=cfg["variant"], device=dev,
-                       seed=1234, rank=rank, world_size=world, bank=bank, bank_sources=bank_src,
-                       trend_k=cfg.get("trend_k", 0))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        tr.train_iteration()
-    # ---- timed region: exactly K iterations, barrier + synchronize on both sides
-    ops.KERNEL_TIMER.enable(("lstm_bwd", "lstm_fwd", "lstm_wgrad", "rollout", "ppo_loss"))
-    ev_roll = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev_roll[k][0].record()
-        tr.collect()
-        ev_roll[k][1].record()
-        tr.update()
-        tr.update_curriculum()
-        tr.iteration += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    timers = ops.KERNEL_TIMER.summary()
-    ops.KERNEL_TIMER.disable()
-    tr.losses()     # raises if any NaN probability was seen (reference convention)
-
-    roll_ms = sum(a.elapsed_time(b) for a, b in ev_roll) / args.steps
+    kind = cfg.get("policy", "lstm")
+    T, H = cfg["horizon"], cfg["hidden"]
+    n_cfg = cfg["num_envs"]
+    if n_cfg % world:
+        raise SystemExit(f"config {args.config}: {n_cfg} envs do not split over {world} ranks")
+    n_weak, n_strong = n_cfg, n_cfg // world
+    N = n_weak if args.scaling == "weak" else n_strong
+    tr = build_trainer(cfg, N, rank, world, dev, ops)
+    dt, roll_ms, timers = measure(tr, args.steps, args.warmup, world, dev, ops, dist,
+                                  timers=("lstm_bwd", "lstm_fwd", "lstm_wgrad", "rollout", "ppo_loss"))
+    epochs = tr.hp["epochs"]
     env_steps = N * T * world * args.steps
     value = env_steps / dt
-    opt_steps = tr.hp["epochs"] * tr.num_minibatches
-    # roofline of the dominant kernel, the BPTT sequence kernel lstm_bwd_h3k_kernel.  With its dh = dG W_hh product
-    # on the fp16 matrix pipe (two-piece operand split, three products, f32 accuracy) it sits under the HBM roof, not the MFMA one:
-    # algorithmic bytes per (env, step) = 5H stash values read + 4H gate gradients written + NH dheads + keep,
-    # x N*T per launch (DESIGN.md "Kernels"), over its average launch duration timed live with HIP events on the
-    # launch stream.  `traffic` = HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction +
-    # WRITE_SIZE, separate passes), measured at this very shape and stored under profiles/ (a profiler cannot
-    # run inside the timed region).  The MFMA side is reported next to it in f32-equivalent flops.
-    NHEADS = 6
-    bytes_bwd = N * T * (5 * H + 4 * H + NHEADS + 1) * 4 * cfg["layers"]
-    fl_bwd = N * T * 2 * 4 * H * H * cfg["layers"]
-    bwd = timers.get("lstm_bwd")
-    roofline = None
-    if bwd:
-        sec = bwd["avg_ms"] * 1e-3
-        ach = bytes_bwd / sec / 1e9
-        traffic = None
-        kname = "lstm_bwd_h3k_kernel<%d>" % H
-        tf = os.path.join(ROOT, "profiles", "r01_j_hbm_traffic_pmc.json")
-        if args.config == "c3" and os.path.exists(tf):
-            traffic = json.load(open(tf)).get(kname, {}).get("hbm_total_bytes")
-        roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBPS, "traffic": traffic, "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
-                    "algorithmic_bytes": bytes_bwd,
-                    "mfma": {"f32_equiv_tflops": fl_bwd / sec / 1e12, "executed_fp16_tflops": 3 * fl_bwd / sec / 1e12,
-                             "fp16_peak_tflops": PEAK_BF16_MFMA_TFLOPS, "frac": 3 * fl_bwd / sec / 1e12 / PEAK_BF16_MFMA_TFLOPS}}
+    opt_steps = epochs * tr.num_minibatches
+    reused = kind == "lstm" and cfg["layers"] == 1 and H in (64, 128) and not cfg.get("trend_k")
+    roofline = roofline_block(cfg, N, T, H, timers, dt / args.steps, epochs, reused, kind)
+    pol = f"LSTM h={H} x{cfg['layers']}" if kind == "lstm" else "MLP 6-256-128 (the reference's policy)"
     out = {
-        "metric": f"env-steps/sec (rollout + GAE + {tr.hp['epochs']}-epoch PPO update), {N} envs x {T} T per GPU, LSTM h={H}",
+        "metric": f"env-steps/sec (rollout + GAE + {epochs}-epoch PPO update), {N} envs x {T} T per GPU, {pol}",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init LSTM actor-critic)",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (procedural Gaussian-plume envs, random-init actor-critic)",
         "arithmetic": "f32 results throughout; the recurrent LSTM products are evaluated as three fp16 piece products per f32 "
                       "product (two-piece operand split carrying 24 bits, gradients block-scaled by powers of two), weight gradients "
                       "included, all with f32 accumulation -- error vs f64 no larger than the "
                       "exact-f32 MFMA chain's (tests/test_gpu_lstm.py::test_split_kernels_have_f32_accuracy); env arithmetic in f64",
         "config": {"workload": f"BASELINE config {args.config.upper()}: PPO{cfg['variant'].upper()}, {N} envs/GPU x T={T}, "
-                               f"LSTM h={H} x{cfg['layers']}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs {6 + cfg.get('trend_k', 0)}, "
-                               f"5 actions, reference_exact GAE, {tr.hp['epochs']} epochs x {tr.num_minibatches} minibatch "
-                               f"of {N * T} samples/GPU", "num_envs_per_gpu": N, "horizon": T, "hidden": H,
+                               f"{pol}, {'materialised bank F=%d' % cfg['bank_fields'] if cfg.get('bank_fields') else 'procedural field'}, obs {6 + cfg.get('trend_k', 0)}, "
+                               f"5 actions, reference_exact GAE, {epochs} epochs x {tr.num_minibatches} minibatch "
+                               f"of {N * T} samples/GPU", "num_envs_per_gpu": N, "num_envs_total": N * world, "horizon": T, "hidden": H,
                    "minibatch_samples": N * T // tr.num_minibatches, "parallelism": f"dp{world} (env shards, RCCL grad all-reduce)"},
         "rollout_env_steps_per_s": N * T * world / (roll_ms * 1e-3),
         "ppo_iterations_per_s": args.steps / dt, "optimizer_steps_per_s": args.steps * opt_steps / dt,
         "rollout_ms": roll_ms, "kernel_ms": {k: v["avg_ms"] for k, v in timers.items()},
         "roofline": roofline,
     }
+    if world > 1 and args.scaling == "weak":
+        # the same job shape as the 1-GPU run, split over the ranks (SURVEY 8d "strong scaling for C3").  The sequence
+        # kernels' time is T x (step latency of one workgroup) whatever the number of workgroups, so expect
+        # this to stay near the 1-GPU iteration time: it is reported, not hidden.
+        del tr
+        torch.cuda.empty_cache()
+        tr2 = build_trainer(cfg, n_strong, rank, world, dev, ops)
+        k2 = max(3, args.steps // 2)
+        dt2, roll2, _ = measure(tr2, k2, min(args.warmup, 2), world, dev, ops, dist)
+        out["strong_scaling"] = {"value": n_strong * T * world * k2 / dt2, "unit": "env-steps/s", "num_envs_per_gpu": n_strong,
+                                 "num_envs_total": n_strong * world, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+                                 "rollout_ms": roll2}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline_vectorised"] = cpu_baseline_vectorised(T=128, H=128, n_full=4096)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

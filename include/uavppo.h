@@ -92,10 +92,13 @@ int uav_ppo_loss_from_y(uav_ctx* ctx, const float* y, const float* w_head, const
 
 /* ---- K3 (sampling part): softmax + Categorical sample + log_prob + NaN check
  * (train_ppo2.0.py:161-163,189; torch Categorical(probs) semantics).  u: uniforms in [0,1)
- * [n] or NULL to use the counter RNG (seed, counter).  forced_act: i32 [n] or NULL; when
- * given, act_out = forced_act (parity tests / greedy callers).  nan_count: i32[1] device. */
+ * [n] or NULL to use the counter RNG: row i draws from Philox(seed; counter & 0xffffffff, index_offset + i,
+ * counter >> 32) -- with counter = (iteration << 32) | step and index_offset = the global index of this rank's
+ * env 0 that is uav_rollout's own key, so a job samples the same actions however it is sharded.
+ * forced_act: i32 [n] or NULL; when given, act_out = forced_act (parity tests / greedy callers).
+ * nan_count: i32[1] device. */
 int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, const float* u,
-                      uint64_t seed, uint64_t counter, const int32_t* forced_act,
+                      uint64_t seed, uint64_t counter, int64_t index_offset, const int32_t* forced_act,
                       int32_t* act_out, float* logp_out, float* probs_out, int32_t* nan_count,
                       uav_stream stream);
 

@@ -23,7 +23,14 @@ torch.cuda.set_device(0)
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 N = 64 // world
-tr = VecPPOTrainer(N, 32, "lstm", hidden=64, device="cuda:0", seed=11, rank=rank, world_size=world, epochs=2)
+kind = os.environ["POLICY"]
+if kind == "lstm64":          # fused persistent rollout + sequence kernels
+    tr = VecPPOTrainer(N, 32, "lstm", hidden=64, device="cuda:0", seed=11, rank=rank, world_size=world, epochs=2)
+elif kind == "mlp":           # the reference's policy: step-wise rollout (uav_policy_sample keyed by global env index)
+    tr = VecPPOTrainer(N, 32, "mlp", device="cuda:0", seed=11, rank=rank, world_size=world, epochs=2)
+else:                         # C5 family: h=256 stacked x2 + trend obs, step-wise LSTM rollout
+    tr = VecPPOTrainer(N, 12, "lstm", hidden=256, layers=2, trend_k=2, variant="v2.1", device="cuda:0", seed=11, rank=rank,
+                       world_size=world, epochs=2)
 tr.record = True
 for _ in range(2):
     tr.train_iteration()
@@ -35,20 +42,24 @@ if world > 1:
 '''
 
 
-def _run(world, out, port):
+def _run(world, out, port, policy):
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OUT=out)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OUT=out,
+                   POLICY=policy)
         code = f"ROOT={ROOT!r}; PKG={PKG!r}\n" + WORKER
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
 
 
-def test_two_ranks_equal_one_rank(tmp_path):
-    port = 29600 + os.getpid() % 1000
-    _run(1, str(tmp_path / "w1"), port)
-    _run(2, str(tmp_path / "w2"), port + 1)
+@pytest.mark.parametrize("policy", ["lstm64", "mlp", "lstm256x2"])
+def test_two_ranks_equal_one_rank(tmp_path, policy):
+    """A job is invariant to its sharding on EVERY rollout path: the fused kernel and uav_policy_sample both key the
+    action RNG by (seed; step, GLOBAL env index, iteration)."""
+    port = 29600 + os.getpid() % 1000 + 7 * ["lstm64", "mlp", "lstm256x2"].index(policy)
+    _run(1, str(tmp_path / "w1"), port, policy)
+    _run(2, str(tmp_path / "w2"), port + 1, policy)
     one = torch.load(tmp_path / "w1.0")
     a, b = torch.load(tmp_path / "w2.0"), torch.load(tmp_path / "w2.1")
     # rollouts: shard r of the 2-rank job == envs [32r, 32r+32) of the 1-rank job (same global RNG keys)

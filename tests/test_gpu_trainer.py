@@ -102,8 +102,10 @@ def test_rollout_sampling_statistics_and_determinism():
 
 
 # --------------------------------------------------------------------------------------------- update
-def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, epochs, gae_mode, last_val):
-    """_update_model semantics (train_ppo2.0.py:15-88) with the LSTM policy, torch-CPU autograd."""
+def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, epochs, gae_mode, last_val, num_minibatches=1):
+    """_update_model semantics (train_ppo2.0.py:15-88) with the LSTM policy, torch-CPU autograd.
+    num_minibatches > 1: train_ppo2.0.py:43-53's minibatch loop with minibatch m = the whole sequences of envs
+    [m*N/M, (m+1)*N/M) (an LSTM minibatch cannot cut a sequence), one optimiser step per minibatch."""
     if gae_mode == "reference_exact":
         adv = po.gae_reference_exact(rew, val, done)
     else:
@@ -113,19 +115,114 @@ def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, ep
     x = torch.from_numpy(obs).transpose(0, 1)
     k = torch.from_numpy(keep).transpose(0, 1)
     log = []
+    M = num_minibatches
+    nb = N // M
+    adv2, ret2 = adv.reshape(N, T), ret.reshape(N, T)
     for _ in range(epochs):
-        leaf = {n: v.detach().clone().requires_grad_(True) for n, v in p.items()}
-        probs, value, _, _ = po.lstm_policy_forward(leaf, x, h0, c0, keep=k)
-        probs = probs.transpose(0, 1).reshape(N * T, -1)
-        value = value.transpose(0, 1).reshape(-1)
-        total, pl, vl, ent = po.ppo_losses(probs, value, torch.from_numpy(act).reshape(-1), torch.from_numpy(logp).reshape(-1),
-                                           adv, ret, torch.from_numpy(val).reshape(-1))
-        total.backward()
-        grads = {n: leaf[n].grad for n in p}
-        gn = po.clip_grads(grads)
-        adam.step(p, grads)
-        log.append([float(pl), float(vl), float(ent), gn])
+        for m in range(M):
+            sl = slice(m * nb, (m + 1) * nb)
+            leaf = {n: v.detach().clone().requires_grad_(True) for n, v in p.items()}
+            probs, value, _, _ = po.lstm_policy_forward(leaf, x[:, sl], h0[:, sl], c0[:, sl], keep=k[:, sl])
+            probs = probs.transpose(0, 1).reshape(nb * T, -1)
+            value = value.transpose(0, 1).reshape(-1)
+            total, pl, vl, ent = po.ppo_losses(probs, value, torch.from_numpy(act[sl]).reshape(-1),
+                                               torch.from_numpy(logp[sl]).reshape(-1), adv2[sl].reshape(-1),
+                                               ret2[sl].reshape(-1), torch.from_numpy(val[sl]).reshape(-1))
+            total.backward()
+            grads = {n: leaf[n].grad for n in p}
+            gn = po.clip_grads(grads)
+            adam.step(p, grads)
+            log.append([float(pl), float(vl), float(ent), gn])
     return np.array(log), adv.numpy(), ret.numpy()
+
+
+def _fill_synthetic(tr, N, T, L, H, seed):
+    rng = np.random.RandomState(seed)
+    d = {"obs": rng.rand(N, T, 6).astype(np.float32), "act": rng.randint(0, 5, (N, T)).astype(np.int32),
+         "rew": rng.randn(N, T).astype(np.float32), "val": rng.randn(N, T).astype(np.float32),
+         "logp": (np.log(0.2) + 0.1 * rng.randn(N, T)).astype(np.float32),
+         "done": (rng.rand(N, T) < 0.08).astype(np.float32)}
+    d["keep"] = np.ones((N, T), np.float32)
+    d["keep"][:, 1:] = 1 - d["done"][:, :-1]
+    last_val = rng.randn(N).astype(np.float32)
+    for k, v in d.items():
+        if k in tr.buf:
+            tr.buf[k].copy_(torch.from_numpy(v))
+    if tr.last_val is not None:
+        tr.last_val.copy_(torch.from_numpy(last_val))
+    return d, last_val
+
+
+@pytest.mark.parametrize("H,N,T,M,mode", [(64, 8, 24, 2, "reference_exact"), (64, 12, 9, 4, "standard"),
+                                          (128, 20, 33, 4, "reference_exact"), (128, 6, 40, 2, "standard"),
+                                          (128, 48, 16, 3, "reference_exact")])
+def test_lstm_minibatched_update_matches_oracle(H, N, T, M, mode):
+    """U1 at M > 1 (train_ppo2.0.py:43-53): minibatches of whole env sequences -- h0/c0 slices, nb-sized work buffers,
+    no rollout-forward reuse, loss mean over the minibatch -- against the oracle update that slices the same way."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=3, gae_mode=mode, use_curriculum=False, epochs=2,
+                       num_minibatches=M)
+    d, last_val = _fill_synthetic(tr, N, T, 1, H, seed=N + M)
+    h0 = torch.randn(1, N, H) * 0.3
+    c0 = torch.randn(1, N, H) * 0.3
+    tr.h0.copy_(h0)
+    tr.c0.copy_(c0)
+    p = cpu_params(tr.policy)
+    adam = po.AdamState(p)
+    tr.record = True
+    tr.update()
+    log, adv, ret = oracle_lstm_update(p, adam, d["obs"], d["act"], d["rew"], d["val"], d["logp"], d["done"], d["keep"],
+                                       h0, c0, 2, mode, last_val, num_minibatches=M)
+    assert len(tr.log) == 2 * M
+    assert np.allclose(tr.adv_n.cpu().numpy().reshape(-1), adv, atol=2e-5, rtol=1e-4)
+    n = (N // M) * T
+    for i, (sums, gn) in enumerate(tr.log):
+        s = sums.cpu().numpy()
+        assert np.allclose(s[:3] / n, log[i, :3], rtol=2e-4, atol=2e-6), (i, s[:3] / n, log[i])
+        assert np.isclose(gn.item(), log[i, 3], rtol=2e-3), (i, gn.item(), log[i, 3])
+    got = cpu_params(tr.policy)
+    for k in p:
+        assert torch.allclose(got[k], p[k], atol=4e-6, rtol=0), (k, (got[k] - p[k]).abs().max().item())
+    assert np.allclose(tr.losses(), log[-1, :3], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("N,T,M,mode", [(8, 32, 2, "reference_exact"), (12, 20, 4, "standard")])
+def test_mlp_minibatched_update_matches_oracle(N, T, M, mode):
+    """U1 at M > 1 for the reference's MLP policy: minibatch m = the rows of envs [m*N/M, (m+1)*N/M)."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(N, T, "mlp", device=DEV, seed=5, gae_mode=mode, use_curriculum=False, epochs=2, num_minibatches=M)
+    d, last_val = _fill_synthetic(tr, N, T, 0, 0, seed=N * M)
+    p = cpu_params(tr.policy)
+    adam = po.AdamState(p)
+    tr.record = True
+    tr.update()
+    adv = (po.gae_reference_exact(d["rew"], d["val"], d["done"]) if mode == "reference_exact"
+           else po.gae_standard(d["rew"], d["val"], d["done"], last_val))
+    adv, ret = po.normalise(adv, d["val"])
+    adv2, ret2 = adv.reshape(N, T), ret.reshape(N, T)
+    nb = N // M
+    log = []
+    for _ in range(2):
+        for m in range(M):
+            sl = slice(m * nb, (m + 1) * nb)
+            leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+            probs, value, _ = po.mlp_forward(leaf, torch.from_numpy(d["obs"][sl]).reshape(nb * T, 6))
+            total, pl, vl, ent = po.ppo_losses(probs, value, torch.from_numpy(d["act"][sl]).reshape(-1),
+                                               torch.from_numpy(d["logp"][sl]).reshape(-1), adv2[sl].reshape(-1),
+                                               ret2[sl].reshape(-1), torch.from_numpy(d["val"][sl]).reshape(-1))
+            total.backward()
+            grads = {k: leaf[k].grad for k in p}
+            gn = po.clip_grads(grads)
+            adam.step(p, grads)
+            log.append([float(pl), float(vl), float(ent), gn])
+    assert len(tr.log) == 2 * M
+    for i, (sums, gn) in enumerate(tr.log):
+        s = sums.cpu().numpy()
+        assert np.allclose(s[:3] / (nb * T), log[i][:3], rtol=2e-4, atol=2e-6), (i, s[:3] / (nb * T), log[i])
+        assert np.isclose(gn.item(), log[i][3], rtol=2e-3), (i, gn.item(), log[i][3])
+    got = cpu_params(tr.policy)
+    for k in p:
+        assert torch.allclose(got[k], p[k], atol=3e-6, rtol=0), (k, (got[k] - p[k]).abs().max().item())
 
 
 @pytest.mark.parametrize("H,L,N,T,mode", [(64, 1, 6, 24, "reference_exact"), (128, 1, 18, 40, "standard"),

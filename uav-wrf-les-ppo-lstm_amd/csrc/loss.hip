@@ -260,7 +260,7 @@ __global__ __launch_bounds__(1024) void loss_final_kernel(const double* __restri
 template <int A>
 __global__ __launch_bounds__(256) void policy_sample_kernel(
     const float* __restrict__ logits, int64_t n, const float* __restrict__ u, uint64_t seed,
-    uint64_t counter, const int32_t* __restrict__ forced, int32_t* __restrict__ act_out,
+    uint64_t counter, int64_t index_offset, const int32_t* __restrict__ forced, int32_t* __restrict__ act_out,
     float* __restrict__ logp_out, float* __restrict__ probs_out, int32_t* __restrict__ nan_count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(
         float uu;
         if (u) uu = u[i];
         else {
-            const Philox4 r = philox4x32_10(seed, (uint32_t)i, (uint32_t)(i >> 32), (uint32_t)counter, RNG_ACTION);
+            // the fused rollout's key (rollout.hip): (seed; step-in-rollout, GLOBAL env index, iteration), so a job
+            // draws the same actions however its envs are sharded over ranks and whichever rollout path runs it
+            const Philox4 r = philox4x32_10(seed, (uint32_t)counter, (uint32_t)(index_offset + i), (uint32_t)(counter >> 32), RNG_ACTION);
             uu = u01_f32(r.x);
         }
         // inverse-CDF draw over the normalised probabilities (torch.multinomial semantics)
@@ -368,13 +370,13 @@ int uav_ppo_loss_from_y(uav_ctx* ctx, const float* y, const float* w_head, const
 }
 
 int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, const float* u,
-                      uint64_t seed, uint64_t counter, const int32_t* forced_act, int32_t* act_out,
+                      uint64_t seed, uint64_t counter, int64_t index_offset, const int32_t* forced_act, int32_t* act_out,
                       float* logp_out, float* probs_out, int32_t* nan_count, uav_stream stream) {
     UAV_REQUIRE(ctx && logits && act_out && logp_out && nan_count && n > 0, "uav_policy_sample: bad argument");
     const int nb = (int)((n + 255) / 256);
 #define LAUNCH_S(A_)                                                                                      \
     hipLaunchKernelGGL(policy_sample_kernel<A_>, dim3(nb), dim3(256), 0, as_stream(stream), logits, n, u, \
-                       seed, counter, forced_act, act_out, logp_out, probs_out, nan_count)
+                       seed, counter, index_offset, forced_act, act_out, logp_out, probs_out, nan_count)
     switch (n_act) {
         case 2: LAUNCH_S(2); break;
         case 3: LAUNCH_S(3); break;

@@ -37,7 +37,7 @@ SIGNATURES = {
     "uav_adv_normalise": (I32, [P, P, P, I64, P, P, P, P]),
     "uav_ppo_loss": (I32, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P, P, P]),
     "uav_ppo_loss_from_y": (I32, [P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, F32, P, P, P, P]),
-    "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, P, P, P, P, P, P]),
+    "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, I64, P, P, P, P, P, P]),
     "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P]),
     "uav_clip_adamw": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),

@@ -143,7 +143,10 @@ def ppo_loss(logits, value, act, logp_old, adv, ret, val_old, inv_n, clip, ent_b
     return loss_sums, dlogits, dvalue
 
 
-def policy_sample(logits, u=None, seed=0, counter=0, forced_act=None, want_probs=False, nan_count=None):
+def policy_sample(logits, u=None, seed=0, counter=0, forced_act=None, want_probs=False, nan_count=None, index_offset=0,
+                  iteration=0):
+    """Row i draws from Philox(seed; counter, index_offset + i, iteration) -- uav_rollout's key when counter = the step
+    inside the rollout, index_offset = the global index of this rank's first env."""
     n, A = logits.shape
     dev = logits.device
     act = torch.empty(n, dtype=I32, device=dev)
@@ -151,7 +154,8 @@ def policy_sample(logits, u=None, seed=0, counter=0, forced_act=None, want_probs
     probs = torch.empty(n, A, dtype=F32, device=dev) if want_probs else None
     nan_count = torch.zeros(1, dtype=I32, device=dev) if nan_count is None else nan_count
     check(lib().uav_policy_sample(_h(logits), _p(logits, F32, (n, A), "logits"), n, A, _p(u, F32, (n,), "u"),
-                                  int(seed), int(counter), _p(forced_act, I32, (n,), "forced_act"),
+                                  int(seed), (int(iteration) << 32) | (int(counter) & 0xffffffff), int(index_offset),
+                                  _p(forced_act, I32, (n,), "forced_act"),
                                   _p(act), _p(logp), _p(probs), _p(nan_count, I32, (1,), "nan_count"), _stream()),
           "uav_policy_sample")
     return act, logp, probs, nan_count

@@ -147,9 +147,9 @@ class VecPPOTrainer:
         for t in range(self.T):
             heads = self.policy.step(self.cur_obs, self.h, self.c, st["keep"], st["work"])
             fa = None if forced_act is None else forced_act[:, t].contiguous()
-            act, logp, _, _ = ops.policy_sample(heads[:, :5].contiguous(), seed=self.seed + 7919 * self.rank,
-                                                counter=self.iteration * self.T + t, forced_act=fa,
-                                                nan_count=self.nan_count)
+            act, logp, _, _ = ops.policy_sample(heads[:, :5].contiguous(), seed=self.seed, counter=t,
+                                                iteration=self.iteration, index_offset=env_shard(self.rank, self.N)[0],
+                                                forced_act=fa, nan_count=self.nan_count)
             b["obs"][:, t] = self.cur_obs
             b["act"][:, t] = act
             b["val"][:, t] = heads[:, 5]
@@ -190,8 +190,8 @@ class VecPPOTrainer:
             tmp["stash"] = self.policy._stash
             logits = heads[:, :5].contiguous()
             fa = None if forced_act is None else forced_act[:, t].contiguous()
-            act, logp, _, _ = ops.policy_sample(logits, seed=self.seed + 7919 * self.rank,
-                                                counter=self.iteration * self.T + t, forced_act=fa,
+            act, logp, _, _ = ops.policy_sample(logits, seed=self.seed, counter=t, iteration=self.iteration,
+                                                index_offset=env_shard(self.rank, self.N)[0], forced_act=fa,
                                                 nan_count=self.nan_count)
             b["obs"][:, t] = self.cur_obs
             b["act"][:, t] = act
@@ -284,13 +284,14 @@ class VecPPOTrainer:
     def losses(self):
         """(policy_loss, value_loss, entropy) of the LAST optimiser step; raises on NaN probabilities
         like the reference (train_ppo2.0.py:58-62)."""
-        s = self.loss_sums.cpu().numpy()
+        # the rollout's NaN counter travels with the loss sums, so EVERY rank sees every rank's count and they all
+        # raise together (a rank raising alone would leave the others waiting in the next all-reduce)
+        t = torch.cat([self.loss_sums, self.nan_count.to(torch.float64)])
         if self.world > 1:
             import torch.distributed as dist
-            t = self.loss_sums.clone()
             dist.all_reduce(t)
-            s = t.cpu().numpy()
-        if s[3] > 0 or int(self.nan_count.item()) > 0:
+        s = t.cpu().numpy()
+        if s[3] > 0 or s[4] > 0:
             raise RuntimeError("NaN in probs")
         n = (self.N // self.num_minibatches) * self.T * self.world
         return s[0] / n, s[1] / n, s[2] / n
