@@ -162,7 +162,7 @@ def host_cores(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline_vectorised(T=128, H=128, n_sample=1024, n_full=4096, epochs=5, bank_fields=8):
+def cpu_baseline_vectorised(T=128, H=128, n_sample=4096, n_full=4096, epochs=5, bank_fields=8):
     """Variant (ii) of SURVEY 8d: the SAME iteration as the GPU run (vectorised envs, LSTM(h) actor-critic, GAE,
     whole-buffer normalisation, `epochs` full-batch Adam steps) in numpy / torch-CPU batch operations on all host
     cores.  Bounded sample: n_sample of the n_full envs for the full T steps and all epochs (CPU cost per env-step
@@ -261,8 +261,8 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
         ev[k][0].record()
         tr.collect()
         ev[k][1].record()
+        tr.update_curriculum()      # the iteration's one host sync (success bits + range probe), as train_iteration()
         tr.update()
-        tr.update_curriculum()
         tr.iteration += 1
     barrier()
     dt = time.perf_counter() - t0

@@ -52,6 +52,21 @@ const char* uav_last_error(void);
 int  uav_create(uav_ctx** out, int device, size_t ws_bytes);
 void uav_destroy(uav_ctx* ctx);
 
+/* How uav_lstm_fwd / _bwd / _wgrad evaluate their f32 matrix products (per handle; default FP16X3).  All three give f32
+ * results; they differ in the operand RANGE they accept (see the range note at uav_lstm_wgrad) and in speed:
+ *   FP16X3   two fp16 pieces per operand, three MFMA products   |w| < 65504, |x| < 4096, |h0| < 64   fastest
+ *   BF16X6   three bf16 pieces, six products                    f32's whole exponent range           ~1.2x slower
+ *   F32_MFMA exact-f32 MFMA                                     f32's whole exponent range           ~1.7x slower
+ * A caller that cannot bound its operands measures them (uav_absmax; uav_clip_adam's pmax_out) and switches: the Python
+ * trainer does exactly that (uavppo/trainer.py: check_ranges).  uav_rollout exists in the FP16X3 form only. */
+#define UAV_ARITH_FP16X3   0
+#define UAV_ARITH_BF16X6   1
+#define UAV_ARITH_F32_MFMA 2
+int uav_set_lstm_arith(uav_ctx* ctx, int mode);
+int uav_get_lstm_arith(const uav_ctx* ctx);
+/* out[0] (f32, device) = max |x[i]| over n floats, a NaN counting as +inf: the range probe for the modes above. */
+int uav_absmax(uav_ctx* ctx, const float* x, int64_t n, float* out, uav_stream stream);
+
 /* ---- G1: GAE scan.  Replaces train_ppo2.0.py:18-32 (one wavefront per env row, affine
  * suffix scan over T with wave shuffles).  rew,val,done,adv: f32 [n_env][horizon].
  * last_val: f32 [n_env] (STANDARD mode) or NULL. */
@@ -104,10 +119,11 @@ int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, c
 
 /* ---- U3: global-norm clip + Adam on one flat f32 buffer (train_ppo2.0.py:87-88,114;
  * torch clip_grad_norm_ / optim.Adam formulas).  `step` is the 1-based optimiser step.
- * gnorm_out: f32[1] device (pre-clip global L2 norm) or NULL. */
+ * gnorm_out: f32[1] device (pre-clip global L2 norm) or NULL.  pmax_out: f32[1] device or NULL: max |param| AFTER the
+ * step (the kernel touches every parameter anyway) -- the weight-range probe of uav_set_lstm_arith. */
 int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, float* exp_avg,
                   float* exp_avg_sq, int64_t n, int64_t step, float lr, float beta1, float beta2,
-                  float eps, float max_norm, float* gnorm_out, uav_stream stream);
+                  float eps, float max_norm, float* gnorm_out, float* pmax_out, uav_stream stream);
 /* AdamW (torch.optim.AdamW, PPOV2.0/train_lstm.py:67): as uav_clip_adam with the decoupled decay param *= 1 - lr*weight_decay. */
 int uav_clip_adamw(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                    int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,

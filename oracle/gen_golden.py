@@ -469,9 +469,170 @@ def gen_train_lstm_v21():
     print("train_lstm_v21: samples", len(ds), "losses", losses, "gnorms", gnorms, "pos labels", float(np.asarray(ds.labels)[:, 1].sum()))
 
 
+
+# --------------------------------------------------------------------------- N4: trajectory log
+def gen_nc_schema():
+    """PPOV2.1/nc_info.txt:1-46 -- the reference-held schema dump of its training_data.nc (written by its own
+    check_nc_info.py) -- parsed into a JSON fixture: dimensions; per variable shape, dtype, attributes, value range."""
+    import json
+    import re
+    dims, variables, cur, section = {}, {}, None, None
+    for raw in open("/root/reference/PPOV2.1/nc_info.txt", encoding="utf-8"):
+        line = raw.rstrip("\n")
+        if not line.strip():
+            continue
+        if not line.startswith(" "):
+            section = "dims" if line.startswith("维度") else ("vars" if line.startswith("变量") else None)
+            continue
+        if section == "dims":
+            k, v = line.strip().split(":")
+            dims[k.strip()] = int(v)
+        elif section == "vars":
+            m = re.match(r"^  (\w+): shape=\(([^)]*)\), dtype=(\w+)$", line)
+            if m:
+                shape = [int(t) for t in m.group(2).replace(" ", "").split(",") if t]
+                cur = variables[m.group(1)] = {"shape": shape, "dtype": m.group(3), "attrs": {}}
+                continue
+            body = line.strip()
+            mm = re.match(r"^min=([-\w.]+), max=([-\w.]+)$", body)
+            if mm:
+                cur["min"], cur["max"] = float(mm.group(1)), float(mm.group(2))
+            else:
+                k, v = body.split(":", 1)
+                cur["attrs"][k.strip()] = v.strip()
+    out = {"source": "PPOV2.1/nc_info.txt:1-46", "dimensions": dims, "variables": variables}
+    json.dump(out, open(os.path.join(OUT, "nc_schema.json"), "w"), indent=1, ensure_ascii=False)
+    print("nc_schema:", dims, list(variables))
+
+
+def gen_traj():
+    """The reference's own NetCDFWriter (PPOV2.0/netcdf_writer.py:4-114 and PPOV2.1/model.py:351-422) and loaders
+    (PPOV2.0/data_loader.py:5-22, PPOV2.1/model.py:68-90) run over oracle/_refload.MemDataset, an in-memory stand-in for
+    netCDF4.Dataset (absent from the image).  Recorded: the episodes handed to write_episode_data, every variable's array,
+    dtype, fill value and attributes afterwards, and what the loaders return from it."""
+    import importlib.util
+    import json
+    out = {}
+    rng = np.random.RandomState(11)
+    E, S = 7, 40
+    episodes = []
+    for ep, steps in ((0, 25), (2, 40), (3, 1), (5, 33), (6, 19)):
+        episodes.append((ep, steps, rng.rand(steps) * 499, rng.rand(steps) * 499, rng.rand(steps) * 100,
+                         float(rng.rand() * 400 + 50), float(rng.rand() * 400 + 50), 100.0))
+    out["episodes_idx"] = np.asarray([[e[0], e[1]] for e in episodes], np.int64)
+    for k, (ep, steps, x, y, c, sx, sy, sc) in enumerate(episodes):
+        out[f"in{k}/x"], out[f"in{k}/y"], out[f"in{k}/c"] = x, y, c
+        out[f"in{k}/src"] = np.asarray([sx, sy, sc])
+    meta = {}
+    for ver in ("PPOV2.0", "PPOV2.1"):
+        cfg, envm, mdl, train = _refload.load(ver)
+        W = train.NetCDFWriter
+        name = f"mem://{ver}.nc"
+        w = W(name, 500, max_episodes=E, max_steps=S)
+        for (ep, steps, x, y, c, sx, sy, sc) in episodes:
+            if ver == "PPOV2.1":
+                w.write_episode_data(ep, steps, x, y, c, sx, sy, sc, 15.0, 100.0)
+            else:
+                w.write_episode_data(ep, steps, x, y, c, sx, sy, sc)
+        w.close()
+        ds = _refload._MEM_FILES[name]
+        meta[ver] = {"global": {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in ds._gattrs.items()},
+                     "dimensions": dict(ds.dimensions), "variables": {}}
+        for vn, var in ds.variables.items():
+            out[f"{ver}/{vn}"] = var.data.copy()
+            meta[ver]["variables"][vn] = {"dims": list(var.dimensions), "dtype": str(var.data.dtype), "attrs": dict(var._attrs),
+                                          "explicit_fill": bool(var.explicit_fill),
+                                          "fill": (None if not var.explicit_fill else
+                                                   ("nan" if isinstance(var.fill_value, np.floating) and np.isnan(var.fill_value)
+                                                    else float(var.fill_value)))}
+        if ver == "PPOV2.0":
+            spec = importlib.util.spec_from_file_location("ref_data_loader", "/root/reference/PPOV2.0/data_loader.py")
+            dl = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(dl)
+            seqs, concs = dl.load_raw_sequences(name)
+            out["v20_raw/lens"] = np.asarray([len(q) for q in seqs], np.int64)
+            out["v20_raw/flat"] = np.asarray([v for q in seqs for v in q], np.float64)
+            out["v20_raw/source_concs"] = np.asarray(concs, np.float64)
+        else:
+            with contextlib.redirect_stdout(io.StringIO()):
+                segs = mdl.load_trajectory_segments(name, window_size=20)
+            out["v21_seg/positions"] = np.stack([q["positions"] for q in segs]).astype(np.float64)
+            out["v21_seg/concentrations"] = np.stack([q["concentrations"] for q in segs]).astype(np.float64)
+            out["v21_seg/source_pos"] = np.stack([q["source_pos"] for q in segs]).astype(np.float64)
+            out["v21_seg/sigma"] = np.asarray([q["sigma"] for q in segs], np.float64)
+    out["meta_json"] = np.asarray(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "traj_log.npz"), versions=str(VERS), **out)
+    print("traj:", {k: v.shape for k, v in out.items() if k.startswith("v2")})
+
+
+# --------------------------------------------------------------------------- end to end, PPOV1.1 loop shape (BASELINE C1)
+def gen_e2e_v11(extra_steps=300):
+    """PPOV1.1/train_ppo1.1.py:116-190 driven by the reference's own objects under fixed seeds: ONE full episode
+    (MAX_STEPS = 5000: full-buffer updates every 256 steps, then the end-of-episode flush of the SHORT leftover buffer,
+    :166-169, then the curriculum call) plus `extra_steps` of the next episode (one more full-buffer update)."""
+    cfg, envm, mdl, train = _refload.load("PPOV1.1")
+    env_seed, torch_seed = 31, 32
+    np.random.seed(env_seed)
+    torch.manual_seed(torch_seed)
+    env = envm.MethaneEnv()
+    model = mdl.PPOActorCritic(6, 5)
+    sd0 = sd_to_np(model.state_dict())
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.LEARNING_RATE)
+    buf = mdl.PPOBuffer()
+    trainer = mdl.PPOTrainer(env, model, opt)
+    rec = {k: [] for k in ("act", "val", "logp", "rew", "done", "obs")}
+    update_sizes, curr, ep_rows = [], [], []
+    with Capture() as cap, contextlib.redirect_stdout(io.StringIO()):
+        for episode in range(2):
+            state = env.reset()
+            done = False
+            total = 0.0
+            nstep = 0
+            while not done:
+                st = torch.FloatTensor(state).unsqueeze(0)
+                with torch.no_grad():
+                    probs, value = model(st)
+                dist = torch.distributions.Categorical(probs)
+                a = dist.sample().item()
+                lp = dist.log_prob(torch.tensor(a))
+                nxt, r, done, info = env.step(a)
+                buf.store(state, a, r, value.item(), lp.item(), done)
+                for k, v in (("obs", np.asarray(state, np.float32)), ("act", a), ("val", value.item()), ("logp", lp.item()),
+                             ("rew", r), ("done", done)):
+                    rec[k].append(v)
+                if len(buf.states) >= cfg.BATCH_SIZE:
+                    update_sizes.append(len(buf.states))
+                    train._update_model(buf, model, opt)
+                    buf.clear()
+                total += r
+                state = nxt
+                nstep += 1
+                if episode == 1 and nstep >= extra_steps:
+                    break
+            if not done:
+                break
+            if len(buf.states) > 0:                      # train_ppo1.1.py:166-169
+                update_sizes.append(len(buf.states))
+                train._update_model(buf, model, opt)
+                buf.clear()
+            ep_rows.append([total, float(env.trajectory[-1]["reached"]), env.step_count, trainer.current_radius])
+            trainer.update(env.trajectory[-1]["reached"])
+            curr.append([trainer.current_radius, trainer.explore_bonus])
+    post = sd_to_np(model.state_dict())
+    out = {f"init/{k}": v for k, v in sd0.items()}
+    out.update({f"post_sum/{k}": np.float64(v.astype(np.float64).sum()) for k, v in post.items()})
+    out.update(env_seed=env_seed, torch_seed=torch_seed, max_steps=cfg.MAX_STEPS, update_sizes=np.asarray(update_sizes),
+               act=np.asarray(rec["act"], np.int8), val=np.asarray(rec["val"], np.float32),
+               logp=np.asarray(rec["logp"], np.float32), rew=np.asarray(rec["rew"], np.float64),
+               done=np.asarray(rec["done"], bool), obs=np.asarray(rec["obs"], np.float32),
+               loss=np.asarray(cap.loss), gnorm=np.asarray(cap.gnorm), curriculum=np.asarray(curr), episodes=np.asarray(ep_rows))
+    print("e2e_v11 steps", len(rec["act"]), "update sizes", update_sizes, "optimiser steps", len(cap.loss))
+    np.savez_compressed(os.path.join(OUT, "e2e_v11.npz"), versions=str(VERS), **out)
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval", "train_lstm", "train_lstm_v21"]
+    which = sys.argv[1:] or ["env", "policy", "curriculum", "e2e", "eval", "train_lstm", "train_lstm_v21", "nc_schema", "traj",
+                             "e2e_v11"]
     if "env" in which:
         gen_env()
     if "policy" in which:
@@ -486,3 +647,9 @@ if __name__ == "__main__":
         gen_train_lstm()
     if "train_lstm_v21" in which:
         gen_train_lstm_v21()
+    if "nc_schema" in which:
+        gen_nc_schema()
+    if "traj" in which:
+        gen_traj()
+    if "e2e_v11" in which:
+        gen_e2e_v11()

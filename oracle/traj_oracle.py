@@ -9,8 +9,11 @@ __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
   load_trajectory_segments        PPOV2.1/model.py:68-90 on those arrays (every sliding window of every long-enough episode)
 
 Pinning: RadiusTracker against the reference's own class (tests/golden/curriculum.npz gets a `tracker_*` trace from
-oracle/gen_golden.py curriculum).  The writer / loader are PARITY UNPINNED: they need netCDF4, which this image lacks, so
-they are restated from the source and checked for self-consistency (write -> load round trip) only.
+oracle/gen_golden.py curriculum).  Writer and loaders: tests/golden/traj_log.npz holds what the reference's OWN NetCDFWriter /
+load_raw_sequences / load_trajectory_segments produce when run over an in-memory stand-in for netCDF4.Dataset
+(oracle/_refload.MemDataset; the package is absent from the image), and tests/golden/nc_schema.json the reference-held schema
+dump PPOV2.1/nc_info.txt; tests/test_oracle_traj.py checks this restatement and the product's writer against both.  Only
+netCDF's on-disk encoding stays unpinned.
 """
 import numpy as np
 
@@ -20,8 +23,8 @@ def writer_arrays(max_episodes, max_steps):
     return {"x": np.full((E, S), np.nan, np.float32), "y": np.full((E, S), np.nan, np.float32),
             "concentration": np.full((E, S), np.nan, np.float32), "is_source": np.zeros((E, S), np.int8),
             "source_concentration": np.full(E, np.nan, np.float32), "source_x": np.full(E, np.nan, np.float32),
-            "source_y": np.full(E, np.nan, np.float32), "gaussian_sigma": np.full(E, np.nan, np.float32),
-            "peak_concentration": np.full(E, np.nan, np.float32)}
+            "source_y": np.full(E, np.nan, np.float32), "gaussian_sigma": np.full(E, np.float32(9.969209968386869e36), np.float32),
+            "peak_concentration": np.full(E, np.float32(9.969209968386869e36), np.float32)}
 
 
 def write_episode(a, episode_idx, steps, x, y, conc, source_x, source_y, source_conc, sigma=None, peak=None):

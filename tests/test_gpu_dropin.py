@@ -290,3 +290,69 @@ def test_vectorised_trajectory_log_matches_oracle_simulation():
         to.write_episode(a, *call)
     seqs, _ = to.load_raw_sequences(a)
     assert len(seqs) == len(succ)
+
+
+def test_ppov11_loop_matches_reference_golden(golden):
+    """BASELINE config 1 (PPOV1.1/train_ppo1.1.py:116-190): V1.1 environment, full-buffer updates every 256 steps AND the
+    end-of-episode flush of the short leftover buffer (:166-169), curriculum call per episode -- the product's
+    train_ppo1.1.py driven with the reference run's recorded actions; losses of all 15 optimiser steps to 1e-4."""
+    from environment import MethaneEnv
+    from model import PPOActorCritic
+    spec = importlib.util.spec_from_file_location("train_ppo1_1", os.path.join(PKG, "train_ppo1.1.py"))
+    t11 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(t11)
+    g = golden("e2e_v11.npz")
+    act = g["act"].astype(np.int32)
+    steps = len(act)
+    ora = OracleEnv("v1.1", seed=int(g["env_seed"]))
+    ora.reset()                                     # MethaneEnv() + the loop's first reset
+    episodes = [(ora.source.copy(), ora.conc, ora.tke)]
+    noise = np.zeros((steps, 2))
+    for t in range(steps):
+        st = ora.rs.get_state()
+        noise[t] = ora.rs.randn(2)
+        ora.rs.set_state(st)
+        o, _, d, _, _ = ora.step(int(act[t]))
+        assert np.array_equal(d, g["done"][t])
+        if d:
+            ora.reset()
+            episodes.append((ora.source.copy(), ora.conc, ora.tke))
+    bank = FieldBank(np.stack([e[0] for e in episodes]), np.stack([e[1] for e in episodes]),
+                     np.stack([e[2] for e in episodes]))
+    env = MethaneEnv("v1.1", bank=bank.interleaved(), bank_sources=bank.sources)
+    model = PPOActorCritic(6, 5)
+    model.load_state_dict({k: torch.from_numpy(g["init/" + k]) for k in po.MLP_KEYS})
+    # record what _update_model sees and produces
+    sizes, losses = [], []
+    orig = t11._update_model
+
+    def spy(buffer, m, opt):
+        sizes.append(len(buffer.states))
+        n0 = len(losses)
+        real_loss = t11._t20.ops.ppo_loss
+
+        def loss_spy(*a, **k):
+            r = real_loss(*a, **k)
+            s = r[0].cpu().numpy()
+            losses.append((s[0] + s[1] - 0.01 * s[2]) / sizes[-1])
+            return r
+        t11._t20.ops.ppo_loss = loss_spy
+        try:
+            orig(buffer, m, opt)
+        finally:
+            t11._t20.ops.ppo_loss = real_loss
+        assert len(losses) - n0 == 5
+    t11._update_model = spy
+    n_ep = int(g["done"].sum())
+    model, rows, trainer = t11.train_ppo(episodes=n_ep, csv_path=None, model_path=None, env=env, model=model,
+                                         forced_actions=act, noise=noise)
+    assert sizes == g["update_sizes"].tolist() and sizes[1] < 256          # the short end-of-episode flush happened
+    print("max |loss - reference| over", len(losses), "optimiser steps:", np.max(np.abs(np.array(losses) - g["loss"])))
+    assert np.max(np.abs(np.array(losses) - g["loss"])) < 1e-4
+    sd = model.state_dict()
+    for k in po.MLP_KEYS:
+        assert np.isclose(sd[k].double().sum().item(), g["post_sum/" + k], rtol=1e-4, atol=1e-4), k
+    ep = g["episodes"]
+    assert [r[8] for r in rows] == ep[:, 2].tolist() and [r[2] for r in rows] == ep[:, 1].tolist()
+    assert np.allclose([r[1] for r in rows], ep[:, 0], rtol=1e-6)
+    assert np.allclose([r[10] for r in rows], ep[:, 3]) and np.allclose(trainer.current_radius, g["curriculum"][-1, 0])

@@ -321,3 +321,35 @@ def test_split_fp16_weight_gradients_over_a_wide_dynamic_range(ops, H):
     # (e): inputs far from O(1) (the x | 1 columns carry their own, smaller block scale: |x| < 4096)
     x.mul_(3000.0)
     check(base, "large x", [(0, 4 * H, 5e-6)])
+
+
+def test_gate_activation_error_bounds(ops):
+    """csrc/common.h: fast_sigmoid / fast_tanh are v_exp_f32 + v_rcp_f32 (no IEEE division sequence).  tanh is evaluated as
+    1 - 2/(exp(2x)+1): ABSOLUTE error <= 2.5e-7 everywhere (what the recurrence needs: c and h are sums of O(1) terms), but
+    the form cancels for small |x|, so the RELATIVE error grows like 1.5e-7/|x| -- stated in DESIGN.md 3 and pinned here.
+    The activations are read straight from the BPTT stash (gates after activation) of a one-step layer with W = 0."""
+    H, N = 128, 64
+    xs = torch.cat([torch.linspace(-12, 12, 4096), torch.logspace(-6, 0, 2048), -torch.logspace(-6, 0, 2048)]).double()
+    xs = xs[: (xs.numel() // H) * H].reshape(-1, H)                     # one row of pre-activations per "env"
+    rows = xs.shape[0]
+    w_ih = torch.zeros(4 * H, 6, device=DEV)
+    w_ih[:, 0] = 1.0                                                      # gate pre-activation = x[0] (+ bias 0)
+    w_hh = torch.zeros(4 * H, H, device=DEV)
+    b = torch.zeros(4 * H, device=DEV)
+    worst_abs_t = worst_abs_s = worst_rel_t = 0.0
+    for r in range(rows):
+        # every unit of env n sees the same scalar; put value xs[r, u] on env u (N = H envs)
+        x = torch.zeros(H, 1, 6, device=DEV)
+        x[:, 0, 0] = xs[r].float().to(DEV)
+        z = torch.zeros(H, H, device=DEV)
+        _, _, _, stash = ops.lstm_fwd(x, None, z, z, w_ih, w_hh, b, b)
+        st = stash[:, 0].cpu().double()
+        pre = xs[r].float().double()[:, None]                             # the f32 value the kernel saw
+        sig, tnh = st[:, 0:H], st[:, 2 * H:3 * H]                        # i gate (sigmoid), g gate (tanh)
+        worst_abs_s = max(worst_abs_s, (sig - torch.sigmoid(pre)).abs().max().item())
+        et = (tnh - torch.tanh(pre)).abs()
+        worst_abs_t = max(worst_abs_t, et.max().item())
+        worst_rel_t = max(worst_rel_t, (et * pre.abs() / torch.tanh(pre).abs().clamp_min(1e-300)).max().item())
+    print("sigmoid abs", worst_abs_s, "tanh abs", worst_abs_t, "tanh rel*|x|", worst_rel_t)
+    assert worst_abs_s < 1.5e-7 and worst_abs_t < 2.5e-7
+    assert worst_rel_t < 2.5e-7            # relative error of tanh <= 2.5e-7 / |x|

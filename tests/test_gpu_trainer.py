@@ -432,3 +432,85 @@ def test_c5_trend_policy_trains():
     tr2 = VecPPOTrainer(40, 10, "lstm", hidden=128, device=DEV, seed=3, trend_k=1, use_curriculum=False, epochs=1)
     tr2.train_iteration()
     assert np.isfinite(tr2.losses()).all() and tr2.buf["obs"].shape[-1] == 7
+
+
+# --------------------------------------------------------------------------------------------- range guard
+def _oracle_one_update(tr, d, h0, c0, last_val, mode, epochs):
+    p = cpu_params(tr.policy)
+    adam = po.AdamState(p)
+    log, _, _ = oracle_lstm_update(p, adam, d["obs"], d["act"], d["rew"], d["val"], d["logp"], d["done"], d["keep"],
+                                   h0, c0, epochs, mode, last_val)
+    return p, log
+
+
+@pytest.mark.parametrize("what", ["weights", "obs", "h0"])
+def test_range_guard_switches_to_wide_range_kernels(what):
+    """include/uavppo.h range note: the fp16-split kernels need |w| < 65504, |x| < 4096, |h0| < 64.  The trainer measures
+    all three (uav_absmax / uav_clip_adam's pmax_out) and runs the bf16-split kernels when one is violated -- without
+    an environment variable -- and counts the event; results still match the f32 oracle."""
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    N, T, H = 10, 12, 64
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=3, use_curriculum=False, epochs=1, lr=1e-6)
+    d, last_val = _fill_synthetic(tr, N, T, 1, H, seed=5)
+    h0 = torch.randn(1, N, H) * 0.3
+    c0 = torch.randn(1, N, H) * 0.3
+    if what == "weights":
+        with torch.no_grad():       # one recurrent weight far outside fp16's range (the unit saturates; everything stays finite)
+            tr.policy.views["lstm.weight_hh_l0"][5, 7] = 1.0e5
+    elif what == "obs":
+        d["obs"][..., 0] *= 1.0e4
+        tr.buf["obs"].copy_(torch.from_numpy(d["obs"]))
+    else:
+        h0[0, :, 3] = 100.0
+    tr.h0.copy_(h0)
+    tr.c0.copy_(c0)
+    want, log = _oracle_one_update(tr, d, h0, c0, last_val, "reference_exact", 1)
+    tr.record = True
+    tr.update()
+    assert tr.arith == "bf16x6" and tr.range_events == 1 and ops.get_lstm_arith(DEV) == "bf16x6"
+    s = tr.log[0][0].cpu().numpy()
+    assert np.isfinite(s).all()
+    assert np.allclose(s[:3] / (N * T), log[0, :3], rtol=3e-4, atol=3e-6), (s[:3] / (N * T), log[0])
+    assert np.isclose(tr.log[0][1].item(), log[0, 3], rtol=3e-3)
+    # in range again -> back to the fp16 split on the next probe
+    tr2 = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=3, use_curriculum=False, epochs=1)
+    _fill_synthetic(tr2, N, T, 1, H, seed=5)
+    tr2.update()
+    assert tr2.arith == "fp16x3" and tr2.range_events == 0 and ops.get_lstm_arith(DEV) == "fp16x3"
+
+
+def test_range_guard_in_the_training_loop():
+    """Weights pushed out of fp16's range between iterations: the next rollout takes the step-wise path on the bf16-split
+    kernels (uav_rollout has only the fp16 form), training stays finite; in range it stays on the fused kernel."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(64, 16, "lstm", hidden=128, device=DEV, seed=4, epochs=2)
+    tr.train_iteration()
+    assert tr.arith == "fp16x3" and tr.range_events == 0
+    with torch.no_grad():
+        tr.policy.views["lstm.weight_hh_l0"][0, 0] = 7.0e4
+    tr.train_iteration()
+    assert tr.arith == "bf16x6" and tr.range_events >= 1
+    assert np.isfinite(tr.losses()).all() and torch.isfinite(tr.policy.flat).all()
+    with torch.no_grad():
+        tr.policy.views["lstm.weight_hh_l0"][0, 0] = 0.01
+    tr.train_iteration()
+    tr.train_iteration()
+    assert tr.arith == "fp16x3"
+
+
+def test_adam_publishes_max_abs_param(ops=None):
+    from uavppo import ops
+    n = 5000
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g).to(DEV)
+    p[1234] = -77.0
+    grad = (torch.randn(n, generator=g) * 1e-3).to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    out = torch.full((1,), -1.0, device=DEV)
+    ops.clip_adam(p, grad, m, v, 1, 1e-3, pmax_out=out)
+    assert out.item() == p.abs().max().item() and 76.9 < out.item() < 77.1
+    x = torch.randn(100000, generator=g).to(DEV)
+    assert ops.absmax(x).item() == x.abs().max().item()
+    x[77] = float("nan")
+    assert ops.absmax(x).item() == float("inf")

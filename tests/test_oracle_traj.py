@@ -95,3 +95,110 @@ def test_v21_writer_fields_and_segment_loader(tmp_path):
         assert np.array_equal(s_["positions"], o["positions"]) and np.array_equal(s_["concentrations"], o["concentrations"])
         assert np.array_equal(s_["source_pos"], o["source_pos"]) and s_["sigma"] == o["sigma"] == np.float32(15.0)
     assert np.array_equal(segs[-1]["positions"][-1], [43.0, 53.0])              # the last logged step carries the source position
+
+
+# ---- pins against the reference's own writer / loaders and its schema dump -------------------------------------------
+def _golden_traj():
+    import json
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "traj_log.npz"), allow_pickle=False)
+    meta = json.loads(str(g["meta_json"]))
+    eps = []
+    for k, (ep, steps) in enumerate(g["episodes_idx"]):
+        sx, sy, sc = g[f"in{k}/src"]
+        eps.append((int(ep), int(steps), g[f"in{k}/x"], g[f"in{k}/y"], g[f"in{k}/c"], float(sx), float(sy), float(sc)))
+    return g, meta, eps
+
+
+def _product_modules():
+    sys.path.insert(0, ROOT)
+    try:
+        import data_loader
+        import netcdf_writer
+    finally:
+        sys.path.remove(ROOT)
+    return netcdf_writer, data_loader
+
+
+def test_writer_matches_the_reference_writer(tmp_path):
+    """tests/golden/traj_log.npz: arrays the reference's NetCDFWriter classes (PPOV2.0/netcdf_writer.py:4-114,
+    PPOV2.1/model.py:351-422) left behind for the recorded write_episode_data calls.  Oracle restatement and product
+    writer (npz back end) must hold the same values in the same variables, dtypes and fills."""
+    g, meta, eps = _golden_traj()
+    nw, _ = _product_modules()
+    for ver, extra in (("PPOV2.0", {}), ("PPOV2.1", {"sigma": 15.0, "peak": 100.0})):
+        E, S = meta[ver]["dimensions"]["episode"], meta[ver]["dimensions"]["step"]
+        a = to.writer_arrays(E, S)
+        path = str(tmp_path / f"{ver}.npz")
+        w = nw.NetCDFWriter(path, 500, max_episodes=E, max_steps=S)
+        for e in eps:
+            to.write_episode(a, *e, **extra)
+            w.write_episode_data(*e, **extra)
+        w.close()
+        d = np.load(path)
+        assert int(d["GRID_SIZE"]) == meta[ver]["global"]["GRID_SIZE"] == 500
+        for name, info in meta[ver]["variables"].items():
+            want = g[f"{ver}/{name}"]
+            assert d[name].dtype == want.dtype == np.dtype(info["dtype"]), name
+            assert np.array_equal(d[name], want, equal_nan=True), (ver, name)
+            if name in a:
+                assert np.array_equal(a[name], want, equal_nan=True), (ver, name, "oracle")
+            assert nw.ATTRS[name] == info["attrs"], name
+        if ver == "PPOV2.0":        # PPOV2.0's writer has no sigma / peak variables; ours keeps them at the fill value
+            assert set(meta[ver]["variables"]) == set(nw.ATTRS) - {"gaussian_sigma", "peak_concentration"}
+        else:
+            assert set(meta[ver]["variables"]) == set(nw.ATTRS)
+
+
+def test_loaders_match_the_reference_loaders(tmp_path):
+    """load_raw_sequences (PPOV2.0/data_loader.py:5-22) and load_trajectory_segments (PPOV2.1/model.py:68-90) run by the
+    reference on its own writer's output vs the product's loaders on the product writer's file."""
+    g, meta, eps = _golden_traj()
+    nw, dl = _product_modules()
+    path = str(tmp_path / "training_data.npz")
+    w = nw.NetCDFWriter(path, 500, max_episodes=7, max_steps=40)
+    a = to.writer_arrays(7, 40)
+    for e in eps:
+        w.write_episode_data(*e, sigma=15.0, peak=100.0)
+        to.write_episode(a, *e, sigma=15.0, peak=100.0)
+    w.close()
+    seqs, concs = dl.load_raw_sequences(path)
+    assert [len(s) for s in seqs] == g["v20_raw/lens"].tolist()
+    assert np.array_equal(np.asarray([v for s in seqs for v in s], np.float64), g["v20_raw/flat"])
+    assert np.array_equal(np.asarray(concs, np.float64), g["v20_raw/source_concs"])
+    oseqs, oconcs = to.load_raw_sequences(a)
+    assert [len(s) for s in oseqs] == g["v20_raw/lens"].tolist() and np.array_equal(np.asarray(oconcs, np.float64), g["v20_raw/source_concs"])
+    for segs in (dl.load_trajectory_segments(path, window_size=20), to.load_trajectory_segments(a, window_size=20)):
+        assert len(segs) == len(g["v21_seg/sigma"])
+        assert np.array_equal(np.stack([s["positions"] for s in segs]).astype(np.float64), g["v21_seg/positions"])
+        assert np.array_equal(np.stack([s["concentrations"] for s in segs]).astype(np.float64), g["v21_seg/concentrations"])
+        assert np.array_equal(np.stack([s["source_pos"] for s in segs]).astype(np.float64), g["v21_seg/source_pos"])
+        assert np.array_equal(np.asarray([s["sigma"] for s in segs], np.float64), g["v21_seg/sigma"])
+
+
+def test_writer_layout_matches_the_reference_schema_dump(tmp_path):
+    """tests/golden/nc_schema.json = PPOV2.1/nc_info.txt:1-46 (the reference's dump of its training_data.nc): dimension
+    sizes, variable names, shapes, dtypes, _FillValue and text attributes of the product writer's default layout."""
+    import json
+    schema = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nc_schema.json"), encoding="utf-8"))
+    nw, _ = _product_modules()
+    path = str(tmp_path / "training_data.npz")
+    w = nw.NetCDFWriter(path, 500)                      # defaults: max_episodes=2000, max_steps=1000 (train_ppo2.0.py:119-125)
+    w.write_episode_data(3, 5, np.arange(5.0), np.arange(5.0), np.full(5, 50.0), 449.0, 51.0, 100.0, sigma=15.0, peak=100.0)
+    w.close()
+    d = np.load(path)
+    assert schema["dimensions"] == {"episode": w.max_episodes, "step": w.max_steps} == {"episode": 2000, "step": 1000}
+    files = set(d.files) - {"GRID_SIZE", "attrs_json"}
+    assert files == set(schema["variables"])
+    attrs = json.loads(str(d["attrs_json"]))
+    for name, v in schema["variables"].items():
+        assert list(d[name].shape) == v["shape"] and str(d[name].dtype) == v["dtype"], name
+        text = {k: val for k, val in v["attrs"].items() if k != "_FillValue"}
+        assert attrs[name] == text, name
+        if "_FillValue" in v["attrs"]:                  # the unwritten part holds the declared fill value
+            fill = v["attrs"]["_FillValue"]
+            blank = d[name][0]                          # episode 0 was never written
+            assert (np.isnan(blank).all() if fill == "nan" else (blank == int(fill)).all()), name
+        if "min" in v and name in ("gaussian_sigma", "peak_concentration", "source_concentration", "is_source"):
+            got = d[name][3]
+            got = got[got != 0] if name == "is_source" else got
+            assert np.all(got >= v["min"]) and np.all(got <= v["max"]), name      # the constants the reference logs

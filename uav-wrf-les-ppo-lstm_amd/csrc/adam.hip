@@ -9,8 +9,9 @@
 constexpr int NORM_BLOCKS = 256;
 
 __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g, int64_t n,
-                                                     double* __restrict__ partial) {
+                                                     double* __restrict__ partial, unsigned* __restrict__ pmax_bits) {
     __shared__ double sm[4];
+    if (pmax_bits && blockIdx.x == 0 && threadIdx.x == 0) *pmax_bits = 0u;      // adam_kernel (next launch) maxes into it
     double q = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const double v = (double)g[i];
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    const double* __restrict__ partial, int nb, float max_norm,
                                                    float* __restrict__ gnorm_out, float b1, float b2,
-                                                   float step_size, float sqrt_bc2, float eps, float decay) {
+                                                   float step_size, float sqrt_bc2, float eps, float decay,
+                                                   unsigned* __restrict__ pmax_bits) {
 #pragma clang fp contract(off)
     __shared__ double sm[4];
     __shared__ float coef_s;
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     __syncthreads();
     const float coef = coef_s;
+    float amax = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * coef;
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1-beta1)
@@ -51,18 +54,48 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / sqrt_bc2 + eps;      // (exp_avg_sq.sqrt() / sqrt(bc2)).add_(eps)
-        p[i] = p[i] * decay - step_size * (mi / denom);
+        const float pn = p[i] * decay - step_size * (mi / denom);
+        p[i] = pn;
+        amax = fmaxf(amax, pn == pn ? fabsf(pn) : __builtin_inff());      // a NaN parameter reads as "out of range"
     }
+    if (pmax_bits) {       // max |param| after this step (bit patterns of non-negative floats order like the floats)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(pmax_bits, __float_as_uint(amax));
+    }
+}
+
+// out[0] = max |x[i]| (NaN counts as +inf); *out zeroed by the memset in front of the launch.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ out) {
+    float amax = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        amax = fmaxf(amax, v == v ? fabsf(v) : __builtin_inff());
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(amax));
+}
+
+extern "C" int uav_absmax(uav_ctx* ctx, const float* x, int64_t n, float* out, uav_stream stream) {
+    UAV_REQUIRE(ctx && x && out && n > 0, "uav_absmax: bad argument");
+    UAV_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), as_stream(stream)));
+    int nb = (int)((n + 4095) / 4096);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3(nb), dim3(256), 0, as_stream(stream), x, n, reinterpret_cast<unsigned*>(out));
+    UAV_LAUNCH_CHECK();
+    return 0;
 }
 
 static int clip_adam_impl(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                           int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
-                          float* gnorm_out, uav_stream stream) {
+                          float* gnorm_out, float* pmax_out, uav_stream stream) {
     UAV_REQUIRE(ctx && param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "uav_clip_adam: bad argument");
+    unsigned* pmax_bits = reinterpret_cast<unsigned*>(pmax_out);
     double* partial = (double*)ctx->ws;
     int nb = (int)((n + 1023) / 1024);
     if (nb > NORM_BLOCKS) nb = NORM_BLOCKS;
-    hipLaunchKernelGGL(sumsq_partial, dim3(nb), dim3(256), 0, as_stream(stream), grad, n, partial);
+    hipLaunchKernelGGL(sumsq_partial, dim3(nb), dim3(256), 0, as_stream(stream), grad, n, partial, pmax_bits);
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr / bc1);
@@ -70,22 +103,23 @@ static int clip_adam_impl(uav_ctx* ctx, float* param, const float* grad, float* 
     int ab = (int)((n + 255) / 256);
     if (ab > 2048) ab = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(ab), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
-                       partial, nb, max_norm, gnorm_out, beta1, beta2, step_size, sqrt_bc2, eps, 1.0f - lr * weight_decay);
+                       partial, nb, max_norm, gnorm_out, beta1, beta2, step_size, sqrt_bc2, eps, 1.0f - lr * weight_decay, pmax_bits);
     UAV_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int uav_clip_adam(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              int64_t step, float lr, float beta1, float beta2, float eps, float max_norm, float* gnorm_out,
-                             uav_stream stream) {
-    return clip_adam_impl(ctx, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, 0.f, max_norm, gnorm_out, stream);
+                             float* pmax_out, uav_stream stream) {
+    return clip_adam_impl(ctx, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, 0.f, max_norm, gnorm_out,
+                          pmax_out, stream);
 }
 
 extern "C" int uav_clip_adamw(uav_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                               int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm,
                               float* gnorm_out, uav_stream stream) {
     return clip_adam_impl(ctx, param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, max_norm,
-                          gnorm_out, stream);
+                          gnorm_out, nullptr, stream);
 }
 
 // SmoothL1Loss(beta), reduction = mean (train_lstm.py:66): loss_sum[0] += sum_i l(pred_i - target_i) (f64, one block, fixed

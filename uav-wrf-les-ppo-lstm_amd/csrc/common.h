@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/uavppo.h"
 
@@ -12,7 +13,14 @@ struct uav_ctx {
     void* ws;          // scratch for two-stage reductions / split-K slabs
     size_t ws_bytes;
     double* pow075;    // device table pow(i, 0.75), i = 0..5000 (env_core.h)
+    int lstm_arith;    // UAV_ARITH_*: how the LSTM sequence kernels evaluate their f32 matrix products (uav_set_lstm_arith)
 };
+
+// arithmetic of the call in flight on this thread (set from ctx->lstm_arith by the LSTM entry points; the launch helpers
+// below them have no ctx argument).  The UAV_LSTM_BF16X6 / UAV_LSTM_F32_MFMA environment variables still force a mode.
+extern thread_local int g_uav_arith;
+static inline bool uav_want_f32_mfma() { return g_uav_arith == UAV_ARITH_F32_MFMA || getenv("UAV_LSTM_F32_MFMA") != nullptr; }
+static inline bool uav_want_bf16x6() { return g_uav_arith == UAV_ARITH_BF16X6 || getenv("UAV_LSTM_BF16X6") != nullptr; }
 
 void uav_set_error(const char* fmt, ...);
 

@@ -3,6 +3,7 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+thread_local int g_uav_arith = 0;
 int env_init_tables(uav_ctx* ctx);
 
 void uav_set_error(const char* fmt, ...) {
@@ -30,6 +31,7 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->num_cu = prop.multiProcessorCount;
     c->ws_bytes = ws_bytes;
     c->pow075 = nullptr;
+    c->lstm_arith = UAV_ARITH_FP16X3;
     if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
         delete c;
         uav_set_error("uav_create: hipMalloc(%zu) failed", ws_bytes);
@@ -43,6 +45,13 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     *out = c;
     return 0;
 }
+
+int uav_set_lstm_arith(uav_ctx* ctx, int mode) {
+    UAV_REQUIRE(ctx && mode >= UAV_ARITH_FP16X3 && mode <= UAV_ARITH_F32_MFMA, "uav_set_lstm_arith: bad argument");
+    ctx->lstm_arith = mode;
+    return 0;
+}
+int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; }
 
 void uav_destroy(uav_ctx* ctx) {
     if (!ctx) return;

@@ -42,8 +42,8 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 // UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split ones)
-static bool f32_mfma_requested() { return getenv("UAV_LSTM_F32_MFMA") != nullptr; }   // read per call: tests toggle it
-static bool bf16x6_requested() { return getenv("UAV_LSTM_BF16X6") != nullptr; }        // the predecessor of the fp16 split
+static bool f32_mfma_requested() { return uav_want_f32_mfma(); }   // read per call: tests toggle it
+static bool bf16x6_requested() { return uav_want_bf16x6(); }        // the predecessor of the fp16 split
 constexpr int TC = 32;      // time steps staged per chunk
 
 #define sigmoidf_ fast_sigmoid
@@ -1942,6 +1942,7 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
                  float* hn, float* cn, float* stash, const float* w_head, const float* b_head, int n_heads, float* heads,
                  uav_stream stream) {
     UAV_REQUIRE(ctx && x && h0 && c0 && w_ih && w_hh && b_ih && b_hh && y && hn && cn, "uav_lstm_fwd: NULL argument");
+    g_uav_arith = ctx->lstm_arith;
     UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_fwd: N=%d T=%d I=%d", N, T, I);
     UAV_REQUIRE(!heads || (w_head && b_head && n_heads > 0 && n_heads <= 8), "uav_lstm_fwd: heads needs w_head, b_head, 1..8 heads");
     hipStream_t st = as_stream(stream);
@@ -1977,6 +1978,7 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
                  const float* dheads, const float* w_head, int n_heads, const float* dhn, const float* dcn, int N,
                  int T, int H, float* dgates, float* dh0, float* dc0, uav_stream stream) {
     UAV_REQUIRE(ctx && stash && w_hh && dgates, "uav_lstm_bwd: NULL argument");
+    g_uav_arith = ctx->lstm_arith;
     UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd: give exactly one of dy / dheads");
     UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd: dheads needs w_head and 1..8 heads");
     UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd: N=%d T=%d", N, T);
@@ -1993,6 +1995,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
                    int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* dw_head, float* dx,
                    uav_stream stream) {
     UAV_REQUIRE(ctx && x && h0 && y && dgates && w_ih && dw_ih && dw_hh && db, "uav_lstm_wgrad: NULL argument");
+    g_uav_arith = ctx->lstm_arith;
     UAV_REQUIRE(N > 0 && T > 0 && I > 0 && H > 0, "uav_lstm_wgrad: N=%d T=%d I=%d H=%d", N, T, I, H);
     UAV_REQUIRE(!dheads || (dw_head && n_heads > 0 && n_heads <= 8), "uav_lstm_wgrad: dheads needs dw_head, 1..8 heads");
     hipStream_t st = as_stream(stream);

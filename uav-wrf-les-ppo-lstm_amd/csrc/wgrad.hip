@@ -925,7 +925,7 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
         rpx = (rpx + KS6 - 1) / KS6 * KS6;
         const int nbx = (int)((NTr + rpx - 1) / rpx);
         const bool x6_ok = (NTr % rpx == 0) && T >= 8 && I <= 6 && (!dheads || NH <= 8) && NTr * 4 * H < (1ll << 30) &&
-                           (y_prev_src == ytop || ytop == nullptr) && !getenv("UAV_LSTM_F32_MFMA");
+                           (y_prev_src == ytop || ytop == nullptr) && !uav_want_f32_mfma();
         if (x6_ok) {
             using GX = WGX<H>;
             static bool attr3 = false;
@@ -936,7 +936,7 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX::LDS));
                 attr3 = true;
             }
-            const bool h3 = !getenv("UAV_LSTM_BF16X6") && !getenv("UAV_WGRAD_BF16X6");
+            const bool h3 = !uav_want_bf16x6() && !getenv("UAV_WGRAD_BF16X6");
             if (h3) {
                 using GH = WGH<H>;
                 static bool attr4 = false;

@@ -97,11 +97,12 @@ class MethaneEnv:
         v.step(self._act)
         v.current_radius = keep
 
-    def step(self, action):
+    def step(self, action, noise=None):
+        """noise: optional two standard normals replacing the draw of environment.py:101 (parity tests)."""
         v = self._vec
         v.current_radius, v.explore_bonus = self.current_radius, self.explore_bonus
         self._act.fill_(int(action))
-        v.step(self._act)
+        v.step(self._act, None if noise is None else torch.as_tensor(noise, dtype=torch.float64).reshape(1, 2).to(v.device))
         obs = v.term_obs[0].cpu().numpy()
         reward = float(v.rew64[0])
         flags = int(v.flags[0])

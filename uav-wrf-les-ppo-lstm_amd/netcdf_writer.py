@@ -9,7 +9,27 @@ an .npz with the same variable names.  PPOV2.1 keeps the same class in model.py:
 gaussian_sigma and peak_concentration, and two more write_episode_data() arguments: both are here, optional."""
 from __future__ import annotations
 
+import json
+
 import numpy as np
+
+# variable attributes of netcdf_writer.py:31-85 / PPOV2.1/model.py:369-398 (the schema PPOV2.1/nc_info.txt:1-46 shows)
+ATTRS = {
+    "episode": {"long_name": "Training episode index"},
+    "step": {"long_name": "Step index within episode"},
+    "x": {"units": "grid unit", "long_name": "Agent x-coordinate"},
+    "y": {"units": "grid unit", "long_name": "Agent y-coordinate"},
+    "concentration": {"long_name": "Methane concentration"},
+    "is_source": {"long_name": "Source position flag"},
+    "source_concentration": {"long_name": "Actual source concentration in each episode"},
+    "source_x": {"long_name": "Actual source x-coordinate"},
+    "source_y": {"long_name": "Actual source y-coordinate"},
+    "gaussian_sigma": {"long_name": "Gaussian distribution standard deviation"},
+    "peak_concentration": {"units": "ppm", "long_name": "Source peak concentration"},
+}
+# netCDF's default fill values, what a variable created WITHOUT fill_value holds where nothing was written
+# (episode, step, gaussian_sigma, peak_concentration in the reference's writer)
+NC_FILL_FLOAT, NC_FILL_INT = np.float32(9.969209968386869e36), np.int32(-2147483647)
 
 
 class NetCDFWriter:
@@ -40,9 +60,12 @@ class NetCDFWriter:
             self.source_y_var = mk("source_y", np.float32, ("episode",), np.nan)
             self.sigma_var = nc.createVariable("gaussian_sigma", np.float32, ("episode",))
             self.peak_var = nc.createVariable("peak_concentration", np.float32, ("episode",))
+            for name, attrs in ATTRS.items():
+                for k, v in attrs.items():
+                    setattr(nc.variables[name], k, v)
         else:
-            self.episode_var = np.zeros(E, np.int32)
-            self.step_var = np.zeros(S, np.int32)
+            self.episode_var = np.full(E, NC_FILL_INT, np.int32)
+            self.step_var = np.full(S, NC_FILL_INT, np.int32)
             self.x_var = np.full((E, S), np.nan, np.float32)
             self.y_var = np.full((E, S), np.nan, np.float32)
             self.conc_var = np.full((E, S), np.nan, np.float32)
@@ -50,8 +73,8 @@ class NetCDFWriter:
             self.source_conc_var = np.full(E, np.nan, np.float32)
             self.source_x_var = np.full(E, np.nan, np.float32)
             self.source_y_var = np.full(E, np.nan, np.float32)
-            self.sigma_var = np.full(E, np.nan, np.float32)
-            self.peak_var = np.full(E, np.nan, np.float32)
+            self.sigma_var = np.full(E, NC_FILL_FLOAT, np.float32)
+            self.peak_var = np.full(E, NC_FILL_FLOAT, np.float32)
 
     def write_episode_data(self, episode_idx, steps, x, y, conc, source_x, source_y, source_conc, sigma=None, peak=None):
         """netcdf_writer.py:87-110 (called for successful episodes only); sigma / peak: PPOV2.1/model.py:405-419."""
@@ -77,4 +100,4 @@ class NetCDFWriter:
                             concentration=self.conc_var, is_source=self.source_var,
                             source_concentration=self.source_conc_var, source_x=self.source_x_var,
                             source_y=self.source_y_var, gaussian_sigma=self.sigma_var, peak_concentration=self.peak_var,
-                            GRID_SIZE=np.int64(self.grid_size))
+                            GRID_SIZE=np.int64(self.grid_size), attrs_json=np.asarray(json.dumps(ATTRS)))

@@ -32,13 +32,16 @@ SIGNATURES = {
     "uav_last_error": (C.c_char_p, []),
     "uav_create": (I32, [C.POINTER(C.c_void_p), I32, SZ]),
     "uav_destroy": (None, [P]),
+    "uav_set_lstm_arith": (I32, [P, I32]),
+    "uav_get_lstm_arith": (I32, [P]),
+    "uav_absmax": (I32, [P, P, I64, P, P]),
     "uav_gae": (I32, [P, P, P, P, P, I32, I32, F32, F32, I32, P, P]),
     "uav_adv_stats": (I32, [P, P, I64, P, P]),
     "uav_adv_normalise": (I32, [P, P, P, I64, P, P, P, P]),
     "uav_ppo_loss": (I32, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P, P, P]),
     "uav_ppo_loss_from_y": (I32, [P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, F32, P, P, P, P]),
     "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, I64, P, P, P, P, P, P]),
-    "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P]),
+    "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P, P]),
     "uav_clip_adamw": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),
     "uav_mse_bce": (I32, [P, P, P, I64, P, P, P]),

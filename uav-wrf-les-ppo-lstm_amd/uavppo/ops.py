@@ -191,8 +191,28 @@ def ppo_loss_from_y(y, w_head, b_head, act, logp_old, adv, ret, val_old, inv_n, 
 
 
 # ----------------------------------------------------------------------------- U3
+ARITH = {"fp16x3": 0, "bf16x6": 1, "f32_mfma": 2}
+
+
+def set_lstm_arith(mode, device=None):
+    """Operand arithmetic of the LSTM sequence kernels on this device's handle (include/uavppo.h, UAV_ARITH_*)."""
+    check(lib().uav_set_lstm_arith(Context.get(device).handle, ARITH[mode]), "uav_set_lstm_arith")
+
+
+def get_lstm_arith(device=None):
+    m = int(lib().uav_get_lstm_arith(Context.get(device).handle))
+    return {v: k for k, v in ARITH.items()}[m]
+
+
+def absmax(x, out=None):
+    """max |x| (NaN -> inf) as a 1-element device tensor; no host sync."""
+    out = torch.empty(1, dtype=F32, device=x.device) if out is None else out
+    check(lib().uav_absmax(_h(x), _p(x, F32, name="x"), x.numel(), _p(out, F32, (1,), "out"), _stream()), "uav_absmax")
+    return out
+
+
 def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, max_norm=0.5,
-              gnorm_out=None):
+              gnorm_out=None, pmax_out=None):
     n = param.numel()
     for t, nm in ((grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if t.numel() != n:
@@ -200,7 +220,8 @@ def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
     check(lib().uav_clip_adam(_h(param), _p(param, F32, name="param"), _p(grad, F32, name="grad"),
                               _p(exp_avg, F32, name="exp_avg"), _p(exp_avg_sq, F32, name="exp_avg_sq"), n, int(step),
                               float(lr), float(beta1), float(beta2), float(eps), float(max_norm),
-                              _p(gnorm_out, F32, (1,), "gnorm_out"), _stream()), "uav_clip_adam")
+                              _p(gnorm_out, F32, (1,), "gnorm_out"), _p(pmax_out, F32, (1,), "pmax_out"), _stream()),
+          "uav_clip_adam")
 
 
 # ----------------------------------------------------------------------------- GEMM

@@ -19,6 +19,10 @@ from .policy import LSTMActorCritic, MLPActorCritic
 
 # reference hyper-parameters, PPOV2.0/config.py:12-18 and train_ppo2.0.py:87,114
 DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, ent_beta=0.01, lr=3e-5, epochs=5, max_grad_norm=0.5)
+# operand ranges of the default (fp16-split) LSTM kernels, include/uavppo.h: |w| < 65504, |x| < 4096, |h0| < 64.  The
+# trainer switches to the bf16-split kernels at HALF of each limit; parameters move by at most lr per optimiser step, so a
+# weight maximum read one iteration late still has that margin.
+RANGE_LIMITS = (0.5 * 65504.0, 0.5 * 4096.0, 0.5 * 64.0)
 
 
 class VecPPOTrainer:
@@ -70,6 +74,14 @@ class VecPPOTrainer:
         self._rollout_forward_valid = False
         self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
         self.log = []
+        # range guard of the fp16-split kernels: device maxima [|param|, |obs|, |h0|], mirrored to pinned host memory
+        self.ranges = torch.zeros(3, **f32)
+        self._ranges_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self._ranges_ev = torch.cuda.Event()
+        self._ranges_state = None    # None: buffers of unknown origin | "pending": copy in flight | "valid"
+        self.arith = "fp16x3"
+        self.range_events = 0        # iterations that ran on the wide-range (bf16-split) kernels
+        self._flat_version = -1
         # environments of this rank: global indices [rank*N, (rank+1)*N)
         self.env_state = torch.zeros(ops.env_state_bytes(N), dtype=torch.uint8, device=d)
         self.cur_obs = torch.zeros(N, D, **f32)
@@ -106,6 +118,42 @@ class VecPPOTrainer:
                                 env_offset=env_shard(self.rank, self.N)[0], n_env_total=self.world * self.N,
                                 trend_k=self.trend_k)
 
+    # ------------------------------------------------------------------------------------------ range guard
+    def _guarded(self):
+        return self.kind == "lstm" and self.policy.hidden in (64, 128)
+
+    def _probe_ranges(self, external=False):
+        """Queue the maxima behind whatever filled the buffers and start their copy to the host (no sync).  max |param|
+        normally comes from the Adam kernel (uav_clip_adam's pmax_out); it is measured here only when the parameters were
+        written by anything else since (torch bumps flat._version on every in-place op).  The recurrent state handed
+        from rollout to rollout is the kernels' own output (|h| < 1): probed only for foreign buffers."""
+        if external or self.policy.flat._version != self._flat_version:
+            ops.absmax(self.policy.flat, out=self.ranges[0:1])
+            self._flat_version = self.policy.flat._version
+        ops.absmax(self.buf["obs"], out=self.ranges[1:2])
+        if external:
+            ops.absmax(self.h0, out=self.ranges[2:3])
+        self._ranges_host.copy_(self.ranges, non_blocking=True)
+        self._ranges_ev.record()
+        self._ranges_state = "pending"
+
+    def check_ranges(self):
+        """Select the kernels' operand arithmetic from the measured maxima: fp16 split inside its range, bf16 split
+        (f32's exponent range, no preconditions) outside.  Waits only for the probe's own copy."""
+        if not self._guarded():
+            return self.arith
+        if self._ranges_state is None:
+            self._probe_ranges(external=True)
+        if self._ranges_state == "pending":
+            self._ranges_ev.synchronize()
+            self._ranges_state = "valid"
+            m = self._ranges_host.tolist()
+            ok = all(v == v and v < lim for v, lim in zip(m, RANGE_LIMITS))
+            self.arith = "fp16x3" if ok else "bf16x6"
+            self.range_events += (not ok)
+        ops.set_lstm_arith(self.arith, self.device)
+        return self.arith
+
     def reset(self):
         ops.env_reset(self.env_state, self.N, self.env_cfg(), self.cur_obs)
         if self.kind == "lstm":
@@ -115,7 +163,19 @@ class VecPPOTrainer:
     # ------------------------------------------------------------------------------------------ R1
     def collect(self, forced_act=None, noise=None):
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
-        if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128) or self.trend_k):
+        self._rollout_forward_valid = False
+        if self._guarded():
+            if self.policy.flat._version != self._flat_version:
+                # parameters written by something other than the Adam kernel (initialisation, load_state_dict):
+                # measure them before the rollout runs on them -- a host sync, but only on such an iteration
+                ops.absmax(self.policy.flat, out=self.ranges[0:1])
+                self._flat_version = self.policy.flat._version
+                wmax = float(self.ranges[0].item())
+                if not wmax < RANGE_LIMITS[0]:
+                    self.arith = "bf16x6"
+            ops.set_lstm_arith(self.arith, self.device)
+        wide = self._guarded() and self.arith != "fp16x3"      # uav_rollout exists in the fp16-split form only
+        if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128) or self.trend_k or wide):
             self.h0.copy_(self.h)
             self.c0.copy_(self.c)
             self._collect_stepwise_lstm(forced_act, noise)
@@ -131,6 +191,8 @@ class VecPPOTrainer:
             self._rollout_forward_valid = reuse
         else:
             self._collect_stepwise(forced_act, noise)
+        if self._guarded():
+            self._probe_ranges()
 
     def _collect_stepwise_lstm(self, forced_act=None, noise=None):
         """Stacked / wide LSTM policies (BASELINE C5: h=256 x2): one cell step per layer + heads GEMM +
@@ -228,6 +290,8 @@ class VecPPOTrainer:
     # ------------------------------------------------------------------------------------------ U1-U3
     def update(self):
         """GAE + EPOCHS x num_minibatches optimiser steps (_update_model, train_ppo2.0.py:15-88)."""
+        if self.check_ranges() != "fp16x3":
+            self._rollout_forward_valid = False
         self.compute_advantages()
         b, hp = self.buf, self.hp
         N, T, M = self.N, self.T, self.num_minibatches
@@ -259,9 +323,10 @@ class VecPPOTrainer:
                 allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
                 self.opt_step += 1
                 ops.clip_adam(self.policy.flat, grad, self.exp_avg, self.exp_avg_sq, self.opt_step, hp["lr"],
-                              max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm)
+                              max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm, pmax_out=self.ranges[0:1])
                 if self.record:
                     self.log.append((self.loss_sums.clone(), self.gnorm.clone()))
+        self._ranges_state = None          # whatever fills the buffers next gets probed again
         return self.loss_sums
 
     # ------------------------------------------------------------------------------------------ T1
@@ -275,9 +340,13 @@ class VecPPOTrainer:
         self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
 
     def train_iteration(self):
+        """collect -> curriculum -> update.  The curriculum needs this rollout's success bits on the host, the ONE host
+        sync of an iteration; placed right after the rollout it also delivers the range probe's maxima before the
+        update's kernels are chosen, and the update then queues with the next rollout straight behind it.  (Either
+        order feeds the new radius / bonus to the NEXT rollout, as model.py:131-133 does.)"""
         self.collect()
-        sums = self.update()
         self.update_curriculum()
+        sums = self.update()
         self.iteration += 1
         return sums
 
