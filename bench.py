@@ -261,8 +261,8 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
         ev[k][0].record()
         tr.collect()
         ev[k][1].record()
-        tr.update_curriculum()      # the iteration's one host sync (success bits + range probe), as train_iteration()
         tr.update()
+        tr.update_curriculum()      # the iteration's one host sync (success bits; the range guard's max |param| rides along)
         tr.iteration += 1
     barrier()
     dt = time.perf_counter() - t0

@@ -305,8 +305,9 @@ def test_ppov11_loop_matches_reference_golden(golden):
     act = g["act"].astype(np.int32)
     steps = len(act)
     ora = OracleEnv("v1.1", seed=int(g["env_seed"]))
-    ora.reset()                                     # MethaneEnv() + the loop's first reset
-    episodes = [(ora.source.copy(), ora.conc, ora.tke)]
+    episodes = [(ora.source.copy(), ora.conc, ora.tke)]          # MethaneEnv() resets once itself (environment.py:39) ...
+    ora.reset()                                                    # ... and the loop resets again before the first step
+    episodes.append((ora.source.copy(), ora.conc, ora.tke))
     noise = np.zeros((steps, 2))
     for t in range(steps):
         st = ora.rs.get_state()

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (pmax_bits) {       // max |param| after this step (bit patterns of non-negative floats order like the floats)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(pmax_bits, __float_as_uint(amax));
+        __shared__ float wmax[4];
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0)      // ONE atomic per block: a few hundred to one address, not a few thousand
+            atomicMax(pmax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
     }
 }
 

@@ -78,7 +78,8 @@ class VecPPOTrainer:
         self.ranges = torch.zeros(3, **f32)
         self._ranges_host = torch.zeros(3, dtype=torch.float32).pin_memory()
         self._ranges_ev = torch.cuda.Event()
-        self._ranges_state = None    # None: buffers of unknown origin | "pending": copy in flight | "valid"
+        self._buffers_own = False    # True between a collect() and the update() that consumes its buffers
+        self._pmax_pending = False   # a copy of the Adam kernel's max |param| is on its way to _ranges_host
         self.arith = "fp16x3"
         self.range_events = 0        # iterations that ran on the wide-range (bf16-split) kernels
         self._flat_version = -1
@@ -119,38 +120,50 @@ class VecPPOTrainer:
                                 trend_k=self.trend_k)
 
     # ------------------------------------------------------------------------------------------ range guard
+    # The fp16-split kernels need |w| < 65504, |x| < 4096, |h0| < 64 (include/uavppo.h).  What can leave that range, and
+    # where it is caught without stalling the loop:
+    #   parameters   move by <= lr per optimiser step.  The Adam kernel publishes max |param| after every step
+    #                (uav_clip_adam's pmax_out); its copy to pinned host memory is read at the iteration's existing host
+    #                sync (the curriculum's), i.e. one iteration late, against HALF the limit.  Parameters written by
+    #                anything else (initialisation, load_state_dict: torch bumps flat._version) are measured before the
+    #                next rollout runs on them -- a sync, on such an iteration only.
+    #   observations / recurrent state of the trainer's OWN rollouts are bounded by construction (positions, field values
+    #                and counters scaled to O(1); |h| < 1), so they are not measured in the loop.  Buffers filled by a
+    #                caller (update() without a preceding collect()) ARE measured, synchronously, before the update.
     def _guarded(self):
         return self.kind == "lstm" and self.policy.hidden in (64, 128)
 
-    def _probe_ranges(self, external=False):
-        """Queue the maxima behind whatever filled the buffers and start their copy to the host (no sync).  max |param|
-        normally comes from the Adam kernel (uav_clip_adam's pmax_out); it is measured here only when the parameters were
-        written by anything else since (torch bumps flat._version on every in-place op).  The recurrent state handed
-        from rollout to rollout is the kernels' own output (|h| < 1): probed only for foreign buffers."""
-        if external or self.policy.flat._version != self._flat_version:
+    def _decide(self, maxima):
+        ok = all(v == v and v < lim for v, lim in zip(maxima, RANGE_LIMITS))
+        self.arith = "fp16x3" if ok else "bf16x6"
+        self.range_events += (not ok)
+        return ok
+
+    def _measure_params(self):
+        """Synchronous probe of the parameters when something other than the Adam kernel wrote them."""
+        if self.policy.flat._version != self._flat_version:
             ops.absmax(self.policy.flat, out=self.ranges[0:1])
             self._flat_version = self.policy.flat._version
-        ops.absmax(self.buf["obs"], out=self.ranges[1:2])
-        if external:
-            ops.absmax(self.h0, out=self.ranges[2:3])
-        self._ranges_host.copy_(self.ranges, non_blocking=True)
-        self._ranges_ev.record()
-        self._ranges_state = "pending"
+            self._decide([float(self.ranges[0].item()), 0.0, 0.0])
+
+    def poll_param_range(self):
+        """Read the Adam kernel's max |param| if its host copy has landed (never waits)."""
+        if self._guarded() and self._pmax_pending and self._ranges_ev.query():
+            self._pmax_pending = False
+            self._decide([float(self._ranges_host[0]), 0.0, 0.0])
 
     def check_ranges(self):
-        """Select the kernels' operand arithmetic from the measured maxima: fp16 split inside its range, bf16 split
-        (f32's exponent range, no preconditions) outside.  Waits only for the probe's own copy."""
+        """Kernel arithmetic for the update about to be queued (see above); sets it on the device's handle."""
         if not self._guarded():
             return self.arith
-        if self._ranges_state is None:
-            self._probe_ranges(external=True)
-        if self._ranges_state == "pending":
-            self._ranges_ev.synchronize()
-            self._ranges_state = "valid"
-            m = self._ranges_host.tolist()
-            ok = all(v == v and v < lim for v, lim in zip(m, RANGE_LIMITS))
-            self.arith = "fp16x3" if ok else "bf16x6"
-            self.range_events += (not ok)
+        if not self._buffers_own:               # foreign buffers: measure everything now
+            ops.absmax(self.policy.flat, out=self.ranges[0:1])
+            ops.absmax(self.buf["obs"], out=self.ranges[1:2])
+            ops.absmax(self.h0, out=self.ranges[2:3])
+            self._flat_version = self.policy.flat._version
+            self._decide(self.ranges.tolist())
+        else:
+            self._measure_params()
         ops.set_lstm_arith(self.arith, self.device)
         return self.arith
 
@@ -165,15 +178,10 @@ class VecPPOTrainer:
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
         self._rollout_forward_valid = False
         if self._guarded():
-            if self.policy.flat._version != self._flat_version:
-                # parameters written by something other than the Adam kernel (initialisation, load_state_dict):
-                # measure them before the rollout runs on them -- a host sync, but only on such an iteration
-                ops.absmax(self.policy.flat, out=self.ranges[0:1])
-                self._flat_version = self.policy.flat._version
-                wmax = float(self.ranges[0].item())
-                if not wmax < RANGE_LIMITS[0]:
-                    self.arith = "bf16x6"
+            self.poll_param_range()
+            self._measure_params()
             ops.set_lstm_arith(self.arith, self.device)
+            self._buffers_own = True
         wide = self._guarded() and self.arith != "fp16x3"      # uav_rollout exists in the fp16-split form only
         if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128) or self.trend_k or wide):
             self.h0.copy_(self.h)
@@ -191,8 +199,6 @@ class VecPPOTrainer:
             self._rollout_forward_valid = reuse
         else:
             self._collect_stepwise(forced_act, noise)
-        if self._guarded():
-            self._probe_ranges()
 
     def _collect_stepwise_lstm(self, forced_act=None, noise=None):
         """Stacked / wide LSTM policies (BASELINE C5: h=256 x2): one cell step per layer + heads GEMM +
@@ -326,7 +332,11 @@ class VecPPOTrainer:
                               max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm, pmax_out=self.ranges[0:1])
                 if self.record:
                     self.log.append((self.loss_sums.clone(), self.gnorm.clone()))
-        self._ranges_state = None          # whatever fills the buffers next gets probed again
+        if self._guarded():                # max |param| of the last Adam step -> pinned host memory, read at the next poll
+            self._ranges_host.copy_(self.ranges, non_blocking=True)
+            self._ranges_ev.record()
+            self._pmax_pending = True
+            self._buffers_own = False
         return self.loss_sums
 
     # ------------------------------------------------------------------------------------------ T1
@@ -338,15 +348,13 @@ class VecPPOTrainer:
             return
         self.curriculum.update_many(gather_episode_successes(self.buf["flags"]))
         self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
+        self.poll_param_range()            # the success bits' host sync has also delivered the Adam kernel's max |param|
 
     def train_iteration(self):
-        """collect -> curriculum -> update.  The curriculum needs this rollout's success bits on the host, the ONE host
-        sync of an iteration; placed right after the rollout it also delivers the range probe's maxima before the
-        update's kernels are chosen, and the update then queues with the next rollout straight behind it.  (Either
-        order feeds the new radius / bonus to the NEXT rollout, as model.py:131-133 does.)"""
         self.collect()
-        self.update_curriculum()
         sums = self.update()
+        self.update_curriculum()
+        self.poll_param_range()
         self.iteration += 1
         return sums
 
