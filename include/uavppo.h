@@ -170,6 +170,18 @@ int uav_mlp_bwd(uav_ctx* ctx, const float* params, const float* x, float* stash,
                 const float* dheads, int64_t B, int in_dim, int h1, int h2, int n_act,
                 float* grad, uav_stream stream);
 
+/* ---- M2 + U2 fused: gradient of the clipped-PPO loss through the reference's MLP policy in ONE pass over the samples
+ * (train_ppo2.0.py:55-86: model forward, Categorical log_prob, the three loss terms, backward).  Forward, loss and backward
+ * of a 16-sample tile stay on the CU (LayerNorm statistics and activations are never written to HBM); what is read is the
+ * 44 algorithmic bytes per sample.  obs [n][6], act i32 [n], logp_old / adv / ret / val_old f32 [n]; inv_n = 1 / (global
+ * sample count); loss_sums f64[4] as uav_ppo_loss; grad: flat f32 gradient in the layout of `params` (overwritten;
+ * includes the head biases).  The fused kernel is specialised for the reference's sizes (in 6, 256, 128, 5 actions); other
+ * sizes take uav_mlp_fwd + uav_ppo_loss + uav_mlp_bwd. */
+int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* obs, const int32_t* act, const float* logp_old,
+                     const float* adv, const float* ret, const float* val_old, int64_t n, int in_dim, int h1, int h2,
+                     int n_act, float inv_n, float clip, float ent_beta, double* loss_sums, float* grad,
+                     uav_stream stream);
+
 /* ---- L1: nn.LSTM-semantics sequence kernels (gate order i,f,g,o; bias b_ih+b_hh;
  * PPOV2.0/model.py:206-212, PPOV2.1/model.py:263).  One layer per call.
  * x [N][T][I], keep [N][T] (1 = carry the recurrent state into step t, 0 = restart from zero;
@@ -250,8 +262,8 @@ int uav_env_materialise(uav_ctx* ctx, const void* state, int n_env, const uav_en
 /* ---- R1: fused persistent rollout (train_ppo2.0.py:157-198 for n_env environments):
  * policy step + sample + env step + store, T steps in one launch; one workgroup owns a tile
  * of envs and keeps h/c in LDS/registers across the time loop.
- * policy_kind 0 = MLP (params as uav_mlp_fwd), 1 = single-layer LSTM (params: w_ih w_hh b_ih
- * b_hh Whead bhead).  Buffers (env,T,.) : obs [N][T][6], act i32, rew, val, logp, done f32
+ * policy_kind 0 = the reference's MLP 6-256-128 (params as uav_mlp_fwd; h, c, keep, stash, y_out unused / NULL; `hidden`
+ * ignored), 1 = single-layer LSTM (params: w_ih w_hh b_ih b_hh Whead bhead).  Buffers (env,T,.) : obs [N][T][6], act i32, rew, val, logp, done f32
  * [N][T], flags u8 [N][T].  cur_obs [N][6] in/out (state to act on), h,c [N][H] in/out (LSTM),
  * keep [N][T] out (LSTM: 0 where the state restarted), last_val [N] out or NULL (V of the state
  * after the last step, for UAV_GAE_STANDARD).  forced_act i32 [N][T] / noise f64 [N][T][2] are

@@ -330,18 +330,18 @@ def test_ppov11_loop_matches_reference_golden(golden):
     def spy(buffer, m, opt):
         sizes.append(len(buffer.states))
         n0 = len(losses)
-        real_loss = t11._t20.ops.ppo_loss
+        real_grad = t11._t20.ops.mlp_ppo_grad
 
         def loss_spy(*a, **k):
-            r = real_loss(*a, **k)
-            s = r[0].cpu().numpy()
+            r = real_grad(*a, **k)
+            s = a[10].cpu().numpy()             # loss_sums
             losses.append((s[0] + s[1] - 0.01 * s[2]) / sizes[-1])
             return r
-        t11._t20.ops.ppo_loss = loss_spy
+        t11._t20.ops.mlp_ppo_grad = loss_spy
         try:
             orig(buffer, m, opt)
         finally:
-            t11._t20.ops.ppo_loss = real_loss
+            t11._t20.ops.mlp_ppo_grad = real_grad
         assert len(losses) - n0 == 5
     t11._update_model = spy
     n_ep = int(g["done"].sum())

@@ -67,6 +67,10 @@ def test_two_ranks_equal_one_rank(tmp_path, policy):
     # whole-buffer advantage normalisation and the averaged gradient -> identical parameters on all ranks
     assert torch.allclose(torch.cat([a["adv"], b["adv"]], 0), one["adv"], atol=1e-5)
     assert torch.equal(a["flat"], b["flat"])
-    assert torch.allclose(a["flat"], one["flat"], atol=2e-6)
+    # Adam turns a gradient g into a step of lr * g / (|g| + eps): an element whose gradient is nearly zero can move by a
+    # different fraction of lr when the ranks' partial sums are added in another order.  Bound the difference by a tenth of
+    # the largest possible movement (4 optimiser steps x lr) and require it to be negligible on average.
+    diff = (a["flat"] - one["flat"]).abs()
+    assert diff.max().item() < 0.1 * 4 * 3e-5 and diff.mean().item() < 2e-7
     assert np.allclose(a["gn"], one["gn"], rtol=1e-3) and a["gn"] == b["gn"]
     assert a["radius"] == b["radius"] == one["radius"] and a["hist"] == one["hist"]

@@ -514,3 +514,128 @@ def test_adam_publishes_max_abs_param(ops=None):
     assert ops.absmax(x).item() == x.abs().max().item()
     x[77] = float("nan")
     assert ops.absmax(x).item() == float("inf")
+
+
+# --------------------------------------------------------------------------------------------- fused MLP kernels
+@pytest.mark.parametrize("n", [1, 7, 16, 100, 256, 5000, 70001])
+def test_fused_mlp_gradient_matches_oracle_and_layered_path(n):
+    """uav_mlp_ppo_grad (forward + loss + backward on chip, csrc/mlp_fused.hip) vs torch-CPU autograd through the oracle's
+    restatement of model.py:42-53 + train_ppo2.0.py:55-83, and vs the layer-by-layer HIP path; ragged last tiles included."""
+    from uavppo import ops
+    from uavppo.policy import MLPActorCritic
+    pol = MLPActorCritic(6, 5, device=DEV, seed=n)
+    with torch.no_grad():        # non-trivial LayerNorm parameters and biases
+        g = torch.Generator().manual_seed(1)
+        for k in ("feature.0.bias", "feature.1.bias", "feature.3.bias", "feature.4.bias", "head.bias"):
+            pol.views[k].copy_(torch.randn(pol.views[k].shape, generator=g) * 0.2)
+        for k in ("feature.1.weight", "feature.4.weight"):
+            pol.views[k].copy_(1 + 0.3 * torch.randn(pol.views[k].shape, generator=g))
+        pol.views["head.weight"].mul_(20.0)
+    rng = np.random.RandomState(n)
+    obs = rng.rand(n, 6).astype(np.float32)
+    act = rng.randint(0, 5, n).astype(np.int32)
+    adv = rng.randn(n).astype(np.float32)
+    ret = rng.randn(n).astype(np.float32)
+    vo = rng.randn(n).astype(np.float32)
+    lp = (np.log(0.2) + 0.3 * rng.randn(n)).astype(np.float32)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    sums = torch.zeros(4, dtype=torch.float64, device=DEV)
+    ops.mlp_ppo_grad(pol.flat, d(obs), d(act), d(lp), d(adv), d(ret), d(vo), 1.0 / n, 0.2, 0.01, sums, pol.grad)
+    got = {k: v.detach().cpu().clone() for k, v in pol.named_grads().items()}
+    got_sums = sums.cpu().numpy()
+    # oracle
+    leaf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in pol.named_views().items()}
+    probs, value, _ = po.mlp_forward(leaf, torch.from_numpy(obs))
+    total, pl, vl, ent = po.ppo_losses(probs, value, torch.from_numpy(act), torch.from_numpy(lp), torch.from_numpy(adv),
+                                       torch.from_numpy(ret), torch.from_numpy(vo))
+    total.backward()
+    assert np.allclose(got_sums[:3] / n, [float(pl), float(vl), float(ent)], rtol=2e-5, atol=1e-6) and got_sums[3] == 0
+    for k in leaf:
+        scale = leaf[k].grad.abs().max().item() + 1e-12
+        err = (got[k] - leaf[k].grad).abs().max().item()
+        # f32 sums over n samples on both sides, in different orders: rounding grows like sqrt(n) * 2^-24
+        assert err <= (2e-5 + 2e-7 * np.sqrt(n)) * scale + 1e-9, (k, err, scale)
+    # layer-by-layer HIP path
+    heads = pol.heads(d(obs))
+    dheads = torch.empty(n, 6, device=DEV)
+    s2 = torch.zeros(4, dtype=torch.float64, device=DEV)
+    ops.ppo_loss_heads(heads, d(act), d(lp), d(adv), d(ret), d(vo), 1.0 / n, 0.2, 0.01, s2, dheads)
+    g2 = pol.backward(dheads).clone()
+    ops.mlp_ppo_grad(pol.flat, d(obs), d(act), d(lp), d(adv), d(ret), d(vo), 1.0 / n, 0.2, 0.01, sums, pol.grad)
+    assert torch.allclose(pol.grad, g2, rtol=2e-4, atol=2e-6 * g2.abs().max().item())
+    assert np.allclose(sums.cpu().numpy(), s2.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,T", [(5, 40), (37, 70)])
+def test_fused_mlp_rollout_matches_oracle_simulation(N, T):
+    """uav_rollout policy_kind 0 (the reference's policy, train_ppo2.0.py:157-198 for N envs) vs a step-by-step oracle
+    simulation on injected noise + forced actions + a materialised bank: env bit-exact, policy outputs to f32 tolerance;
+    and the step-wise HIP path (uav_mlp_fwd + uav_policy_sample + uav_env_step) fills identical buffers."""
+    from uavppo.trainer import VecPPOTrainer
+    bank = FieldBank.from_seed(3 * N, "v2.0", seed=31)
+    mk = lambda: VecPPOTrainer(N, T, "mlp", variant="v2.0", device=DEV, seed=5, bank=bank.interleaved(),
+                               bank_sources=bank.sources, gae_mode="standard", use_curriculum=False, log_info=True)
+    tr, ts = mk(), mk()
+    assert tr.fused_mlp
+    ts.fused_mlp = False
+    for t_ in (tr, ts):
+        t_.radius = 45.0
+        t_.reset()
+    rng = np.random.RandomState(2)
+    noise = rng.randn(N, T, 2)
+    ora = OracleVecEnv(N, bank, "v2.0", radius=45.0)
+    obs = ora.reset()
+    p = cpu_params(tr.policy)
+    acts = np.zeros((N, T), np.int32)
+    want = {k: [] for k in ("obs", "rew", "done", "val", "logp")}
+    for t in range(T):
+        a = []
+        for i, e in enumerate(ora.envs):
+            dd = e.source - e.pos
+            hom = (3 if dd[0] > 0 else 4) if abs(dd[0]) > abs(dd[1]) else (1 if dd[1] > 0 else 2)
+            a.append(hom if (t < 30 or i % 2 == 0) else int(rng.randint(0, 5)))
+        acts[:, t] = a
+        with torch.no_grad():
+            probs, value, _ = po.mlp_forward(p, torch.from_numpy(obs))
+            lp = po.categorical_logp(probs, torch.tensor(a))
+        want["obs"].append(obs.copy())
+        want["val"].append(value[:, 0].numpy().copy())
+        want["logp"].append(lp.numpy().copy())
+        obs, rew, done, reached, info, term = ora.step(np.array(a), noise[:, t])
+        want["rew"].append(rew.astype(np.float32))
+        want["done"].append(done.astype(np.float32))
+    with torch.no_grad():
+        _, v_last, _ = po.mlp_forward(p, torch.from_numpy(obs))
+    fa, nz = torch.from_numpy(acts).to(DEV), torch.from_numpy(noise).to(DEV)
+    tr.collect(forced_act=fa, noise=nz)
+    ts.collect(forced_act=fa, noise=nz)
+    b = {k: v.cpu().numpy() for k, v in tr.buf.items()}
+    assert np.array_equal(b["obs"], np.stack(want["obs"], 1))
+    assert np.array_equal(b["done"], np.stack(want["done"], 1))
+    assert np.array_equal(b["act"], acts)
+    assert np.allclose(b["rew"], np.stack(want["rew"], 1), atol=1e-6, rtol=0)
+    assert np.allclose(b["val"], np.stack(want["val"], 1), atol=2e-5, rtol=1e-4)
+    assert np.allclose(b["logp"], np.stack(want["logp"], 1), atol=2e-5, rtol=1e-4)
+    assert np.array_equal(tr.cur_obs.cpu().numpy(), obs)
+    assert np.allclose(tr.last_val.cpu().numpy(), v_last[:, 0].numpy(), atol=2e-5, rtol=1e-4)
+    assert b["done"].sum() >= 2 and tr.nan_count.item() == 0
+    for k in ("obs", "act", "done", "flags"):
+        assert torch.equal(tr.buf[k], ts.buf[k]), k
+    for k in ("rew", "val", "logp"):
+        assert torch.allclose(tr.buf[k], ts.buf[k], atol=2e-5, rtol=1e-4), k
+    assert torch.allclose(tr.info, ts.info, atol=1e-4) and torch.allclose(tr.last_val, ts.last_val, atol=2e-5)
+
+
+def test_fused_mlp_rollout_logp_is_the_updates_first_forward():
+    """Rollout and update run the same forward code in the same order: at epoch 0 the ratio is exactly 1, so the policy loss
+    is exactly -mean(adv_n) and sampling follows the policy (counter RNG, statistics)."""
+    from uavppo.trainer import VecPPOTrainer
+    N, T = 1024, 32
+    tr = VecPPOTrainer(N, T, "mlp", device=DEV, seed=9, use_curriculum=False, epochs=1)
+    tr.collect()
+    tr.record = True
+    tr.update()
+    s = tr.log[0][0].cpu().numpy()
+    assert abs(s[0] / (N * T) + tr.adv_n.double().mean().item()) < 1e-9
+    freq = torch.bincount(tr.buf["act"].reshape(-1).long(), minlength=5).float() / (N * T)
+    assert (freq - 0.2).abs().max() < 0.02 and (tr.buf["logp"].exp().mean() - 0.2).abs() < 0.01

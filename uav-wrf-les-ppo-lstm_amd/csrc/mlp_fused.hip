@@ -1,0 +1,857 @@
+// mlp_fused.hip -- the reference's OWN policy (PPOV2.0/model.py:17-53: Linear(6,256) -> LayerNorm -> ReLU ->
+// Linear(256,128) -> LayerNorm -> ReLU -> actor Linear(128,5) | critic Linear(128,1)) as two persistent kernels that keep
+// every activation on chip:
+//
+//   rollout_mlp_kernel   R1 for the MLP policy (train_ppo2.0.py:157-198 for N environments x T steps in ONE launch):
+//                        policy forward -> Categorical sample -> env step -> store, 16 environments per workgroup.
+//   mlp_ppo_grad_kernel  U1-U3 up to the gradient (train_ppo2.0.py:55-86): forward, clipped-PPO loss, backward through the
+//                        whole network for tiles of 16 samples; LayerNorm statistics, activations and their gradients
+//                        never leave the CU, weight gradients accumulate in registers over all of a workgroup's tiles and
+//                        leave as one slab per workgroup.  HBM traffic = the 44 algorithmic bytes per sample.
+//
+// Arithmetic: exact f32 (v_mfma_f32_16x16x4_f32 = a k-ordered fmaf chain), the reference's dtype; products are laid out
+// "units on rows, samples on columns" (weights are the A operand), so the accumulator of a lane holds 4 consecutive units
+// of ONE sample and LayerNorm's per-sample reductions are a 4-lane shuffle + one LDS exchange between the 8 waves.
+// Both kernels run the same forward code in the same order: the rollout's log-probabilities are bit-identical to the
+// update's first forward pass.
+#include "env_core.h"
+#include "loss_core.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, EnvParams& P);
+int launch_loss_final(double* partial, int nb, int n_heads, double* loss_sums, float* dhead_bias, hipStream_t st);
+
+#ifdef UAV_X6_PROFILE
+// phase timing (instrumented build only, tools/build_prof.sh): cycles per phase summed over the tiles of workgroup 0,
+// waves 0 (loss wave) and 1
+__device__ unsigned long long g_mlp_prof[2][16];
+#define M_PROF_DECL unsigned long long pm_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pl_ = __builtin_readcyclecounter()
+#define M_PROF_MARK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pm_[i] += n_ - pl_; pl_ = n_; } while (0)
+#define M_PROF_FLUSH() do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2) for (int i_ = 0; i_ < 16; ++i_) g_mlp_prof[threadIdx.x >> 6][i_] = pm_[i_]; } while (0)
+extern "C" int uav_mlp_prof_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_prof), sizeof(g_mlp_prof)) == hipSuccess ? 0 : 1;
+}
+#else
+#define M_PROF_DECL
+#define M_PROF_MARK(i)
+#define M_PROF_FLUSH()
+#endif
+
+namespace {
+
+constexpr int MT = 16;                  // samples (environments) per tile = one MFMA column tile
+constexpr int IN = 6, H1 = 256, H2 = 128, NA = 5, NH = 6;
+constexpr int NWAVE = 8;
+constexpr int AS1 = 260, AS2 = 132;     // row strides (floats) of the a1 / a2 tiles: float4-aligned rows
+constexpr int WS2 = 260;                // row stride of the rollout's LDS image of wave 0's W2 rows (float4-aligned)
+constexpr float LN_EPS_F = 1e-5f;
+constexpr float R_EPS = 1.1920928955078125e-07f;
+
+// flat parameter layout of csrc/mlp.hip: W1 b1 g1 be1 W2 b2 g2 be2 Wh bh
+constexpr int O_W1 = 0, O_B1 = O_W1 + H1 * IN, O_G1 = O_B1 + H1, O_BE1 = O_G1 + H1, O_W2 = O_BE1 + H1,
+              O_B2 = O_W2 + H2 * H1, O_G2 = O_B2 + H2, O_BE2 = O_G2 + H2, O_WH = O_BE2 + H2, O_BH = O_WH + NH * H2,
+              NPARAM = O_BH + NH;
+static_assert(NPARAM == 36230, "MLP parameter count (SURVEY 8a M1)");
+
+// LDS regions common to both kernels (floats).  NC = column tiles (of 16 samples) a workgroup advances together: 1 in the
+// rollout (16 environments per workgroup keep all 256 CUs busy at 4096 environments), 2 in the update (every weight
+// fragment fetched from L2 then feeds two MFMAs, and the per-tile latencies -- barriers, the loss lanes -- are shared by 32
+// samples).
+template <int NC>
+struct Tiles {
+    static constexpr int MS = MT * NC;
+    float* prm;      // b1 g1 be1 [256 each] | b2 g2 be2 [128 each]
+    float* X;        // [MS][8]   observations of the tile, columns 6, 7 zero
+    float* A1;       // [MS][AS1] a1 = relu(LN1(z1)); later dz1
+    float* A2;       // [MS][AS2] a2 = relu(LN2(z2)); later dz2
+    double* red;     // [2][8 waves][MS] per-wave partial sums of the LayerNorm reductions
+    f32x4* HP;       // [8 waves][NC][32] partial head tiles (K split over the waves; rows 0..7 = lanes with kq < 2)
+    float* HD;       // [MS][8]   heads: logits | value
+    static constexpr int FLOATS = 3 * H1 + 3 * H2 + MS * 8 + MS * AS1 + MS * AS2 + 2 * (2 * NWAVE * MS) + NWAVE * NC * 32 * 4 + MS * 8;
+    __device__ __forceinline__ explicit Tiles(float* base) {
+        prm = base;
+        X = prm + 3 * H1 + 3 * H2;
+        A1 = X + MS * 8;
+        A2 = A1 + MS * AS1;
+        red = reinterpret_cast<double*>(A2 + MS * AS2);
+        HP = reinterpret_cast<f32x4*>(red + 2 * NWAVE * MS);
+        HD = reinterpret_cast<float*>(HP + NWAVE * NC * 32);
+    }
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    return f32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]}; }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// sum over the four lanes that hold the same sample (lane & 15) of a wave
+__device__ __forceinline__ double quad_sum(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// One LayerNorm reduction round: every wave leaves (a, b) for its sample columns, then every lane reads the 8 partial
+// pairs of ITS samples in a fixed order.  One barrier inside; the caller syncs before `red` is written again.
+template <int NC>
+__device__ __forceinline__ void ln_exchange(const Tiles<NC>& L, int w, int j, int kq, const double (&a)[NC], const double (&b)[NC],
+                                            double (&A)[NC], double (&B)[NC]) {
+    constexpr int MS = MT * NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double ta = quad_sum(a[c]), tb = quad_sum(b[c]);
+        if (kq == 0) {
+            L.red[w * MS + 16 * c + j] = ta;
+            L.red[(NWAVE + w) * MS + 16 * c + j] = tb;
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        A[c] = 0.0;
+        B[c] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) {
+            A[c] += L.red[i * MS + 16 * c + j];
+            B[c] += L.red[(NWAVE + i) * MS + 16 * c + j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+// z1 -> LN1 -> a1 (to LDS).  Lane (j = lane & 15, kq = lane >> 4) of wave w holds units 32 w + 16 t + 4 kq + r, t < 2,
+// r < 4 of samples 16 c + j.  Leaves xhat1 / rstd1 for the backward.  One barrier inside (ln_exchange); the caller's
+// barrier after it publishes A1.
+template <int NC>
+__device__ __forceinline__ void layer1(const Tiles<NC>& L, const float (&w1a)[2][2], int w, int j, int kq, f32x4 (&xh)[NC][2],
+                                       float (&rstd)[NC]) {
+    f32x4 z[NC][2];
+    double s[NC], q[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float xb0 = L.X[(16 * c + j) * 8 + kq], xb1 = L.X[(16 * c + j) * 8 + 4 + kq];
+        s[c] = 0.0;
+        q[c] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = 32 * w + 16 * t + 4 * kq;
+            f32x4 acc = ld4(L.prm + u);                      // b1
+            acc = mfma4(w1a[t][0], xb0, acc);
+            acc = mfma4(w1a[t][1], xb1, acc);
+            z[c][t] = acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[c] += (double)acc[r];
+                q[c] += (double)acc[r] * (double)acc[r];
+            }
+        }
+    }
+    double S[NC], Q[NC];
+    ln_exchange<NC>(L, w, j, kq, s, q, S, Q);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double mean = S[c] * (1.0 / H1);
+        double var = Q[c] * (1.0 / H1) - mean * mean;        // f64: no cancellation at f32 data precision
+        var = var > 0.0 ? var : 0.0;
+        const float mf = (float)mean;
+        rstd[c] = 1.0f / sqrtf((float)var + LN_EPS_F);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int u = 32 * w + 16 * t + 4 * kq;
+            const f32x4 g = ld4(L.prm + H1 + u), be = ld4(L.prm + 2 * H1 + u);
+            f32x4 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xh[c][t][r] = (z[c][t][r] - mf) * rstd[c];
+                const float pre = xh[c][t][r] * g[r] + be[r];
+                a[r] = pre < 0.f ? 0.f : pre;                // NaN propagates like torch.relu
+            }
+            st4(L.A1 + (16 * c + j) * AS1 + u, a);
+        }
+    }
+}
+
+// z2 -> LN2 -> a2 (to LDS).  Lane holds units 16 w + 4 kq + r of samples 16 c + j.  The K = 256 sum runs in 16 slabs of 16:
+// in slab s the lane group kq multiplies k = 16 s + 4 kq + i, i < 4 -- a permutation of the MFMA's natural k order (any
+// order is a valid dot product as long as A and B agree) that makes BOTH operands four consecutive floats per lane:
+// wa4(s) = W2[16 w + (lane & 15)][16 s + 4 kq .. + 3] is ONE dwordx4 load (registers, LDS or L2), the a1 fragment one
+// ds_read_b128.
+template <int NC, class WA>
+__device__ __forceinline__ void layer2(const Tiles<NC>& L, WA&& wa4, int w, int j, int kq, f32x4 (&xh)[NC], float (&rstd)[NC]) {
+    const int u = 16 * w + 4 * kq;
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = ld4(L.prm + 3 * H1 + u);       // b2
+    const float* brow = L.A1 + j * AS1 + 4 * kq;
+    // four slabs of weights in flight ahead of the MFMAs that use them (L2 latency), never all sixteen (registers)
+    f32x4 wq[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wq[0][i] = wa4(i);
+#pragma unroll
+    for (int ch = 0; ch < H1 / 64; ++ch) {
+        if (ch + 1 < H1 / 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wq[(ch + 1) & 1][i] = wa4(4 * (ch + 1) + i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 a = wq[ch & 1][i];
+            f32x4 b[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) b[c] = ld4(brow + 16 * c * AS1 + 16 * (4 * ch + i));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = mfma4(a[k], b[c][k], acc[c]);
+        }
+        asm volatile("" ::: "memory");
+    }
+    double s1[NC], q1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        s1[c] = 0.0;
+        q1[c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1[c] += (double)acc[c][r];
+            q1[c] += (double)acc[c][r] * (double)acc[c][r];
+        }
+    }
+    double S[NC], Q[NC];
+    ln_exchange<NC>(L, w, j, kq, s1, q1, S, Q);
+    const f32x4 g = ld4(L.prm + 3 * H1 + H2 + u), be = ld4(L.prm + 3 * H1 + 2 * H2 + u);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double mean = S[c] * (1.0 / H2);
+        double var = Q[c] * (1.0 / H2) - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float mf = (float)mean;
+        rstd[c] = 1.0f / sqrtf((float)var + LN_EPS_F);
+        f32x4 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xh[c][r] = (acc[c][r] - mf) * rstd[c];
+            const float pre = xh[c][r] * g[r] + be[r];
+            a[r] = pre < 0.f ? 0.f : pre;
+        }
+        st4(L.A2 + (16 * c + j) * AS2 + u, a);
+    }
+}
+
+// heads = Wh a2 + bh with K = 128 split over the 8 waves (16 each); wave 0 adds the partial tiles in a fixed order and
+// leaves heads[sample][0..5] in HD.  wh[s] = Wh[lane & 15][16 w + 4 s + kq] (0 for rows >= 6).  Barrier inside.
+template <int NC>
+__device__ __forceinline__ void heads_fwd(const Tiles<NC>& L, const float (&wh)[4], const float* __restrict__ bh, int w, int lane) {
+    const int j = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+        const float* brow = L.A2 + (16 * c + j) * AS2 + 16 * w + kq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) hp = mfma4(wh[s], brow[4 * s], hp);
+        if (kq < 2) L.HP[(w * NC + c) * 32 + lane] = hp;
+    }
+    lds_barrier();
+    if (w == 0 && kq < 2) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 t = L.HP[c * 32 + lane];
+#pragma unroll
+            for (int i = 1; i < NWAVE; ++i) t = t + L.HP[(i * NC + c) * 32 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int hd = 4 * kq + r;
+                L.HD[(16 * c + j) * 8 + hd] = t[r] + (hd < NH ? bh[hd] : 0.f);
+            }
+        }
+    }
+}
+
+// ==================================================================================================== rollout
+struct MlpRollBufs {
+    float* cur_obs; float* obs; int32_t* act; float* rew; float* val; float* logp; float* done; uint8_t* flags;
+    float* last_val; const int32_t* forced_act; const double* noise; int32_t* nan_count; float* info; float* heads;
+};
+
+constexpr size_t ROLL_LDS = (size_t)(Tiles<1>::FLOATS + 16 * WS2) * sizeof(float);
+
+__global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob blob, int N, int T, uint64_t iter,
+                                                            const float* __restrict__ params, MlpRollBufs B) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Tiles<1> L(smem);
+    float* W2i = smem + Tiles<1>::FLOATS;                        // [16][WS2] rows 0..15 of W2: wave 0 (the env role) keeps no weight VGPRs
+    __shared__ unsigned short vis[MT * NVIS];
+    __shared__ EnvState es_s[MT];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * MT;
+    const int my_env = n0 + lane;
+    const bool env_lane = (w == 0) && lane < MT && my_env < N;
+    unsigned short* myvis = vis + (lane & 15) * NVIS;
+
+    // ---- parameters
+    for (int i = threadIdx.x; i < H1; i += 512) {
+        L.prm[i] = params[O_B1 + i];
+        L.prm[H1 + i] = params[O_G1 + i];
+        L.prm[2 * H1 + i] = params[O_BE1 + i];
+    }
+    for (int i = threadIdx.x; i < H2; i += 512) {
+        L.prm[3 * H1 + i] = params[O_B2 + i];
+        L.prm[3 * H1 + H2 + i] = params[O_G2 + i];
+        L.prm[3 * H1 + 2 * H2 + i] = params[O_BE2 + i];
+    }
+    for (int i = threadIdx.x; i < 16 * H1; i += 512) W2i[(i >> 8) * WS2 + (i & 255)] = params[O_W2 + i];
+    float w1a[2][2], wh[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 4 * s + kq;
+            w1a[t][s] = k < IN ? params[O_W1 + (32 * w + 16 * t + j) * IN + k] : 0.f;
+        }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wh[s] = j < NH ? params[O_WH + j * H2 + 16 * w + 4 * s + kq] : 0.f;
+    const float* bh = params + O_BH;
+
+    if (w == 0 && lane < MT) {
+        const int n = min(my_env, N - 1);
+        es_s[lane] = env_load(blob, n);
+        for (int k = 0; k < NVIS; ++k) myvis[k] = blob.visited[(size_t)n * NVIS + k];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) L.X[lane * 8 + f] = f < IN ? B.cur_obs[(size_t)n * IN + f] : 0.f;
+    }
+    lds_barrier();
+
+    const float* w2row = W2i + j * WS2 + 4 * kq;
+    const int steps = T + (B.last_val ? 1 : 0);              // one extra value-only pass for V(s_T)
+    if (w != 0) {
+        // ------------------------------------------------------------------ waves 1..7: their rows of W2 in registers
+        f32x4 wA[H1 / 16];
+#pragma unroll
+        for (int s = 0; s < H1 / 16; ++s) wA[s] = ld4(params + O_W2 + (16 * w + j) * H1 + 16 * s + 4 * kq);
+        for (int t = 0; t < steps; ++t) {
+            f32x4 xh1[1][2], xh2[1];
+            float r1[1], r2[1];
+            layer1<1>(L, w1a, w, j, kq, xh1, r1);
+            lds_barrier();                                   // a1 visible
+            layer2<1>(L, [&](int s) { return wA[s]; }, w, j, kq, xh2, r2);
+            lds_barrier();                                   // a2 visible
+            heads_fwd<1>(L, wh, bh, w, lane);
+            lds_barrier();                                   // wave 0 has stepped the environments: next observations visible
+        }
+    } else {
+        // ------------------------------------------------------------------ wave 0: its rows from LDS + the env role
+        for (int t = 0; t < steps; ++t) {
+            const bool value_only = (t == T);
+            f32x4 xh1[1][2], xh2[1];
+            float r1[1], r2[1];
+            layer1<1>(L, w1a, w, j, kq, xh1, r1);
+            lds_barrier();                                       // a1 visible
+            layer2<1>(L, [&](int s) { return ld4(w2row + 16 * s); }, w, j, kq, xh2, r2);
+            lds_barrier();                                       // a2 visible
+            heads_fwd<1>(L, wh, bh, w, lane);
+            if (w == 0) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): HD written (single wave)
+                __builtin_amdgcn_wave_barrier();
+                if (lane < MT) {
+                    float z[NA], p[NA];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) z[a] = L.HD[lane * 8 + a];
+                    const float V = L.HD[lane * 8 + NA];
+                    if (value_only) {
+                        if (env_lane) B.last_val[my_env] = V;
+                    } else {
+                        // softmax + Categorical(probs) sample / log_prob (train_ppo2.0.py:161-163,189), as rollout.hip
+                        float m = z[0];
+#pragma unroll
+                        for (int a = 1; a < NA; ++a) m = fmaxf(m, z[a]);
+                        float ssum = 0.f;
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) { p[a] = __expf(z[a] - m); ssum += p[a]; }
+                        float psum = 0.f;
+                        bool bad = false;
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) { p[a] = p[a] / ssum; psum += p[a]; bad |= (p[a] != p[a]); }
+                        if (bad && env_lane) atomicAdd(B.nan_count, 1);
+                        const int eg = P.env_offset + my_env;
+                        const size_t row = (size_t)min(my_env, N - 1) * T + t;
+                        int a_sel;
+                        if (B.forced_act) {
+                            a_sel = B.forced_act[row];
+                        } else {
+                            const uint32_t u_act = philox4x32_10(P.seed, (uint32_t)t, (uint32_t)eg, (uint32_t)iter, RNG_ACTION).x;
+                            const float target = u01_f32(u_act) * psum;
+                            float cdf = 0.f;
+                            a_sel = NA - 1;
+                            bool found = false;
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) {       // inverse CDF: first a with target < cdf
+                                cdf += p[a];
+                                if (!found && target < cdf) { a_sel = a; found = true; }
+                            }
+                        }
+                        a_sel = a_sel < 0 ? 0 : (a_sel > NA - 1 ? NA - 1 : a_sel);
+                        float psel = 0.f;
+#pragma unroll
+                        for (int a = 0; a < NA; ++a) if (a == a_sel) psel = p[a];
+                        const float lp = __logf(fminf(fmaxf(psel / psum, R_EPS), 1.0f - R_EPS));
+                        // environment step (f64, env_core.h) + auto reset
+                        EnvState es = es_s[lane];
+                        double z0, z1, wind_x, wind_y;
+                        if (B.noise) { z0 = B.noise[2 * row]; z1 = B.noise[2 * row + 1]; }
+                        else env_step_noise(P, eg, es, z0, z1);
+                        env_step_wind(es, z0, z1, wind_x, wind_y);
+                        StepOut so;
+                        env_step_core(P, eg, es, myvis, a_sel, wind_x, wind_y, so);
+                        if (env_lane) {
+#pragma unroll
+                            for (int f = 0; f < IN; ++f) B.obs[row * IN + f] = L.X[lane * 8 + f];
+                            B.act[row] = a_sel;
+                            B.rew[row] = (float)so.reward;
+                            B.val[row] = V;
+                            B.logp[row] = lp;
+                            B.done[row] = so.done ? 1.f : 0.f;
+                            B.flags[row] = (uint8_t)((so.done ? 1 : 0) | (so.reached ? 2 : 0));
+                            if (B.heads) {
+#pragma unroll
+                                for (int a = 0; a < NA; ++a) B.heads[row * NH + a] = z[a];
+                                B.heads[row * NH + NA] = V;
+                            }
+                            if (B.info) {
+#pragma unroll
+                                for (int f = 0; f < 5; ++f) B.info[row * 10 + f] = (float)so.info[f];
+                                B.info[row * 10 + 5] = so.obs[2];
+                                B.info[row * 10 + 6] = es.px;    // agent_pos after the move (before any auto-reset)
+                                B.info[row * 10 + 7] = es.py;
+                                B.info[row * 10 + 8] = (float)es.sx;
+                                B.info[row * 10 + 9] = (float)es.sy;
+                            }
+                        }
+                        if (so.done) {
+                            es.episode += 1;
+                            env_begin_episode(P, eg, es, myvis);
+                            env_obs(P, es, myvis, so.obs);
+                        }
+#pragma unroll
+                        for (int f = 0; f < IN; ++f) L.X[lane * 8 + f] = so.obs[f];
+                        es_s[lane] = es;
+                    }
+                }
+            }
+            lds_barrier();                                       // next observations visible; HD / HP free again
+        }
+    }
+    if (env_lane) {
+        env_store(blob, my_env, es_s[lane]);
+        for (int k = 0; k < NVIS; ++k) blob.visited[(size_t)my_env * NVIS + k] = myvis[k];
+#pragma unroll
+        for (int f = 0; f < IN; ++f) B.cur_obs[(size_t)my_env * IN + f] = L.X[lane * 8 + f];
+    }
+}
+
+// ==================================================================================================== update
+// LDS of the update kernel: the tiles + the per-(sample lane, unit) accumulators of the LayerNorm / bias gradients
+//   ACC1 [3][16][256] (dg1, dbe1, db1)   ACC2 [3][16][128] (dg2, dbe2, db2)   DH [MS][8] dheads
+constexpr int UNC = 2;                  // column tiles per workgroup step: 32 samples
+constexpr int UMS = MT * UNC;
+constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 3 * MT * H1 + 3 * MT * H2 + UMS * 8;
+constexpr size_t UPD_LDS = (size_t)UPD_FLOATS * sizeof(float);
+constexpr int SLAB = NPARAM;            // one gradient slab per workgroup, flat parameter layout
+
+__global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
+    const float* __restrict__ params, const float* __restrict__ obs, const int32_t* __restrict__ act,
+    const float* __restrict__ logp_old, const float* __restrict__ adv, const float* __restrict__ ret,
+    const float* __restrict__ val_old, int64_t Bn, float inv_n, float clip, float beta, double* __restrict__ loss_partial,
+    float* __restrict__ slabs, const float* __restrict__ w2t) {
+    constexpr int NC = UNC, MS = UMS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Tiles<NC> L(smem);
+    float* ACC1 = smem + Tiles<NC>::FLOATS;
+    float* ACC2 = ACC1 + 3 * MT * H1;
+    float* DH = ACC2 + 3 * MT * H2;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+
+    // ---- parameters: LayerNorm / bias vectors in LDS, the small weight fragments in registers
+    for (int i = threadIdx.x; i < H1; i += 512) {
+        L.prm[i] = params[O_B1 + i];
+        L.prm[H1 + i] = params[O_G1 + i];
+        L.prm[2 * H1 + i] = params[O_BE1 + i];
+    }
+    for (int i = threadIdx.x; i < H2; i += 512) {
+        L.prm[3 * H1 + i] = params[O_B2 + i];
+        L.prm[3 * H1 + H2 + i] = params[O_G2 + i];
+        L.prm[3 * H1 + 2 * H2 + i] = params[O_BE2 + i];
+    }
+    for (int i = threadIdx.x; i < 3 * MT * H1 + 3 * MT * H2; i += 512) ACC1[i] = 0.f;
+    float w1a[2][2], wh[4], whT[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 4 * s + kq;
+            w1a[t][s] = k < IN ? params[O_W1 + (32 * w + 16 * t + j) * IN + k] : 0.f;
+        }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wh[s] = j < NH ? params[O_WH + j * H2 + 16 * w + 4 * s + kq] : 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) whT[s] = (4 * s + kq) < NH ? params[O_WH + (4 * s + kq) * H2 + 16 * w + j] : 0.f;
+    // W2 is NOT held in registers: the 64 + 64 VGPRs of its two orientations beside the 64 of the dW2 accumulators spill
+    // (measured: 85 VGPRs to scratch).  Both orientations are streamed from L2 instead -- 256 KB per 32 samples and CU,
+    // dwordx4 per lane thanks to the permuted k order -- W2 row-major for the forward, its transpose (w2t, made once per
+    // call) for da1 = W2^T dz2.
+    const float* wfw = params + O_W2 + (16 * w + j) * H1 + 4 * kq;           // forward:  W2[16 w + j][16 s + 4 kq ..]
+    const float* wbw0 = w2t + (32 * w + j) * H2 + 4 * kq;                    // backward: W2^T[32 w + 16 t + j][16 s + 4 kq ..]
+    const float* wbw1 = wbw0 + 16 * H2;
+    const float* bh = params + O_BH;
+
+    f32x4 dW2[16], dW1[2], dWh;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dW2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dW1[0] = dW1[1] = dWh = f32x4{0.f, 0.f, 0.f, 0.f};
+    LossAcc lacc{0.0, 0.0, 0.0, 0.0};
+    float s_db[NH];
+#pragma unroll
+    for (int k = 0; k < NH; ++k) s_db[k] = 0.f;
+
+    const int64_t ntile = (Bn + MS - 1) / MS;
+    M_PROF_DECL;
+    for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int64_t s0 = tile * MS;
+        // ---- stage the tile's observations; the loss lanes fetch their per-sample scalars early
+        if (threadIdx.x < MS * 8) {
+            const int sj = threadIdx.x >> 3, f = threadIdx.x & 7;
+            L.X[threadIdx.x] = (f < IN && s0 + sj < Bn) ? obs[(s0 + sj) * IN + f] : 0.f;
+        }
+        int a_s = 0;
+        float lpo = 0.f, Ad = 0.f, Rt = 0.f, vo = 0.f;
+        const bool loss_lane = (w == 0) && lane < MS && s0 + lane < Bn;
+        if (loss_lane) {
+            a_s = act[s0 + lane]; lpo = logp_old[s0 + lane]; Ad = adv[s0 + lane]; Rt = ret[s0 + lane]; vo = val_old[s0 + lane];
+        }
+        lds_barrier();
+        M_PROF_MARK(0);
+        // ---- forward
+        f32x4 xh1[NC][2], xh2[NC];
+        float r1[NC], r2[NC];
+        layer1<NC>(L, w1a, w, j, kq, xh1, r1);
+        lds_barrier();
+        M_PROF_MARK(1);
+        layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
+        lds_barrier();
+        M_PROF_MARK(2);
+        heads_fwd<NC>(L, wh, bh, w, lane);
+        M_PROF_MARK(3);
+        // ---- loss + d(total)/d(heads) for the tile's samples (lanes 0..MS-1 of wave 0)
+        if (w == 0) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < MS) {
+                float dz[NA], dV = 0.f;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) dz[a] = 0.f;
+                if (loss_lane) {
+                    float z[NA];
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) z[a] = L.HD[lane * 8 + a];
+                    dV = ppo_sample<NA>(z, L.HD[lane * 8 + NA], a_s, lpo, Ad, Rt, vo, inv_n, clip, beta, lacc, dz);
+#pragma unroll
+                    for (int a = 0; a < NA; ++a) s_db[a] += dz[a];
+                    s_db[NA] += dV;
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a) DH[lane * 8 + a] = dz[a];
+                DH[lane * 8 + NA] = dV;
+                DH[lane * 8 + 6] = 0.f;
+                DH[lane * 8 + 7] = 0.f;
+            }
+        }
+        lds_barrier();
+        M_PROF_MARK(4);
+        // ---- heads backward: dWh += dheads^T a2 (K = the tile's samples), da2 = Wh^T dheads
+#pragma unroll
+        for (int s = 0; s < MS / 4; ++s) {
+            const float a = j < 8 ? DH[(4 * s + kq) * 8 + j] : 0.f;
+            dWh = mfma4(a, L.A2[(4 * s + kq) * AS2 + 16 * w + j], dWh);
+        }
+        // ---- LayerNorm 2 + ReLU backward (mlp.hip: ln_relu_bwd_kernel's arithmetic)
+        f32x4 dz2[NC];
+        {
+            const int u = 16 * w + 4 * kq;
+            const f32x4 g = ld4(L.prm + 3 * H1 + H2 + u), be = ld4(L.prm + 3 * H1 + 2 * H2 + u);
+            f32x4 dxh[NC];
+            double p1[NC], p2[NC];
+            f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = sg, sz = sg;
+            float* a2p = ACC2 + j * H2 + u;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x4 da2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) da2 = mfma4(whT[s], DH[(16 * c + j) * 8 + 4 * s + kq], da2);
+                p1[c] = 0.0;
+                p2[c] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dy = (xh2[c][r] * g[r] + be[r] > 0.f) ? da2[r] : 0.f;
+                    sg[r] += dy * xh2[c][r];
+                    sb[r] += dy;
+                    dxh[c][r] = dy * g[r];
+                    p1[c] += (double)dxh[c][r];
+                    p2[c] += (double)dxh[c][r] * (double)xh2[c][r];
+                }
+            }
+            st4(a2p, ld4(a2p) + sg);                         // dg2, dbe2: this lane's own (sample lane, unit) slots
+            st4(a2p + MT * H2, ld4(a2p + MT * H2) + sb);
+            double S1[NC], S2[NC];
+            ln_exchange<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dWh reads of A2 are done
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float m1 = (float)(S1[c] * (1.0 / H2)), m2 = (float)(S2[c] * (1.0 / H2));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dz2[c][r] = r2[c] * (dxh[c][r] - m1 - xh2[c][r] * m2);
+                st4(L.A2 + (16 * c + j) * AS2 + u, dz2[c]);  // dz2 replaces a2
+                sz = sz + dz2[c];
+            }
+            st4(a2p + 2 * MT * H2, ld4(a2p + 2 * MT * H2) + sz);
+        }
+        lds_barrier();                                       // dz2 visible
+        M_PROF_MARK(5);
+        // ---- dW2 += dz2^T a1 (row tile w, all 16 column tiles; K = the tile's samples), da1 = W2^T dz2
+        {
+            float af[MS / 4];
+#pragma unroll
+            for (int s = 0; s < MS / 4; ++s) af[s] = L.A2[(4 * s + kq) * AS2 + 16 * w + j];
+#pragma unroll
+            for (int tj = 0; tj < 16; ++tj) {
+#pragma unroll
+                for (int s = 0; s < MS / 4; ++s) dW2[tj] = mfma4(af[s], L.A1[(4 * s + kq) * AS1 + 16 * tj + j], dW2[tj]);
+                if ((tj & 3) == 3) asm volatile("" ::: "memory");      // four column tiles' fragments at a time
+            }
+        }
+        M_PROF_MARK(6);
+        f32x4 da1[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) da1[c][0] = da1[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float* brow = L.A2 + j * AS2 + 4 * kq;
+            f32x4 wq[2][2][2];                               // [buffer][slab in chunk][row tile]: two slabs ahead
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { wq[0][i][0] = ld4(wbw0 + 16 * i); wq[0][i][1] = ld4(wbw1 + 16 * i); }
+#pragma unroll
+            for (int ch = 0; ch < H2 / 32; ++ch) {
+                if (ch + 1 < H2 / 32) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        wq[(ch + 1) & 1][i][0] = ld4(wbw0 + 16 * (2 * (ch + 1) + i));
+                        wq[(ch + 1) & 1][i][1] = ld4(wbw1 + 16 * (2 * (ch + 1) + i));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4 b[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) b[c] = ld4(brow + 16 * c * AS2 + 16 * (2 * ch + i));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            da1[c][0] = mfma4(wq[ch & 1][i][0][k], b[c][k], da1[c][0]);
+                            da1[c][1] = mfma4(wq[ch & 1][i][1][k], b[c][k], da1[c][1]);
+                        }
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        M_PROF_MARK(7);
+        // ---- LayerNorm 1 + ReLU backward
+        {
+            f32x4 dxh[NC][2];                                // da1 becomes dxhat in place
+            double p1[NC], p2[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) p1[c] = p2[c] = 0.0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int u = 32 * w + 16 * t + 4 * kq;
+                const f32x4 g = ld4(L.prm + H1 + u), be = ld4(L.prm + 2 * H1 + u);
+                f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = sg;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dy = (xh1[c][t][r] * g[r] + be[r] > 0.f) ? da1[c][t][r] : 0.f;
+                        sg[r] += dy * xh1[c][t][r];
+                        sb[r] += dy;
+                        dxh[c][t][r] = dy * g[r];
+                        p1[c] += (double)dxh[c][t][r];
+                        p2[c] += (double)dxh[c][t][r] * (double)xh1[c][t][r];
+                    }
+                float* a1p = ACC1 + j * H1 + u;              // dg1, dbe1: this lane's own (sample lane, unit) slots
+                st4(a1p, ld4(a1p) + sg);
+                st4(a1p + MT * H1, ld4(a1p + MT * H1) + sb);
+            }
+            double S1[NC], S2[NC];
+            ln_exchange<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dW2 reads of A1 are done
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int u = 32 * w + 16 * t + 4 * kq;
+                f32x4 sz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float m1 = (float)(S1[c] * (1.0 / H1)), m2 = (float)(S2[c] * (1.0 / H1));
+                    f32x4 dz1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dz1[r] = r1[c] * (dxh[c][t][r] - m1 - xh1[c][t][r] * m2);
+                    st4(L.A1 + (16 * c + j) * AS1 + u, dz1);  // dz1 replaces a1
+                    sz = sz + dz1;
+                }
+                float* a1p = ACC1 + j * H1 + u + 2 * MT * H1;
+                st4(a1p, ld4(a1p) + sz);
+            }
+        }
+        lds_barrier();                                       // dz1 visible
+        M_PROF_MARK(8);
+        // ---- dW1 += dz1^T x
+#pragma unroll
+        for (int s = 0; s < MS / 4; ++s) {
+            const float b = j < 8 ? L.X[(4 * s + kq) * 8 + j] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dW1[t] = mfma4(L.A1[(4 * s + kq) * AS1 + 32 * w + 16 * t + j], b, dW1[t]);
+        }
+        lds_barrier();                                       // X, A1, A2, DH free for the next tile
+        M_PROF_MARK(9);
+    }
+    M_PROF_FLUSH();
+
+    // ---- this workgroup's gradient slab (flat parameter layout) and loss partial
+    float* slab = slabs + (size_t)blockIdx.x * SLAB;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (j < IN) slab[O_W1 + (32 * w + 16 * t + 4 * kq + r) * IN + j] = dW1[t][r];
+#pragma unroll
+    for (int tj = 0; tj < 16; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[O_W2 + (16 * w + 4 * kq + r) * H1 + 16 * tj + j] = dW2[tj][r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * kq + r < NH) slab[O_WH + (4 * kq + r) * H2 + 16 * w + j] = dWh[r];
+    // per-unit sums over the 16 sample lanes, fixed order
+    for (int i = threadIdx.x; i < 3 * H1; i += 512) {
+        const int q = i / H1, u = i % H1;
+        float s = 0.f;
+#pragma unroll
+        for (int sj = 0; sj < MT; ++sj) s += ACC1[(q * MT + sj) * H1 + u];
+        slab[(q == 0 ? O_G1 : (q == 1 ? O_BE1 : O_B1)) + u] = s;
+    }
+    for (int i = threadIdx.x; i < 3 * H2; i += 512) {
+        const int q = i / H2, u = i % H2;
+        float s = 0.f;
+#pragma unroll
+        for (int sj = 0; sj < MT; ++sj) s += ACC2[(q * MT + sj) * H2 + u];
+        slab[(q == 0 ? O_G2 : (q == 1 ? O_BE2 : O_B2)) + u] = s;
+    }
+    if (w == 0) {
+        // loss sums and the head-bias gradient: the loss lanes park their partial sums, lane 0 adds them in lane order
+        if (lane < MS) {
+            double* pr = L.red + lane * 10;
+            pr[0] = lacc.pl; pr[1] = lacc.vl; pr[2] = lacc.en; pr[3] = lacc.nan;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) pr[4 + k] = (double)s_db[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double* pp = loss_partial + (size_t)LOSS_PSTRIDE * blockIdx.x;
+            for (int k = 0; k < 4 + NH; ++k) {
+                double t = 0.0;
+                for (int sj = 0; sj < MS; ++sj) t += L.red[sj * 10 + k];
+                pp[k] = t;
+                if (k >= 4) slab[O_BH + k - 4] = (float)t;
+            }
+        }
+    }
+}
+
+// w2t[u1][u2] = W2[u2][u1]  (128 KB; once per gradient call)
+__global__ __launch_bounds__(256) void mlp_w2_transpose_kernel(const float* __restrict__ params, float* __restrict__ w2t) {
+    const int i = blockIdx.x * 256 + threadIdx.x;           // i = u1 * H2 + u2
+    if (i < H1 * H2) w2t[i] = params[O_W2 + (i % H2) * H1 + i / H2];
+}
+
+// grad[i] = sum over the workgroups' slabs, 8 independent partial sums in a fixed association (deterministic)
+__global__ __launch_bounds__(256) void mlp_slab_reduce_kernel(const float* __restrict__ slabs, int nb, int n, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nb; b += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p8[k] += slabs[(size_t)(b + k) * n + c];
+    for (; b < nb; ++b) p8[0] += slabs[(size_t)b * n + c];
+    out[c] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+}
+
+}  // namespace
+
+// ---- entry used by uav_rollout (rollout.hip) for policy_kind 0
+int launch_rollout_mlp(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg, const float* params, int horizon,
+                       uint64_t iter, float* cur_obs, float* obs, int32_t* act, float* rew, float* val, float* logp,
+                       float* done, uint8_t* flags, float* last_val, const int32_t* forced_act, const double* noise,
+                       int32_t* nan_count, float* info, float* heads, hipStream_t st) {
+    EnvParams P;
+    int rc = env_params_from_cfg(ctx, cfg, n_env, P);
+    if (rc) return rc;
+    UAV_REQUIRE(P.trend_k == 0, "uav_rollout: the fused MLP rollout has 6 observation features (trend_k = 0)");
+    MlpRollBufs B{cur_obs, obs, act, rew, val, logp, done, flags, last_val, forced_act, noise, nan_count, info, heads};
+    EnvBlob blob = env_blob_view(env_state, n_env);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_mlp_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rollout_mlp_kernel, dim3((n_env + MT - 1) / MT), dim3(512), ROLL_LDS, st, P, blob, n_env, horizon, iter,
+                       params, B);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* obs, const int32_t* act,
+                                const float* logp_old, const float* adv, const float* ret, const float* val_old, int64_t n,
+                                int in_dim, int h1, int h2, int n_act, float inv_n, float clip, float ent_beta,
+                                double* loss_sums, float* grad, uav_stream stream) {
+    UAV_REQUIRE(ctx && params && obs && act && logp_old && adv && ret && val_old && loss_sums && grad && n > 0,
+                "uav_mlp_ppo_grad: bad argument");
+    UAV_REQUIRE(in_dim == IN && h1 == H1 && h2 == H2 && n_act == NA,
+                "uav_mlp_ppo_grad: the fused kernel is the reference's network (6-256-128, 5 actions); got %d-%d-%d, %d",
+                in_dim, h1, h2, n_act);
+    hipStream_t st = as_stream(stream);
+    const int64_t ntile = (n + UMS - 1) / UMS;
+    int nb = ctx->num_cu;
+    if (nb > ntile) nb = (int)ntile;
+    const size_t head = 65536, w2t_bytes = (size_t)H1 * H2 * sizeof(float);      // loss partials | W2^T | slabs
+    UAV_REQUIRE(ctx->ws_bytes >= head + w2t_bytes + (size_t)nb * SLAB * sizeof(float), "uav_mlp_ppo_grad: workspace too small");
+    double* partial = (double*)ctx->ws;
+    float* w2t = (float*)((char*)ctx->ws + head);
+    float* slabs = (float*)((char*)ctx->ws + head + w2t_bytes);
+    hipLaunchKernelGGL(mlp_w2_transpose_kernel, dim3(H1 * H2 / 256), dim3(256), 0, st, params, w2t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ppo_grad_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)UPD_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_ppo_grad_kernel, dim3(nb), dim3(512), UPD_LDS, st, params, obs, act, logp_old, adv, ret, val_old, n,
+                       inv_n, clip, ent_beta, partial, slabs, w2t);
+    hipLaunchKernelGGL(mlp_slab_reduce_kernel, dim3((SLAB + 255) / 256), dim3(256), 0, st, slabs, nb, SLAB, grad);
+    UAV_LAUNCH_CHECK();
+    return launch_loss_final(partial, nb, NH, loss_sums, nullptr, st);
+}

@@ -23,6 +23,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, EnvParams& P);
+int launch_rollout_mlp(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg, const float* params, int horizon,
+                       uint64_t iter, float* cur_obs, float* obs, int32_t* act, float* rew, float* val, float* logp,
+                       float* done, uint8_t* flags, float* last_val, const int32_t* forced_act, const double* noise,
+                       int32_t* nan_count, float* info, float* heads, hipStream_t st);
 
 constexpr int RMT = 16;
 
@@ -541,8 +545,12 @@ extern "C" int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_e
     UAV_REQUIRE(ctx && env_state && params && cur_obs && obs && act && rew && val && logp && done && flags && nan_count,
                 "uav_rollout: NULL argument");
     UAV_REQUIRE(n_env > 0 && horizon > 0, "uav_rollout: n_env=%d horizon=%d", n_env, horizon);
-    UAV_REQUIRE(policy_kind == 1, "uav_rollout: only the LSTM policy (policy_kind 1) has a fused kernel; "
-                                  "the MLP policy rolls out step by step (uav_mlp_fwd + uav_policy_sample + uav_env_step)");
+    UAV_REQUIRE(policy_kind == 0 || policy_kind == 1, "uav_rollout: policy_kind %d (0 = MLP, 1 = LSTM)", policy_kind);
+    if (policy_kind == 0) {      // the reference's MLP policy: csrc/mlp_fused.hip
+        UAV_REQUIRE(!stash && !y_out, "uav_rollout: stash / y_out belong to the LSTM policy");
+        return launch_rollout_mlp(ctx, env_state, n_env, cfg, params, horizon, iter, cur_obs, obs, act, rew, val, logp, done,
+                                  flags, last_val, forced_act, noise, nan_count, info, heads, as_stream(stream));
+    }
     UAV_REQUIRE(h && c && keep, "uav_rollout: LSTM policy needs h, c, keep");
     EnvParams P;
     int rc = env_params_from_cfg(ctx, cfg, n_env, P);

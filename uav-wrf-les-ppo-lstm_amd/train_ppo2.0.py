@@ -54,12 +54,19 @@ def _update_model(buffer, model, optimizer):
     adv_n, ret = ops.adv_normalise(adv, val, ops.adv_stats(adv))               # :35-40
     x, act, lp = d(states), d(actions.to(torch.int32)), d(log_probs)
     loss_sums = None
+    core = model.core
+    fused = (core.in_dim, core.h1, core.h2, core.n_act) == (6, 256, 128, 5)    # the reference's sizes: csrc/mlp_fused.hip
     for _ in range(EPOCHS):                                                    # :43 (one minibatch of the whole buffer)
-        heads = model.core.heads(x)
-        loss_sums, dlogits, dvalue = ops.ppo_loss(heads[:, :5].contiguous(), heads[:, 5].contiguous(), act, lp,
-                                                  adv_n.reshape(-1), ret.reshape(-1), val.reshape(-1), 1.0 / L,
-                                                  CLIP_EPSILON, ENTROPY_BETA)
-        grad = model.core.backward(torch.cat([dlogits, dvalue[:, None]], 1).contiguous())
+        if fused:        # forward + loss + backward of :55-86 in one on-chip pass
+            loss_sums = torch.zeros(4, dtype=torch.float64, device=dev) if loss_sums is None else loss_sums
+            grad = ops.mlp_ppo_grad(core.flat, x, act, lp, adv_n.reshape(-1), ret.reshape(-1), val.reshape(-1), 1.0 / L,
+                                    CLIP_EPSILON, ENTROPY_BETA, loss_sums, core.grad)
+        else:
+            heads = core.heads(x)
+            loss_sums, dlogits, dvalue = ops.ppo_loss(heads[:, :5].contiguous(), heads[:, 5].contiguous(), act, lp,
+                                                      adv_n.reshape(-1), ret.reshape(-1), val.reshape(-1), 1.0 / L,
+                                                      CLIP_EPSILON, ENTROPY_BETA)
+            grad = core.backward(torch.cat([dlogits, dvalue[:, None]], 1).contiguous())
         if isinstance(optimizer, ClipAdam):
             optimizer.step_flat(model.core.flat, grad)
         else:                                                                  # a torch optimiser built on model.parameters()

@@ -274,6 +274,23 @@ def mlp_bwd(params, x, stash, dheads, in_dim=6, h1=256, h2=128, n_act=5, grad=No
     return grad
 
 
+def mlp_ppo_grad(params, obs, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta, loss_sums, grad, in_dim=6, h1=256,
+                 h2=128, n_act=5):
+    """Fused forward + clipped-PPO loss + backward of the reference's MLP policy (csrc/mlp_fused.hip): obs [n, 6] and the
+    per-sample scalars in, flat gradient (layout of `params`) and loss_sums f64[4] out; nothing else touches HBM."""
+    n = obs.shape[0]
+    _t = KERNEL_TIMER.bracket("mlp_ppo_grad")
+    check(lib().uav_mlp_ppo_grad(_h(obs), _p(params, F32, (mlp_param_count(in_dim, h1, h2, n_act),), "params"),
+                                 _p(obs, F32, (n, in_dim), "obs"), _p(act, I32, (n,), "act"),
+                                 _p(logp_old, F32, (n,), "logp_old"), _p(adv, F32, (n,), "adv"), _p(ret, F32, (n,), "ret"),
+                                 _p(val_old, F32, (n,), "val_old"), n, in_dim, h1, h2, n_act, float(inv_n), float(clip),
+                                 float(ent_beta), _p(loss_sums, F64, (4,), "loss_sums"), _p(grad, F32, params.shape, "grad"),
+                                 _stream()), "uav_mlp_ppo_grad")
+    if _t is not None:
+        _t.record()
+    return grad
+
+
 # ----------------------------------------------------------------------------- E1-E5
 ENV_VARIANTS = {"v2.0": 0, "v2.1": 1, "v1.1": 2}
 ENV_MAX_STEPS = {"v2.0": 1000, "v2.1": 1000, "v1.1": 5000}
@@ -501,5 +518,23 @@ def rollout_lstm(env_state, n_env, cfg, params, hidden, horizon, it, cur_obs, h,
                             _p(stash, F32, (N, T, 6 * hidden), "stash"), _p(y, F32, (N, T, hidden), "y"),
                             _p(info, F32, (N, T, 10), "info"), _p(heads, F32, (N, T, 6), "heads"), _stream()),
           "uav_rollout")
+    if _t is not None:
+        _t.record()
+
+
+def rollout_mlp(env_state, n_env, cfg, params, horizon, it, cur_obs, bufs, last_val=None, forced_act=None, noise=None,
+                nan_count=None, info=None, heads=None):
+    """Fused persistent rollout of the reference's MLP policy (csrc/mlp_fused.hip): uav_rollout with policy_kind 0."""
+    N, T = n_env, horizon
+    _t = KERNEL_TIMER.bracket("rollout")
+    check(lib().uav_rollout(_h(cur_obs), _p(env_state, U8, name="env state"), N, C.byref(cfg), 0,
+                            _p(params, F32, name="params"), 0, T, int(it), _p(cur_obs, F32, (N, 6), "cur_obs"), None, None,
+                            _p(bufs["obs"], F32, (N, T, 6), "obs"), _p(bufs["act"], I32, (N, T), "act"),
+                            _p(bufs["rew"], F32, (N, T), "rew"), _p(bufs["val"], F32, (N, T), "val"),
+                            _p(bufs["logp"], F32, (N, T), "logp"), _p(bufs["done"], F32, (N, T), "done"),
+                            _p(bufs["flags"], U8, (N, T), "flags"), None, _p(last_val, F32, (N,), "last_val"),
+                            _p(forced_act, I32, (N, T), "forced_act"), _p(noise, F64, (N, T, 2), "noise"),
+                            _p(nan_count, I32, (1,), "nan_count"), None, None, _p(info, F32, (N, T, 10), "info"),
+                            _p(heads, F32, (N, T, 6), "heads"), _stream()), "uav_rollout")
     if _t is not None:
         _t.record()

@@ -70,6 +70,9 @@ class VecPPOTrainer:
         self.exp_avg_sq = torch.zeros(P, **f32)
         self.opt_step = 0
         self.iteration = 0
+        # the reference's MLP (6-256-128, 5 actions) has fused persistent kernels (csrc/mlp_fused.hip); other sizes, trend
+        # channels and fused_mlp=False take the layer-by-layer path (uav_mlp_fwd / uav_ppo_loss / uav_mlp_bwd + step-wise rollout)
+        self.fused_mlp = policy == "mlp" and D == 6
         self.reuse_rollout_forward = True    # epoch 0 adopts the rollout kernel's stash (same parameters)
         self._rollout_forward_valid = False
         self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
@@ -105,7 +108,7 @@ class VecPPOTrainer:
                 self.work["dy"] = torch.empty(nb * T, H, **f32)
         else:
             nb = N // self.num_minibatches
-            self.work = {"stash": torch.empty(nb * T * (2 * 256 + 2 * 128 + 2), **f32)}
+            self.work = {"stash": None}      # layer-by-layer path only (770 floats per sample); allocated on first use
             self._mlp_tmp = {"rew": torch.zeros(N, **f32), "done": torch.zeros(N, **f32),
                              "flags": torch.zeros(N, dtype=torch.uint8, device=d), "stash": None}
         if policy == "lstm":
@@ -197,6 +200,10 @@ class VecPPOTrainer:
                              stash=self.work["stash0"] if reuse else None, y=self.work["y0"] if reuse else None,
                              info=self.info, heads=self.work["heads"] if reuse else None)
             self._rollout_forward_valid = reuse
+        elif self.fused_mlp:
+            ops.rollout_mlp(self.env_state, self.N, self.env_cfg(), self.policy.flat, self.T, self.iteration, self.cur_obs,
+                            self.buf, last_val=self.last_val, forced_act=forced_act, noise=noise, nan_count=self.nan_count,
+                            info=self.info)
         else:
             self._collect_stepwise(forced_act, noise)
 
@@ -321,11 +328,18 @@ class VecPPOTrainer:
                                                   self.h0[:, sl].contiguous() if M > 1 else self.h0,
                                                   self.c0[:, sl].contiguous() if M > 1 else self.c0, self.work)
                     ops.ppo_loss_heads(heads.view(nb * T, -1), *args)
+                elif self.fused_mlp:
+                    grad = ops.mlp_ppo_grad(self.policy.flat, b["obs"][sl].reshape(nb * T, self.obs_dim), *args[:8],
+                                            self.loss_sums, self.policy.grad)
                 else:
+                    if self.work["stash"] is None:
+                        self.work["stash"] = torch.empty(nb * T * (2 * 256 + 2 * 128 + 2), dtype=torch.float32, device=self.device)
                     heads = self.policy.heads(b["obs"][sl].reshape(nb * T, self.obs_dim), stash=self.work["stash"])
                     ops.ppo_loss_heads(heads, *args)
-                grad = (self.policy.backward(self.dheads, self.work, self.dhead_bias) if self.kind == "lstm"
-                        else self.policy.backward(self.dheads))
+                if self.kind == "lstm":
+                    grad = self.policy.backward(self.dheads, self.work, self.dhead_bias)
+                elif not self.fused_mlp:
+                    grad = self.policy.backward(self.dheads)
                 allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
                 self.opt_step += 1
                 ops.clip_adam(self.policy.flat, grad, self.exp_avg, self.exp_avg_sq, self.opt_step, hp["lr"],
