@@ -33,6 +33,10 @@ int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int6
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st);
 int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T,
                      int H, float* y, float* hn, float* cn, float* stash, hipStream_t st);
+int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
+                const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn,
+                float* cn, float* stash, hipStream_t st);
+bool lstm_h3_step_path(int H);
 int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                      const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0, float* dc0,
                      hipStream_t st);
@@ -1948,7 +1952,9 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
     hipStream_t st = as_stream(stream);
     const bool persistent = (H == 64 || H == 128);
     const bool fuse = I <= 8 && persistent;
-    if (!fuse) {
+    const bool step256 = lstm_h3_step_path(H);      // h = 256: one fused launch per step, input projection inside
+    if (step256) UAV_REQUIRE(stash, "uav_lstm_fwd: stash is required when H is not 64/128");
+    if (!fuse && !step256) {
         // time-batched input projection into the gates slot of the stash: pre = x W_ih^T + (b_ih + b_hh)
         UAV_REQUIRE(stash, "uav_lstm_fwd: stash is required when I > 8 or H is not 64/128");
         float* bsum = (float*)ctx->ws;   // 4H floats at the head of the workspace... kept clear of GEMM slabs below
@@ -1964,8 +1970,9 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
     switch (H) {
         case 64: rc = launch_fwd<64>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, n_heads, heads, &heads_done, st); break;
         case 128: rc = launch_fwd<128>(fuse, x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, n_heads, heads, &heads_done, st); break;
-        default:  // any other hidden size: per-step GEMM + pointwise (lstm_generic.hip)
-            rc = lstm_generic_fwd(ctx, keep, h0, c0, w_hh, N, T, H, y, hn, cn, stash, st);
+        default:  // any other hidden size: one launch per time step (lstm_generic.hip)
+            rc = step256 ? lstm_h3_fwd(ctx, x, I, w_ih, b_ih, b_hh, keep, h0, c0, w_hh, N, T, y, hn, cn, stash, st)
+                         : lstm_generic_fwd(ctx, keep, h0, c0, w_hh, N, T, H, y, hn, cn, stash, st);
     }
     if (rc) return rc;
     // kernels without the fused head product: heads = y W_head^T + b_head as one GEMM over the rows of y

@@ -94,17 +94,30 @@ __global__ void gen_fill(float* __restrict__ x, const float* __restrict__ src, i
 
 
 // ================================================================================================ fp16-split step kernels
-// w [rows][cols] f32 -> pieces [2][rows][cols] fp16 (transpose = false) or [2][cols][rows] (transpose = true)
-__global__ void split_weights_kernel(const float* __restrict__ w, int rows, int cols, int transpose,
+// MFMA-fragment order of an operand matrix M [R][K] (R rows = A rows or B columns, K a multiple of 32): the 8 consecutive
+// k that lane (r16, kq) of a 16x16x32 MFMA feeds from row 16 rt + r16 in slab s sit at
+//   frag[((rt * (K/32) + s) * 2 + piece) * 512 + (kq * 16 + r16) * 8 + i],   k = 32 s + 8 kq + i
+// so one wave-wide dwordx4 load is 1 KB of consecutive bytes (row-major pieces give 16 half-used 128-B lines per load).
+__host__ __device__ inline size_t frag_index(int row, int k, int K, int piece) {
+    return ((size_t)((row >> 4) * (K >> 5) + (k >> 5)) * 2 + piece) * 512 + (size_t)((((k & 31) >> 3) * 16 + (row & 15)) * 8 + (k & 7));
+}
+
+// w [rows][cols] f32 (cols zero-padded to KP) -> fragment-ordered fp16 pieces of w (transpose = 0: A rows = w rows, K = KP)
+// or of w^T (transpose = 1: A rows = w columns, K = rows)
+__global__ void split_weights_kernel(const float* __restrict__ w, int rows, int cols, int KP, int transpose,
                                      unsigned short* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)rows * cols) return;
-    const int r = (int)(i / cols), c = (int)(i % cols);
+    if (i >= (int64_t)rows * KP) return;
+    const int r = (int)(i / KP), c = (int)(i % KP);
     _Float16 p0, p1;
-    split2h(w[i], p0, p1);
-    const int64_t o = transpose ? (int64_t)c * rows + r : i;
-    out[o] = h_bits(p0);
-    out[(int64_t)rows * cols + o] = h_bits(p1);
+    split2h(c < cols ? w[(int64_t)r * cols + c] : 0.f, p0, p1);
+    if (!transpose) {
+        out[frag_index(r, c, KP, 0)] = h_bits(p0);
+        out[frag_index(r, c, KP, 1)] = h_bits(p1);
+    } else {
+        out[frag_index(c, r, rows, 0)] = h_bits(p0);
+        out[frag_index(c, r, rows, 1)] = h_bits(p1);
+    }
 }
 
 // state <- init * keep[:,0], as f32 (hs, cs) and as fp16 piece planes of h (hp [2][N][H])
@@ -120,82 +133,125 @@ __global__ void h3_init_state(const float* __restrict__ h0, const float* __restr
     cs[i] = c0[i] * k;
     _Float16 p0, p1;
     split2h(h, p0, p1);
-    hp[i] = h_bits(p0);
-    hp[(int64_t)N * H + i] = h_bits(p1);
+    const int u = (int)(i % H);
+    hp[frag_index(n, u, H, 0)] = h_bits(p0);
+    hp[frag_index(n, u, H, 1)] = h_bits(p1);
 }
 
 __device__ __forceinline__ f16x8 ldh8(const unsigned short* p) { return *reinterpret_cast<const f16x8*>(p); }
 
-// One time step of one layer: gates = pre (x W_ih^T + b, already in the stash) + W_hh h_{t-1}, cell, outputs.
-// Workgroup = 4 waves = a tile of 64 units x 64 envs; wave w owns units 16 w .. 16 w + 15 of the tile (its four gate row
-// tiles) for the four 16-env column tiles: 16 main + 16 cross accumulators.  K = H in slabs of 32, next slab's fragments in
-// flight while the current one multiplies (1 wave per SIMD: up to 512 VGPRs).  A = weight pieces [2][4H][H], B = h pieces
-// [2][N][H]: lane (r16, kq) reads 8 consecutive k of row / env r16 -- one dwordx4 each.
+// One time step of one layer: gates = (b_ih + b_hh) + W_ih x_t + W_hh h_{t-1}, cell, outputs -- input projection included,
+// so no [N][T][4H] pre-activation array is ever written or read.
+// Workgroup = 8 waves = a tile of 64 units x 64 envs; wave w owns units 16 (w & 3) .. + 15 of the tile (its four gate row
+// tiles) for two of the four 16-env column tiles (w >> 2): 8 main + 8 cross accumulators, two waves per SIMD.
+// K runs over the input (IP = I rounded up to 32, x_t read as f32 and split in registers) and then over H (h_{t-1} as fp16
+// piece planes) in slabs of 32, next slab's fragments in flight while the current one multiplies.
+// A = weight pieces [2][4H][IP] and [2][4H][H], lane (r16, kq) reads 8 consecutive k of row r16 -- one dwordx4.
 template <int H>
-__global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* __restrict__ wp,
+__global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp, int IP,
+                                                          const unsigned short* __restrict__ wp,
+                                                          const float* __restrict__ bsum, const float* __restrict__ x, int I,
                                                           const unsigned short* __restrict__ hp_in,
                                                           unsigned short* __restrict__ hp_out, float* __restrict__ hs,
                                                           float* __restrict__ cs, float* __restrict__ stash,
                                                           const float* __restrict__ keep, int N, int T, int t,
                                                           float* __restrict__ y, float* __restrict__ hn,
                                                           float* __restrict__ cn) {
-    constexpr int NS = H / 32;
+    constexpr int NS = H / 32, NC = 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int e0 = blockIdx.x * 64, u0 = blockIdx.y * 64 + 16 * w;
-    const size_t plane_w = (size_t)4 * H * H, plane_h = (size_t)N * H;
-    const unsigned short* ap[4];
+    const int e0 = blockIdx.x * 64 + 32 * (w >> 2), u0 = blockIdx.y * 64 + 16 * (w & 3);
+    int nrow[NC];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) ap[g] = wp + (size_t)(g * H + u0 + r16) * H + 8 * kq;
-    const unsigned short* bp[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) bp[c] = hp_in + (size_t)min(e0 + 16 * c + r16, N - 1) * H + 8 * kq;
+    for (int c = 0; c < NC; ++c) nrow[c] = min(e0 + 16 * c + r16, N - 1);
 
-    // accumulators start from the input projection: acc[g][c][r] <-> unit u0 + 4 kq + r, env e0 + 16 c + r16
-    f32x4 acc[4][4], acl[4][4];
+    // accumulators start from the bias: acc[g][c][r] <-> unit u0 + 4 kq + r, env e0 + 16 c + r16
+    f32x4 acc[4][NC], acl[4][NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int n = min(e0 + 16 * c + r16, N - 1);
-        const float* sp = stash + ((size_t)n * T + t) * (6 * H) + u0 + 4 * kq;
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(bsum + g * H + u0 + 4 * kq);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4*>(sp + g * H);
+        for (int c = 0; c < NC; ++c) {
             acc[g][c] = f32x4{v.x, v.y, v.z, v.w};
             acl[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    f16x8 a[2][4][2], b[2][4][2];                     // [buffer][gate | col tile][piece]
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { a[0][g][0] = ldh8(ap[g]); a[0][g][1] = ldh8(ap[g] + plane_w); }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { b[0][c][0] = ldh8(bp[c]); b[0][c][1] = ldh8(bp[c] + plane_h); }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < NS) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                a[nxt][g][0] = ldh8(ap[g] + 32 * (s + 1));
-                a[nxt][g][1] = ldh8(ap[g] + plane_w + 32 * (s + 1));
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                b[nxt][c][0] = ldh8(bp[c] + 32 * (s + 1));
-                b[nxt][c][1] = ldh8(bp[c] + plane_h + 32 * (s + 1));
-            }
-        }
+    auto mac = [&](const f16x8 (&a)[4][2], const f16x8 (&b)[NC][2]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acl[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][g][1], b[cur][c][0], acl[g][c], 0, 0, 0);
-                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][g][0], b[cur][c][0], acc[g][c], 0, 0, 0);
-                acl[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][g][0], b[cur][c][1], acl[g][c], 0, 0, 0);
+            for (int c = 0; c < NC; ++c) {
+                acl[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][1], b[c][0], acl[g][c], 0, 0, 0);
+                acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][0], b[c][0], acc[g][c], 0, 0, 0);
+                acl[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][0], b[c][1], acl[g][c], 0, 0, 0);
             }
+    };
+    // ---- input projection: x_t [n][I] f32 -> two fp16 pieces per value, K = IP
+    {
+        const unsigned short* axp[4];                  // fragment order: + s * 1024 per slab, + 512 for the second piece
+#pragma unroll
+        for (int g = 0; g < 4; ++g) axp[g] = wxp + (size_t)((g * H + u0) >> 4) * (IP >> 5) * 1024 + lane * 8;
+        for (int s = 0; s < IP / 32; ++s) {
+            f16x8 a[4][2], b[NC][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { a[g][0] = ldh8(axp[g] + 1024 * s); a[g][1] = ldh8(axp[g] + 1024 * s + 512); }
+            const int k0 = 32 * s + 8 * kq;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float* xr = x + ((size_t)nrow[c] * T + t) * I + k0;
+                float v[8];
+                if (k0 + 8 <= I) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(xr), v1 = *reinterpret_cast<const float4*>(xr + 4);
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < I) ? xr[i] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    _Float16 p0, p1;
+                    split2h(v[i], p0, p1);
+                    b[c][0][i] = p0;
+                    b[c][1][i] = p1;
+                }
+            }
+            mac(a, b);
+        }
+    }
+    // ---- recurrent product, K = H, double-buffered slabs
+    {
+        const unsigned short* ap[4];                   // fragment order (frag_index): 1 KB per wave-wide load
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ap[g] = wp + (size_t)((g * H + u0) >> 4) * NS * 1024 + lane * 8;
+        const unsigned short* bp[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bp[c] = hp_in + (size_t)((e0 + 16 * c) >> 4) * NS * 1024 + lane * 8;
+        f16x8 a[2][4][2], b[2][NC][2];                 // [buffer][gate | col tile][piece]
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { a[0][g][0] = ldh8(ap[g]); a[0][g][1] = ldh8(ap[g] + 512); }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { b[0][c][0] = ldh8(bp[c]); b[0][c][1] = ldh8(bp[c] + 512); }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < NS) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    a[nxt][g][0] = ldh8(ap[g] + 1024 * (s + 1));
+                    a[nxt][g][1] = ldh8(ap[g] + 1024 * (s + 1) + 512);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    b[nxt][c][0] = ldh8(bp[c] + 1024 * (s + 1));
+                    b[nxt][c][1] = ldh8(bp[c] + 1024 * (s + 1) + 512);
+                }
+            }
+            mac(a[cur], b[cur]);
+        }
     }
     // ---- cell (gen_cell_fwd's arithmetic) and outputs
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int n = e0 + 16 * c + r16;
         if (n >= N) continue;
         const size_t row = (size_t)n * T + t, i0 = (size_t)n * H + u0 + 4 * kq;
@@ -239,51 +295,65 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
             uint2 v0, v1;
             v0.x = (unsigned)q0[0] | ((unsigned)q0[1] << 16); v0.y = (unsigned)q0[2] | ((unsigned)q0[3] << 16);
             v1.x = (unsigned)q1[0] | ((unsigned)q1[1] << 16); v1.y = (unsigned)q1[2] | ((unsigned)q1[3] << 16);
-            *reinterpret_cast<uint2*>(hp_out + i0) = v0;
-            *reinterpret_cast<uint2*>(hp_out + plane_h + i0) = v1;
+            const int u = u0 + 4 * kq;                 // four consecutive k of the next step's B fragment
+            *reinterpret_cast<uint2*>(hp_out + frag_index(n, u, H, 0)) = v0;
+            *reinterpret_cast<uint2*>(hp_out + frag_index(n, u, H, 1)) = v1;
         }
     }
 }
 
-// Gate gradients of step t (gen_cell_bwd's arithmetic), one block per env: dgates f32 [n][t][4H] for the weight-gradient
-// pass AND, for the recurrent product, the same row as two fp16 planes scaled by the power of two that puts the row's
-// largest magnitude in [2^13, 2^14) (gradients span dozens of binades; scaled back exactly by step_bwd_h3_kernel).
+__global__ void add2v_kernel(const float* a0, const float* a1, float* b, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) b[i] = a0[i] + a1[i];
+}
+
+// Gate gradients of step t (gen_cell_bwd's arithmetic).  One WAVE per env (H = 256: lane l owns units 4 l .. 4 l + 3):
+// dgates f32 [n][t][4H] for the weight-gradient pass AND, for the recurrent product, the same row as two fp16 planes in MFMA
+// fragment order, scaled by the power of two that puts the row's largest magnitude in [2^13, 2^14) (gradients span dozens
+// of binades; scaled back exactly by step_bwd_h3_kernel).
 template <int H>
-__global__ __launch_bounds__(H) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
-                                                        const float* __restrict__ dy, int N, int T, int t,
-                                                        const float* __restrict__ dh_rec, float* __restrict__ dc_next,
-                                                        float* __restrict__ dgates, unsigned short* __restrict__ dgp,
-                                                        float* __restrict__ inv_scale) {
-    __shared__ float smax[H / 64];
-    const int n = blockIdx.x, u = threadIdx.x;
+__global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
+                                                          const float* __restrict__ dy, int N, int T, int t,
+                                                          const float* __restrict__ dh_rec, float* __restrict__ dc_next,
+                                                          float* __restrict__ dgates, unsigned short* __restrict__ dgp,
+                                                          float* __restrict__ inv_scale) {
+    static_assert(H == 256, "one wave per env: 64 lanes x 4 units");
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), u = 4 * lane;
+    if (n >= N) return;
     const size_t row = (size_t)n * T + t, i = (size_t)n * H + u;
-    const float* sp = stash + row * (6 * H);
-    const float gi = sp[u], gf = sp[H + u], gg = sp[2 * H + u], go = sp[3 * H + u], cp = sp[4 * H + u];
-    const float dh = dy[row * H + u] + dh_rec[i];
-    const float c = gf * cp + gi * gg;
-    const float tch = fast_tanh(c);
-    const float dc = dh * go * (1.0f - tch * tch) + dc_next[i];
-    float g4[4];
-    g4[0] = dc * gg * gi * (1.0f - gi);
-    g4[1] = dc * cp * gf * (1.0f - gf);
-    g4[2] = dc * gi * (1.0f - gg * gg);
-    g4[3] = dh * tch * go * (1.0f - go);
-    float* gp = dgates + row * (4 * H);
-    float m = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        gp[q * H + u] = g4[q];
-        m = fmaxf(m, fabsf(g4[q]));
-    }
+    const float* sp = stash + row * (6 * H) + u;
+    const float4 gi4 = *reinterpret_cast<const float4*>(sp), gf4 = *reinterpret_cast<const float4*>(sp + H);
+    const float4 gg4 = *reinterpret_cast<const float4*>(sp + 2 * H), go4 = *reinterpret_cast<const float4*>(sp + 3 * H);
+    const float4 cp4 = *reinterpret_cast<const float4*>(sp + 4 * H);
+    const float4 dy4 = *reinterpret_cast<const float4*>(dy + row * H + u), dr4 = *reinterpret_cast<const float4*>(dh_rec + i);
+    const float4 dn4 = *reinterpret_cast<const float4*>(dc_next + i);
+    const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+    const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+    const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+    const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w}, drv[4] = {dr4.x, dr4.y, dr4.z, dr4.w}, dnv[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
     const float kp = keep ? keep[row] : 1.f;
-    dc_next[i] = dc * gf * kp;
+    float g4[4][4], dcn[4], m = 0.f;                  // g4[gate][r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float dh = dyv[r] + drv[r];
+        const float c = gf[r] * cp[r] + gi[r] * gg[r];
+        const float tch = fast_tanh(c);
+        const float dc = dh * go[r] * (1.0f - tch * tch) + dnv[r];
+        g4[0][r] = dc * gg[r] * gi[r] * (1.0f - gi[r]);
+        g4[1][r] = dc * cp[r] * gf[r] * (1.0f - gf[r]);
+        g4[2][r] = dc * gi[r] * (1.0f - gg[r] * gg[r]);
+        g4[3][r] = dh * tch * go[r] * (1.0f - go[r]);
+        dcn[r] = dc * gf[r] * kp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(g4[q][r]));
+    }
+    float* gp = dgates + row * (4 * H) + u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(gp + q * H) = float4{g4[q][0], g4[q][1], g4[q][2], g4[q][3]};
+    *reinterpret_cast<float4*>(dc_next + i) = float4{dcn[0], dcn[1], dcn[2], dcn[3]};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((u & 63) == 0) smax[u >> 6] = m;
-    __syncthreads();
-    m = smax[0];
-#pragma unroll
-    for (int k = 1; k < H / 64; ++k) m = fmaxf(m, smax[k]);
     // power of two 2^e with m * 2^e in [2^13, 2^14); exponent clamped so that both the scale and its inverse are normal
     int e = 0;
     if (m > 0.f && m < 3.0e38f) {
@@ -291,61 +361,69 @@ __global__ __launch_bounds__(H) void cell_bwd_h3_kernel(const float* __restrict_
         e = e > 100 ? 100 : (e < -100 ? -100 : e);
     }
     const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
-    if (u == 0) inv_scale[n] = isc * kp;                    // the mask of step t rides on the scale
-    const size_t plane = (size_t)N * 4 * H;
+    if (lane == 0) inv_scale[n] = isc * kp;                 // the mask of step t rides on the scale
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        _Float16 p0, p1;
-        split2h(g4[q] * sc, p0, p1);
-        dgp[(size_t)n * 4 * H + q * H + u] = h_bits(p0);
-        dgp[plane + (size_t)n * 4 * H + q * H + u] = h_bits(p1);
+        unsigned short q0[4], q1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            _Float16 p0, p1;
+            split2h(g4[q][r] * sc, p0, p1);
+            q0[r] = h_bits(p0);
+            q1[r] = h_bits(p1);
+        }
+        uint2 v0, v1;
+        v0.x = (unsigned)q0[0] | ((unsigned)q0[1] << 16); v0.y = (unsigned)q0[2] | ((unsigned)q0[3] << 16);
+        v1.x = (unsigned)q1[0] | ((unsigned)q1[1] << 16); v1.y = (unsigned)q1[2] | ((unsigned)q1[3] << 16);
+        const int k = q * H + u;                            // column of the [N][4H] operand
+        *reinterpret_cast<uint2*>(dgp + frag_index(n, k, 4 * H, 0)) = v0;
+        *reinterpret_cast<uint2*>(dgp + frag_index(n, k, 4 * H, 1)) = v1;
     }
 }
 
 // dh_{t-1}[n][u] = keep[n][t] * sum_k dG_t[n][k] W_hh[k][u]: A = W_hh^T pieces [2][H][4H] (rows = units), B = the scaled dG
 // pieces [2][N][4H]; tile 64 units x 64 envs, wave w: one 16-unit row tile x four env column tiles; K = 4H.
 template <int H>
-__global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* __restrict__ wtp,
+__global__ __launch_bounds__(512) void step_bwd_h3_kernel(const unsigned short* __restrict__ wtp,
                                                           const unsigned short* __restrict__ dgp,
                                                           const float* __restrict__ inv_scale, int N,
                                                           float* __restrict__ dh) {
-    constexpr int K = 4 * H, NS = K / 32, DEPTH = 4;
+    constexpr int K = 4 * H, NS = K / 32, DEPTH = 4, NC = 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int e0 = blockIdx.x * 64, u0 = blockIdx.y * 64 + 16 * w;
-    const size_t plane_w = (size_t)H * K, plane_g = (size_t)N * K;
-    const unsigned short* ap = wtp + (size_t)(u0 + r16) * K + 8 * kq;
-    const unsigned short* bp[4];
+    const int e0 = blockIdx.x * 64 + 32 * (w >> 2), u0 = blockIdx.y * 64 + 16 * (w & 3);
+    const unsigned short* ap = wtp + (size_t)(u0 >> 4) * NS * 1024 + lane * 8;      // fragment order (frag_index)
+    const unsigned short* bp[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bp[c] = dgp + (size_t)min(e0 + 16 * c + r16, N - 1) * K + 8 * kq;
-    f32x4 acc[4], acl[4];
+    for (int c = 0; c < NC; ++c) bp[c] = dgp + (size_t)((e0 + 16 * c) >> 4) * NS * 1024 + lane * 8;
+    f32x4 acc[NC], acl[NC];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = acl[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f16x8 a[DEPTH][2], b[DEPTH][4][2];
+    for (int c = 0; c < NC; ++c) acc[c] = acl[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 a[DEPTH][2], b[DEPTH][NC][2];
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) {
-        a[d][0] = ldh8(ap + 32 * d); a[d][1] = ldh8(ap + plane_w + 32 * d);
+        a[d][0] = ldh8(ap + 1024 * d); a[d][1] = ldh8(ap + 1024 * d + 512);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { b[d][c][0] = ldh8(bp[c] + 32 * d); b[d][c][1] = ldh8(bp[c] + plane_g + 32 * d); }
+        for (int c = 0; c < NC; ++c) { b[d][c][0] = ldh8(bp[c] + 1024 * d); b[d][c][1] = ldh8(bp[c] + 1024 * d + 512); }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
         if (s + DEPTH - 1 < NS) {
             const int sn = s + DEPTH - 1;
-            a[nxt][0] = ldh8(ap + 32 * sn); a[nxt][1] = ldh8(ap + plane_w + 32 * sn);
+            a[nxt][0] = ldh8(ap + 1024 * sn); a[nxt][1] = ldh8(ap + 1024 * sn + 512);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { b[nxt][c][0] = ldh8(bp[c] + 32 * sn); b[nxt][c][1] = ldh8(bp[c] + plane_g + 32 * sn); }
+            for (int c = 0; c < NC; ++c) { b[nxt][c][0] = ldh8(bp[c] + 1024 * sn); b[nxt][c][1] = ldh8(bp[c] + 1024 * sn + 512); }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][1], b[cur][c][0], acl[c], 0, 0, 0);
             acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][0], b[cur][c][0], acc[c], 0, 0, 0);
             acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][0], b[cur][c][1], acl[c], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NC; ++c) {
         const int n = e0 + 16 * c + r16;
         if (n >= N) continue;
         const float is = inv_scale[n];
@@ -356,29 +434,40 @@ __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* 
 
 static bool h3_step_ok(int H) { return H == 256 && !uav_want_f32_mfma() && !getenv("UAV_LSTM_STEP_F32"); }
 
-static int lstm_h3_fwd(uav_ctx* ctx, const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T,
-                       float* y, float* hn, float* cn, float* stash, hipStream_t st) {
+// fp16-split step path of uav_lstm_fwd for h = 256 (input projection included: the caller does NOT pre-fill the stash)
+int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
+                const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn,
+                float* cn, float* stash, hipStream_t st) {
     constexpr int H = 256;
     const int64_t NH = (int64_t)N * H;
-    // tail of the workspace: hs, cs f32 | two ping-pong sets of h pieces | W_hh pieces
-    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 2 * NH) * 2 + (size_t)2 * 4 * H * H * 2;
+    const int IP = (I + 31) / 32 * 32;
+    // tail of the workspace: hs, cs f32 | two ping-pong sets of h pieces | W_hh pieces | W_ih pieces | b_ih + b_hh
+    const int64_t NP = (int64_t)(N + 63) / 64 * 64 * H;     // piece planes cover whole 64-env tiles (fragment order)
+    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 2 * NP) * 2 + (size_t)2 * 4 * H * H * 2 + (size_t)2 * 4 * H * IP * 2 +
+                        (size_t)4 * H * 4;
     UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
     char* base = (char*)ctx->ws + ctx->ws_bytes - need;
     float* hs = (float*)base;
     float* cs = hs + NH;
     unsigned short* hp0 = (unsigned short*)(cs + NH);
-    unsigned short* hp1 = hp0 + 2 * NH;
-    unsigned short* wp = hp1 + 2 * NH;
+    unsigned short* hp1 = hp0 + 2 * NP;
+    unsigned short* wp = hp1 + 2 * NP;
+    unsigned short* wxp = wp + (size_t)2 * 4 * H * H;
+    float* bsum = (float*)(wxp + (size_t)2 * 4 * H * IP);
     const unsigned nb = (unsigned)((NH + 255) / 256);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, 0, wp);
+    UAV_CHECK_HIP(hipMemsetAsync(hp0, 0, (size_t)4 * NP * 2, st));      // rows of a ragged last tile stay finite
+    hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 0, wp);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((4 * H * IP + 255) / 256), dim3(256), 0, st, w_ih, 4 * H, I, IP, 0, wxp);
+    hipLaunchKernelGGL(add2v_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, b_ih, b_hh, bsum, 4 * H);
     hipLaunchKernelGGL(h3_init_state, dim3(nb), dim3(256), 0, st, h0, c0, keep, N, T, H, hs, cs, hp0);
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = 0; t < T; ++t)
-        hipLaunchKernelGGL((step_fwd_h3_kernel<H>), grid, dim3(256), 0, st, wp, (t & 1) ? hp1 : hp0, (t & 1) ? hp0 : hp1, hs, cs,
-                           stash, keep, N, T, t, y, hn, cn);
+        hipLaunchKernelGGL((step_fwd_h3_kernel<H>), grid, dim3(512), 0, st, wxp, IP, wp, bsum, x, I, (t & 1) ? hp1 : hp0,
+                           (t & 1) ? hp0 : hp1, hs, cs, stash, keep, N, T, t, y, hn, cn);
     UAV_LAUNCH_CHECK();
     return 0;
 }
+bool lstm_h3_step_path(int H) { return h3_step_ok(H); }
 
 static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                        const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
@@ -386,22 +475,24 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
     constexpr int H = 256;
     const int64_t NH = (int64_t)N * H;
     // tail of the workspace: dh, dc f32 | dG pieces [2][N][4H] | inv_scale [N] | W_hh^T pieces [2][H][4H]
-    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 4 * NH) * 2 + (size_t)((N + 63) / 64 * 64) * 4 + (size_t)2 * 4 * H * H * 2;
+    const int64_t NP = (int64_t)(N + 63) / 64 * 64 * H;
+    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 4 * NP) * 2 + (size_t)((N + 63) / 64 * 64) * 4 + (size_t)2 * 4 * H * H * 2;
     UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
     char* base = (char*)ctx->ws + ctx->ws_bytes - need;
     float* dh = (float*)base;
     float* dc = dh + NH;
     unsigned short* dgp = (unsigned short*)(dc + NH);
-    float* inv_scale = (float*)(dgp + 2 * 4 * NH);
+    float* inv_scale = (float*)(dgp + 2 * 4 * NP);
     unsigned short* wtp = (unsigned short*)(inv_scale + (N + 63) / 64 * 64);
     const unsigned nb = (unsigned)((NH + 255) / 256);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, 1, wtp);
+    UAV_CHECK_HIP(hipMemsetAsync(dgp, 0, (size_t)2 * 4 * NP * 2, st));
+    hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 1, wtp);
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh, dhn, NH);
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = T - 1; t >= 0; --t) {
-        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3(N), dim3(H), 0, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
-        hipLaunchKernelGGL((step_bwd_h3_kernel<H>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh);
+        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 3) / 4), dim3(256), 0, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
+        hipLaunchKernelGGL((step_bwd_h3_kernel<H>), grid, dim3(512), 0, st, wtp, dgp, inv_scale, N, dh);
     }
     if (dh0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh0, dh, NH);
     if (dc0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc0, dc, NH);
@@ -412,7 +503,6 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
 // pre-activations of all steps must already be in the gates slot of the stash (x W_ih^T + b)
 int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T,
                      int H, float* y, float* hn, float* cn, float* stash, hipStream_t st) {
-    if (h3_step_ok(H)) return lstm_h3_fwd(ctx, keep, h0, c0, w_hh, N, T, y, hn, cn, stash, st);
     const int64_t NH = (int64_t)N * H;
     UAV_REQUIRE((size_t)(2 * NH) * sizeof(float) + (64u << 20) <= ctx->ws_bytes, "lstm (generic): workspace too small");
     float* hs = (float*)((char*)ctx->ws + ctx->ws_bytes) - 2 * NH;     // recurrent state at the tail of the workspace
