@@ -58,8 +58,13 @@ def _worker(rank, world, port, out):
     du.allreduce_grad(g)
     fl = du.gather_episode_flags(torch.from_numpy(flags[lo:hi].copy()))
     succ = du.gather_episode_successes(torch.from_numpy(flags[lo:hi].copy()))
+    cap = du.SUCC_CAP
+    du.SUCC_CAP = 3                                   # force the overflow fallback (whole flags arrays)
+    succ_overflow = du.gather_episode_successes(torch.from_numpy(flags[lo:hi].copy()))
+    du.SUCC_CAP = cap
     if rank == 0:
-        torch.save({"adv_n": adv_n, "grad": g, "flags": fl, "cnt": cnt, "succ": torch.from_numpy(succ)}, out)
+        torch.save({"adv_n": adv_n, "grad": g, "flags": fl, "cnt": cnt, "succ": torch.from_numpy(succ),
+                    "succ_overflow": torch.from_numpy(succ_overflow)}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,3 +83,4 @@ def test_two_rank_exchange_equals_single_process(tmp_path):
     assert np.array_equal(got["flags"].numpy(), flags)
     ended = (flags & 1) > 0
     assert np.array_equal(got["succ"].numpy(), ((flags & 2) > 0)[ended])        # global (env, time) order
+    assert np.array_equal(got["succ_overflow"].numpy(), ((flags & 2) > 0)[ended])

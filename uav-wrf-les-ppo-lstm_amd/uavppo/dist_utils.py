@@ -34,26 +34,38 @@ def allreduce_grad(flat_grad):
     return flat_grad
 
 
+SUCC_CAP = 16384          # per-rank capacity of the fixed-size success message (episodes ended in one rollout)
+
+
 def gather_episode_successes(flags):
     """Success bits of the episodes that ENDED in this rollout, over all ranks, in (rank, env, time) =
     global (env, time) order, as a host bool array.  Only the compacted bits travel: flags is non-zero
-    exactly where an episode ended (bit0 done, bit1 reached), so one device-side nonzero() + two tiny
-    all-gathers (counts, then padded bits) replace shipping the whole [N, T] array to every host."""
+    exactly where an episode ended (bit0 done, bit1 reached).  Every rank packs [count | bits, zero padded] into ONE
+    fixed-size u8 message, so an iteration costs ONE all-gather and ONE device-to-host copy however many ranks there
+    are (a count exchange first would add a collective and a host sync per rank); a rollout with more than SUCC_CAP
+    ended episodes on some rank falls back to gathering the whole flags array."""
     f = flags.reshape(-1)
-    idx = torch.nonzero(f).squeeze(1)
-    succ = ((f[idx] >> 1) & 1).to(torch.uint8)
-    if world() > 1:
-        cnt = torch.tensor([succ.numel()], dtype=torch.int64, device=f.device)
-        cnts = [torch.zeros_like(cnt) for _ in range(world())]
-        dist.all_gather(cnts, cnt)
-        cnts = [int(c.item()) for c in cnts]
-        m = max(max(cnts), 1)
-        pad = torch.zeros(m, dtype=torch.uint8, device=f.device)
-        pad[:succ.numel()] = succ
-        parts = [torch.empty_like(pad) for _ in range(world())]
-        dist.all_gather(parts, pad)
-        succ = torch.cat([p[:c] for p, c in zip(parts, cnts)])
-    return succ.cpu().numpy().astype(bool)
+    if world() == 1:
+        idx = torch.nonzero(f).squeeze(1)
+        return ((f[idx] >> 1) & 1).to(torch.uint8).cpu().numpy().astype(bool)
+    # stable compaction without a host sync: position of every ended episode = exclusive prefix count
+    ended = f != 0
+    pos = torch.cumsum(ended.to(torch.int32), 0) - 1
+    cnt = ended.sum().to(torch.int32)
+    msg = torch.zeros(4 + SUCC_CAP + 1, dtype=torch.uint8, device=f.device)     # last byte: dump slot of the scatter
+    msg[:4] = torch.stack([(cnt >> s) & 255 for s in (0, 8, 16, 24)]).to(torch.uint8)
+    slot = torch.where(ended & (pos < SUCC_CAP), pos, torch.full_like(pos, SUCC_CAP)).to(torch.int64)
+    msg[4:].scatter_(0, slot, ((f >> 1) & 1).to(torch.uint8))                     # fixed shapes: nothing syncs with the host
+    parts = [torch.empty_like(msg) for _ in range(world())]
+    dist.all_gather(parts, msg)
+    host = torch.stack(parts).cpu().numpy()
+    counts = [int(h[0]) | int(h[1]) << 8 | int(h[2]) << 16 | int(h[3]) << 24 for h in host]
+    if max(counts) > SUCC_CAP:                       # rare: ship the whole arrays instead
+        allf = gather_episode_flags(flags).reshape(-1)
+        idx = torch.nonzero(allf).squeeze(1)
+        return ((allf[idx] >> 1) & 1).to(torch.uint8).cpu().numpy().astype(bool)
+    import numpy as np
+    return np.concatenate([h[4:4 + c] for h, c in zip(host, counts)]).astype(bool)
 
 
 def gather_episode_flags(flags):
