@@ -147,8 +147,8 @@ __device__ __forceinline__ f16x8 ldh8(const unsigned short* p) { return *reinter
 // K runs over the input (IP = I rounded up to 32, x_t read as f32 and split in registers) and then over H (h_{t-1} as fp16
 // piece planes) in slabs of 32, next slab's fragments in flight while the current one multiplies.
 // A = weight pieces [2][4H][IP] and [2][4H][H], lane (r16, kq) reads 8 consecutive k of row r16 -- one dwordx4.
-template <int H>
-__global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp, int IP,
+template <int H, int IPS>
+__global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp,
                                                           const unsigned short* __restrict__ wp,
                                                           const float* __restrict__ bsum, const float* __restrict__ x, int I,
                                                           const unsigned short* __restrict__ hp_in,
@@ -186,38 +186,6 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
                 acl[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][0], b[c][1], acl[g][c], 0, 0, 0);
             }
     };
-    // ---- input projection: x_t [n][I] f32 -> two fp16 pieces per value, K = IP
-    {
-        const unsigned short* axp[4];                  // fragment order: + s * 1024 per slab, + 512 for the second piece
-#pragma unroll
-        for (int g = 0; g < 4; ++g) axp[g] = wxp + (size_t)((g * H + u0) >> 4) * (IP >> 5) * 1024 + lane * 8;
-        for (int s = 0; s < IP / 32; ++s) {
-            f16x8 a[4][2], b[NC][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { a[g][0] = ldh8(axp[g] + 1024 * s); a[g][1] = ldh8(axp[g] + 1024 * s + 512); }
-            const int k0 = 32 * s + 8 * kq;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float* xr = x + ((size_t)nrow[c] * T + t) * I + k0;
-                float v[8];
-                if (k0 + 8 <= I) {
-                    const float4 v0 = *reinterpret_cast<const float4*>(xr), v1 = *reinterpret_cast<const float4*>(xr + 4);
-                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < I) ? xr[i] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    _Float16 p0, p1;
-                    split2h(v[i], p0, p1);
-                    b[c][0][i] = p0;
-                    b[c][1][i] = p1;
-                }
-            }
-            mac(a, b);
-        }
-    }
     // ---- recurrent product, K = H, double-buffered slabs
     {
         const unsigned short* ap[4];                   // fragment order (frag_index): 1 KB per wave-wide load
@@ -248,6 +216,58 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
             }
             mac(a[cur], b[cur]);
         }
+    }
+    // ---- input projection: x_t [n][I] f32 -> two fp16 pieces per value, K = 32 IPS; the next slab's weight fragments and
+    // raw x values are in flight while the current slab is split and multiplied
+    {
+        constexpr int IP = 32 * IPS;
+        const unsigned short* axp[4];                  // fragment order: + s * 1024 per slab, + 512 for the second piece
+#pragma unroll
+        for (int g = 0; g < 4; ++g) axp[g] = wxp + (size_t)((g * H + u0) >> 4) * IPS * 1024 + lane * 8;
+        const float* xr[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) xr[c] = x + ((size_t)nrow[c] * T + t) * I + 8 * kq;
+        f16x8 a[2][4][2];
+        float4 xv[2][NC][2];
+        auto fetch = [&](int s, int buf) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { a[buf][g][0] = ldh8(axp[g] + 1024 * s); a[buf][g][1] = ldh8(axp[g] + 1024 * s + 512); }
+            const int k0 = 32 * s + 8 * kq;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if (k0 + 8 <= I) {
+                    xv[buf][c][0] = *reinterpret_cast<const float4*>(xr[c] + 32 * s);
+                    xv[buf][c][1] = *reinterpret_cast<const float4*>(xr[c] + 32 * s + 4);
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = (k0 + i < I) ? xr[c][32 * s + i] : 0.f;
+                    xv[buf][c][0] = float4{v[0], v[1], v[2], v[3]};
+                    xv[buf][c][1] = float4{v[4], v[5], v[6], v[7]};
+                }
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < IPS; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < IPS) fetch(s + 1, cur ^ 1);
+            f16x8 b[NC][2];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float v[8] = {xv[cur][c][0].x, xv[cur][c][0].y, xv[cur][c][0].z, xv[cur][c][0].w,
+                                    xv[cur][c][1].x, xv[cur][c][1].y, xv[cur][c][1].z, xv[cur][c][1].w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    _Float16 p0, p1;
+                    split2h(v[i], p0, p1);
+                    b[c][0][i] = p0;
+                    b[c][1][i] = p1;
+                }
+            }
+            mac(a[cur], b);
+        }
+        (void)IP;
     }
     // ---- cell (gen_cell_fwd's arithmetic) and outputs
 #pragma unroll
@@ -440,7 +460,9 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
                 float* cn, float* stash, hipStream_t st) {
     constexpr int H = 256;
     const int64_t NH = (int64_t)N * H;
-    const int IP = (I + 31) / 32 * 32;
+    int IP = (I + 31) / 32 * 32;
+    IP = IP <= 32 ? 32 : (IP <= 64 ? 64 : (IP <= 128 ? 128 : 256));        // instantiated slab counts: 1, 2, 4, 8
+    UAV_REQUIRE(I <= 256, "lstm (h=256): input width %d > 256", I);
     // tail of the workspace: hs, cs f32 | two ping-pong sets of h pieces | W_hh pieces | W_ih pieces | b_ih + b_hh
     const int64_t NP = (int64_t)(N + 63) / 64 * 64 * H;     // piece planes cover whole 64-env tiles (fragment order)
     const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 2 * NP) * 2 + (size_t)2 * 4 * H * H * 2 + (size_t)2 * 4 * H * IP * 2 +
@@ -462,8 +484,16 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
     hipLaunchKernelGGL(h3_init_state, dim3(nb), dim3(256), 0, st, h0, c0, keep, N, T, H, hs, cs, hp0);
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = 0; t < T; ++t)
-        hipLaunchKernelGGL((step_fwd_h3_kernel<H>), grid, dim3(512), 0, st, wxp, IP, wp, bsum, x, I, (t & 1) ? hp1 : hp0,
-                           (t & 1) ? hp0 : hp1, hs, cs, stash, keep, N, T, t, y, hn, cn);
+#define LAUNCH_STEP(IPS_)                                                                                              \
+    hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, (t & 1) ? hp1 : hp0, \
+                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep, N, T, t, y, hn, cn)
+        switch (IP / 32) {
+            case 1: LAUNCH_STEP(1); break;
+            case 2: LAUNCH_STEP(2); break;
+            case 4: LAUNCH_STEP(4); break;
+            default: LAUNCH_STEP(8); break;
+        }
+#undef LAUNCH_STEP
     UAV_LAUNCH_CHECK();
     return 0;
 }
