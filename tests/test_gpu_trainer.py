@@ -639,3 +639,40 @@ def test_fused_mlp_rollout_logp_is_the_updates_first_forward():
     assert abs(s[0] / (N * T) + tr.adv_n.double().mean().item()) < 1e-9
     freq = torch.bincount(tr.buf["act"].reshape(-1).long(), minlength=5).float() / (N * T)
     assert (freq - 0.2).abs().max() < 0.02 and (tr.buf["logp"].exp().mean() - 0.2).abs() < 0.01
+
+
+@pytest.mark.parametrize("N,T", [(1, 3), (17, 1), (1, 256)])
+def test_fused_mlp_edge_shapes(N, T):
+    """Single env, single step, ragged 16-env tile: fused MLP rollout + update stay finite and move the parameters;
+    GAE of the collected buffer against the oracle."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(N, T, "mlp", device=DEV, seed=N + T, epochs=2)
+    assert tr.fused_mlp
+    p0 = tr.policy.flat.clone()
+    for _ in range(2):
+        tr.train_iteration()
+    pl, vl, ent = tr.losses()
+    assert np.isfinite([pl, vl, ent]).all() and torch.isfinite(tr.policy.flat).all()
+    if N * T > 1:
+        assert (tr.policy.flat - p0).abs().max() > 0
+    b = {k: v.cpu().numpy() for k, v in tr.buf.items()}
+    assert np.allclose(tr.adv.cpu().numpy(), po.gae_reference_exact(b["rew"], b["val"], b["done"]), rtol=2e-5, atol=2e-5)
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Error convention of the ABI (non-zero status -> RuntimeError with uav_last_error's text) on the round-2 entry points."""
+    from uavppo import ops
+    from uavppo.policy import MLPActorCritic
+    pol = MLPActorCritic(8, 5, device=DEV, seed=0)            # 8 inputs: not the reference's network
+    n = 32
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)
+    with pytest.raises(RuntimeError, match="fused kernel is the reference's network"):
+        ops.mlp_ppo_grad(pol.flat, z(n, 8), z(n, dt=torch.int32), z(n), z(n), z(n), z(n), 1.0 / n, 0.2, 0.01,
+                         z(4, dt=torch.float64), pol.grad, in_dim=8)
+    with pytest.raises(KeyError):
+        ops.set_lstm_arith("fp8", DEV)
+    from uavppo import _lib
+    assert _lib.lib().uav_set_lstm_arith(ops.Context.get(DEV).handle, 7) != 0
+    assert b"uav_set_lstm_arith" in _lib.lib().uav_last_error()
+    with pytest.raises(RuntimeError, match="expected a contiguous tensor|expected shape"):
+        ops.absmax(z(8, 8)[:, ::2])
