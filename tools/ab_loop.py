@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the iteration loop on one device, interleaved rounds (cdna_hip_programming.md rule 24):
-  old  range guard off          new  range guard on (uavppo/trainer.py: Adam publishes max |param|, polled at the curriculum sync)"""
+  guard   range guard off / on (uavppo/trainer.py: Adam publishes max |param|, polled at the next rollout)
+  side    curriculum success bits packed + copied on the main stream at the iteration's host sync / on a side stream right
+          behind the rollout (the sync then never drains the main stream)
+usage: ab_loop.py [guard|side]"""
 import os
 import sys
 import time
@@ -12,8 +15,13 @@ from uavppo.trainer import VecPPOTrainer  # noqa: E402
 tr = VecPPOTrainer(4096, 128, "lstm", hidden=128, device="cuda:0", seed=1234)
 
 
+WHAT = sys.argv[1] if len(sys.argv) > 1 else "side"
+
+
 def run(mode, k=10):
-    if mode == "old":
+    if WHAT == "side":
+        tr.side_stream_curriculum = (mode == "new")
+    elif mode == "old":
         tr._guarded = lambda: False
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -21,7 +29,7 @@ def run(mode, k=10):
         tr.train_iteration()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k * 1e3
-    if mode == "old":
+    if WHAT == "guard" and mode == "old":
         del tr._guarded
     return dt
 

@@ -37,35 +37,46 @@ def allreduce_grad(flat_grad):
 SUCC_CAP = 16384          # per-rank capacity of the fixed-size success message (episodes ended in one rollout)
 
 
-def gather_episode_successes(flags):
-    """Success bits of the episodes that ENDED in this rollout, over all ranks, in (rank, env, time) =
-    global (env, time) order, as a host bool array.  Only the compacted bits travel: flags is non-zero
-    exactly where an episode ended (bit0 done, bit1 reached).  Every rank packs [count | bits, zero padded] into ONE
-    fixed-size u8 message, so an iteration costs ONE all-gather and ONE device-to-host copy however many ranks there
-    are (a count exchange first would add a collective and a host sync per rank); a rollout with more than SUCC_CAP
-    ended episodes on some rank falls back to gathering the whole flags array."""
+def pack_episode_successes(flags):
+    """Device side of the success exchange, no host sync: this rank's [count (4 bytes LE) | success bits of the ended
+    episodes in (env, time) order, zero padded to SUCC_CAP | dump byte] as ONE fixed-size u8 message; with several ranks
+    the messages of all ranks, stacked [world, 4 + SUCC_CAP + 1], after ONE all-gather.  flags is non-zero exactly where an
+    episode ended (bit0 done, bit1 reached); the position of an ended episode in the message is its exclusive prefix
+    count, so the compaction is a cumsum + scatter with fixed shapes."""
     f = flags.reshape(-1)
-    if world() == 1:
-        idx = torch.nonzero(f).squeeze(1)
-        return ((f[idx] >> 1) & 1).to(torch.uint8).cpu().numpy().astype(bool)
-    # stable compaction without a host sync: position of every ended episode = exclusive prefix count
     ended = f != 0
     pos = torch.cumsum(ended.to(torch.int32), 0) - 1
     cnt = ended.sum().to(torch.int32)
     msg = torch.zeros(4 + SUCC_CAP + 1, dtype=torch.uint8, device=f.device)     # last byte: dump slot of the scatter
     msg[:4] = torch.stack([(cnt >> s) & 255 for s in (0, 8, 16, 24)]).to(torch.uint8)
     slot = torch.where(ended & (pos < SUCC_CAP), pos, torch.full_like(pos, SUCC_CAP)).to(torch.int64)
-    msg[4:].scatter_(0, slot, ((f >> 1) & 1).to(torch.uint8))                     # fixed shapes: nothing syncs with the host
+    msg[4:].scatter_(0, slot, ((f >> 1) & 1).to(torch.uint8))
+    if world() == 1:
+        return msg[None]
     parts = [torch.empty_like(msg) for _ in range(world())]
     dist.all_gather(parts, msg)
-    host = torch.stack(parts).cpu().numpy()
+    return torch.stack(parts)
+
+
+def unpack_episode_successes(host, flags):
+    """Host side: the stacked messages (numpy u8 [world, 4 + SUCC_CAP + 1]) -> success bits of all ranks in global (env, time)
+    order as a bool array.  A rank with more than SUCC_CAP ended episodes (rare) makes every rank fall back to gathering
+    the whole flags arrays (`flags`: this rank's device tensor)."""
+    import numpy as np
     counts = [int(h[0]) | int(h[1]) << 8 | int(h[2]) << 16 | int(h[3]) << 24 for h in host]
-    if max(counts) > SUCC_CAP:                       # rare: ship the whole arrays instead
+    if max(counts) > SUCC_CAP:
         allf = gather_episode_flags(flags).reshape(-1)
         idx = torch.nonzero(allf).squeeze(1)
         return ((allf[idx] >> 1) & 1).to(torch.uint8).cpu().numpy().astype(bool)
-    import numpy as np
     return np.concatenate([h[4:4 + c] for h, c in zip(host, counts)]).astype(bool)
+
+
+def gather_episode_successes(flags):
+    """Success bits of the episodes that ENDED in this rollout, over all ranks, in (rank, env, time) = global (env, time)
+    order, as a host bool array: pack (one all-gather) + one device-to-host copy + unpack.  The trainer runs the two
+    halves apart -- pack on a side stream right behind the rollout, unpack when the curriculum needs it -- so the copy's
+    host sync never idles the GPU; this is the same thing in one call."""
+    return unpack_episode_successes(pack_episode_successes(flags).cpu().numpy(), flags)
 
 
 def gather_episode_flags(flags):

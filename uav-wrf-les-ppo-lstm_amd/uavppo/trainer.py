@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist_utils import allreduce_adv_stats, allreduce_grad, env_shard, gather_episode_successes
+from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, env_shard, pack_episode_successes,
+                         unpack_episode_successes)
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
 
@@ -79,10 +80,11 @@ class VecPPOTrainer:
         self.log = []
         # range guard of the fp16-split kernels: device maxima [|param|, |obs|, |h0|], mirrored to pinned host memory
         self.ranges = torch.zeros(3, **f32)
-        self._ranges_host = torch.zeros(3, dtype=torch.float32).pin_memory()
-        self._ranges_ev = torch.cuda.Event()
+        self._ranges_host = torch.zeros(4, 3, dtype=torch.float32).pin_memory()      # ring: the host may run iterations ahead
+        self._ranges_evs = [torch.cuda.Event() for _ in range(4)]
+        self._pmax_queue = []        # ring slots whose copy of the Adam kernel's max |param| is on its way, oldest first
+        self._pmax_next = 0
         self._buffers_own = False    # True between a collect() and the update() that consumes its buffers
-        self._pmax_pending = False   # a copy of the Adam kernel's max |param| is on its way to _ranges_host
         self.arith = "fp16x3"
         self.range_events = 0        # iterations that ran on the wide-range (bf16-split) kernels
         self._flat_version = -1
@@ -93,6 +95,15 @@ class VecPPOTrainer:
         self.bank_sources = None if bank_sources is None else torch.as_tensor(bank_sources, dtype=torch.float64).to(d).contiguous()
         self.curriculum = Curriculum() if use_curriculum else None
         self.radius, self.bonus = 50.0, 0.6
+        # the curriculum's success bits leave on a side stream right behind the rollout and land in pinned host memory
+        # while the update runs: the iteration's one host sync (update_curriculum) then waits for a copy that finished
+        # milliseconds ago instead of draining the main stream
+        self._side = torch.cuda.Stream(device=self.device) if use_curriculum else None
+        self._succ_host = (torch.zeros(self.world, 4 + SUCC_CAP + 1, dtype=torch.uint8).pin_memory() if use_curriculum else None)
+        self._succ_ev = torch.cuda.Event()
+        self._roll_ev = torch.cuda.Event()
+        self._succ_pending = False
+        self.side_stream_curriculum = True     # False: pack + copy on the main stream inside update_curriculum (A/B, tools/ab_loop.py)
         if policy == "lstm":
             L, H = layers, hidden
             self.h = torch.zeros(L, N, H, **f32)
@@ -126,8 +137,8 @@ class VecPPOTrainer:
     # The fp16-split kernels need |w| < 65504, |x| < 4096, |h0| < 64 (include/uavppo.h).  What can leave that range, and
     # where it is caught without stalling the loop:
     #   parameters   move by <= lr per optimiser step.  The Adam kernel publishes max |param| after every step
-    #                (uav_clip_adam's pmax_out); its copy to pinned host memory is read at the iteration's existing host
-    #                sync (the curriculum's), i.e. one iteration late, against HALF the limit.  Parameters written by
+    #                (uav_clip_adam's pmax_out); its copy to pinned host memory is polled, never waited for, at the start of
+    #                a later rollout (the host runs one to two iterations ahead of the device), against HALF the limit.  Parameters written by
     #                anything else (initialisation, load_state_dict: torch bumps flat._version) are measured before the
     #                next rollout runs on them -- a sync, on such an iteration only.
     #   observations / recurrent state of the trainer's OWN rollouts are bounded by construction (positions, field values
@@ -145,21 +156,25 @@ class VecPPOTrainer:
     def _measure_params(self):
         """Synchronous probe of the parameters when something other than the Adam kernel wrote them."""
         if self.policy.flat._version != self._flat_version:
+            self._pmax_queue.clear()            # maxima published before the foreign write say nothing about it
             ops.absmax(self.policy.flat, out=self.ranges[0:1])
             self._flat_version = self.policy.flat._version
             self._decide([float(self.ranges[0].item()), 0.0, 0.0])
 
     def poll_param_range(self):
-        """Read the Adam kernel's max |param| if its host copy has landed (never waits)."""
-        if self._guarded() and self._pmax_pending and self._ranges_ev.query():
-            self._pmax_pending = False
-            self._decide([float(self._ranges_host[0]), 0.0, 0.0])
+        """Read the newest of the Adam kernel's max |param| copies that has landed (never waits)."""
+        latest = None
+        while self._pmax_queue and self._ranges_evs[self._pmax_queue[0]].query():
+            latest = self._pmax_queue.pop(0)
+        if latest is not None and self._guarded():
+            self._decide([float(self._ranges_host[latest, 0]), 0.0, 0.0])
 
     def check_ranges(self):
         """Kernel arithmetic for the update about to be queued (see above); sets it on the device's handle."""
         if not self._guarded():
             return self.arith
         if not self._buffers_own:               # foreign buffers: measure everything now
+            self._pmax_queue.clear()
             ops.absmax(self.policy.flat, out=self.ranges[0:1])
             ops.absmax(self.buf["obs"], out=self.ranges[1:2])
             ops.absmax(self.h0, out=self.ranges[2:3])
@@ -180,6 +195,8 @@ class VecPPOTrainer:
     def collect(self, forced_act=None, noise=None):
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
         self._rollout_forward_valid = False
+        if self._succ_pending:                 # a previous rollout's flags are still being packed on the side stream
+            torch.cuda.current_stream().wait_event(self._succ_ev)
         if self._guarded():
             self.poll_param_range()
             self._measure_params()
@@ -206,6 +223,13 @@ class VecPPOTrainer:
                             info=self.info)
         else:
             self._collect_stepwise(forced_act, noise)
+        if self.curriculum is not None and self.side_stream_curriculum:
+            self._roll_ev.record()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._roll_ev)
+                self._succ_host.copy_(pack_episode_successes(self.buf["flags"]), non_blocking=True)
+                self._succ_ev.record(self._side)
+            self._succ_pending = True
 
     def _collect_stepwise_lstm(self, forced_act=None, noise=None):
         """Stacked / wide LSTM policies (BASELINE C5: h=256 x2): one cell step per layer + heads GEMM +
@@ -346,10 +370,15 @@ class VecPPOTrainer:
                               max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm, pmax_out=self.ranges[0:1])
                 if self.record:
                     self.log.append((self.loss_sums.clone(), self.gnorm.clone()))
-        if self._guarded():                # max |param| of the last Adam step -> pinned host memory, read at the next poll
-            self._ranges_host.copy_(self.ranges, non_blocking=True)
-            self._ranges_ev.record()
-            self._pmax_pending = True
+        if self._guarded():                # max |param| of the last Adam step -> pinned host memory, read at a later poll
+            if len(self._pmax_queue) == 4:     # the host is four updates ahead of the device: let the oldest copy land
+                self._ranges_evs[self._pmax_queue[0]].synchronize()
+                self.poll_param_range()
+            k = self._pmax_next
+            self._pmax_next = (k + 1) % 4
+            self._ranges_host[k].copy_(self.ranges, non_blocking=True)
+            self._ranges_evs[k].record()
+            self._pmax_queue.append(k)
             self._buffers_own = False
         return self.loss_sums
 
@@ -360,9 +389,13 @@ class VecPPOTrainer:
         global (env, time)-ordered sequence to its replicated curriculum."""
         if self.curriculum is None:
             return
-        self.curriculum.update_many(gather_episode_successes(self.buf["flags"]))
+        if not self._succ_pending:             # flags not produced by collect(): pack them now
+            self._succ_host.copy_(pack_episode_successes(self.buf["flags"]), non_blocking=True)
+            self._succ_ev.record()
+        self._succ_ev.synchronize()
+        self._succ_pending = False
+        self.curriculum.update_many(unpack_episode_successes(self._succ_host.numpy(), self.buf["flags"]))
         self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
-        self.poll_param_range()            # the success bits' host sync has also delivered the Adam kernel's max |param|
 
     def train_iteration(self):
         self.collect()
