@@ -82,6 +82,13 @@ int uav_adv_stats(uav_ctx* ctx, const float* adv, int64_t n, double* stats3, uav
 int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t n,
                       const double* stats3, float* adv_out, float* ret_out, uav_stream stream);
 
+/* ---- T1 input (the curriculum of model.py:131-164 consumes one success flag per finished episode): the success bits of
+ * the episodes that ended in a rollout, compacted in (env, time) order without a host round trip.  flags u8 [n] as written
+ * by uav_rollout / uav_env_step (bit0 done, bit1 reached) -> msg u8 [4 + cap + 1]: count (4 bytes, little endian) | bit1 of
+ * the k-th ended episode at msg[4 + k] for k < cap | one spare byte.  One fixed-size message per rank: a single all-gather
+ * and a single device-to-host copy per iteration feed every rank's replicated curriculum. */
+int uav_pack_success_bits(uav_ctx* ctx, const uint8_t* flags, int64_t n, int cap, uint8_t* msg, uav_stream stream);
+
 /* ---- U2: clipped-PPO loss forward + backward in one pass (train_ppo2.0.py:55-83).
  * logits f32 [n][n_act] (pre-softmax), value f32 [n], act i32 [n]; inv_n = 1/(global sample
  * count).  loss_sums (f64 [4], device): {sum -min(s1,s2), sum 0.5*max(.), sum entropy,

@@ -274,3 +274,17 @@ def test_ppo_loss_fused_heads_equals_unfused(ops, n, H):
     assert np.allclose(d2.cpu().numpy(), d1.cpu().numpy(), rtol=2e-4, atol=1e-6 / n)
     assert np.allclose(db2.cpu().numpy(), db1.cpu().numpy(), rtol=1e-3, atol=1e-6)
     assert np.allclose(db2.cpu().numpy(), d2.cpu().numpy().sum(0), rtol=1e-3, atol=1e-6)
+
+
+def test_pack_success_bits_matches_bruteforce(ops):
+    """uav_pack_success_bits: order-preserving compaction of the ended episodes' success bits, count header, capacity clamp."""
+    rng = np.random.RandomState(0)
+    for n, p, cap in ((1, 1.0, 8), (1000, 0.02, 64), (4096 * 128, 0.0015, 16384), (70001, 0.3, 5000), (513, 0.0, 16)):
+        ended = rng.rand(n) < p
+        flags = (ended * np.where(rng.rand(n) < 0.5, 3, 1)).astype(np.uint8)
+        msg = ops.pack_success_bits(torch.from_numpy(flags).to(DEV), cap).cpu().numpy()
+        cnt = int(msg[0]) | int(msg[1]) << 8 | int(msg[2]) << 16 | int(msg[3]) << 24
+        want = (flags[ended] >> 1) & 1
+        assert cnt == ended.sum() and msg.shape == (4 + cap + 1,)
+        k = min(cnt, cap)
+        assert np.array_equal(msg[4:4 + k], want[:k]) and not msg[4 + k:].any()

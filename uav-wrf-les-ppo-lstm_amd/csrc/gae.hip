@@ -122,6 +122,42 @@ __global__ __launch_bounds__(256) void adv_normalise_kernel(const float* __restr
     }
 }
 
+// ---- T1 input: the success bits of the episodes that ended in a rollout, compacted in (env, time) order.
+// flags u8 [n] (bit0 done, bit1 reached; non-zero exactly where an episode ended) -> msg u8 [4 + cap + 1]:
+// count (4 bytes, little endian) | bit1 of the k-th ended episode at msg[4 + k], k < cap | one spare byte.
+// One block: every thread counts its contiguous chunk, a block scan gives its write offset (order preserving, no atomics).
+__global__ __launch_bounds__(1024) void pack_success_kernel(const uint8_t* __restrict__ flags, int64_t n, int cap,
+                                                            uint8_t* __restrict__ msg) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
+    int cnt = 0;
+    for (int64_t i = lo; i < hi; ++i) cnt += flags[i] != 0;
+    part[tid] = cnt;
+    for (int i = tid; i < 4 + cap + 1; i += 1024) msg[i] = 0;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele over 1024 entries)
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (tid >= o) ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - cnt;
+    if (tid == 1023) {
+        const unsigned total = (unsigned)part[1023];
+        msg[0] = total & 255; msg[1] = (total >> 8) & 255; msg[2] = (total >> 16) & 255; msg[3] = (total >> 24) & 255;
+    }
+    for (int64_t i = lo; i < hi; ++i) {
+        const uint8_t f = flags[i];
+        if (f) {
+            if (pos < cap) msg[4 + pos] = (f >> 1) & 1;
+            ++pos;
+        }
+    }
+}
+
 extern "C" {
 
 int uav_gae(uav_ctx* ctx, const float* rew, const float* val, const float* done,
@@ -157,6 +193,14 @@ int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t 
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(adv_normalise_kernel, dim3(nb), dim3(256), 0, as_stream(stream), adv, val, n, stats3,
                        adv_out, ret_out);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+
+int uav_pack_success_bits(uav_ctx* ctx, const uint8_t* flags, int64_t n, int cap, uint8_t* msg, uav_stream stream) {
+    UAV_REQUIRE(ctx && flags && msg && n > 0 && cap > 0, "uav_pack_success_bits: bad argument");
+    hipLaunchKernelGGL(pack_success_kernel, dim3(1), dim3(1024), 0, as_stream(stream), flags, n, cap, msg);
     UAV_LAUNCH_CHECK();
     return 0;
 }

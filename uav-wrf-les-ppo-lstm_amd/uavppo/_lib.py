@@ -38,6 +38,7 @@ SIGNATURES = {
     "uav_gae": (I32, [P, P, P, P, P, I32, I32, F32, F32, I32, P, P]),
     "uav_adv_stats": (I32, [P, P, I64, P, P]),
     "uav_adv_normalise": (I32, [P, P, P, I64, P, P, P, P]),
+    "uav_pack_success_bits": (I32, [P, P, I64, I32, P, P]),
     "uav_ppo_loss": (I32, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P, P, P]),
     "uav_ppo_loss_from_y": (I32, [P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, F32, P, P, P, P]),
     "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, I64, P, P, P, P, P, P]),

@@ -126,6 +126,15 @@ def adv_normalise(adv, val, stats3, adv_out=None, ret_out=None):
     return adv_out, ret_out
 
 
+def pack_success_bits(flags, cap, out=None):
+    """flags u8 [..] -> u8 [4 + cap + 1] message (count LE | success bits of the ended episodes in order | spare)."""
+    f = flags.reshape(-1)
+    out = torch.empty(4 + cap + 1, dtype=U8, device=f.device) if out is None else out
+    check(lib().uav_pack_success_bits(_h(f), _p(f, U8, name="flags"), f.numel(), int(cap), _p(out, U8, (4 + cap + 1,), "msg"),
+                                      _stream()), "uav_pack_success_bits")
+    return out
+
+
 # ----------------------------------------------------------------------------- U2 / K3
 def ppo_loss(logits, value, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta,
              loss_sums=None, dlogits=None, dvalue=None, dhead_bias=None):
