@@ -130,10 +130,30 @@ __global__ __launch_bounds__(1024) void pack_success_kernel(const uint8_t* __res
                                                             uint8_t* __restrict__ msg) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
-    const int64_t per = (n + 1023) / 1024;
+    int64_t per = (n + 1023) / 1024;
+    per = (per + 15) / 16 * 16;                         // 16-byte loads; ended episodes are rare, so whole zero words are skipped
     const int64_t lo = (int64_t)tid * per, hi = (lo + per < n) ? lo + per : n;
+    const bool vec = (reinterpret_cast<uintptr_t>(flags) & 15) == 0;
+    auto visit = [&](auto&& f) {                        // f(byte) for every non-zero flag of this thread's chunk, in order
+        int64_t i = lo;
+        if (vec)
+            for (; i + 16 <= hi; i += 16) {
+                const uint4 w = *reinterpret_cast<const uint4*>(flags + i);
+                if ((w.x | w.y | w.z | w.w) == 0u) continue;
+                const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint8_t v = (ww[q] >> (8 * k)) & 255;
+                        if (v) f(v);
+                    }
+            }
+        for (; i < hi; ++i)
+            if (flags[i]) f(flags[i]);
+    };
     int cnt = 0;
-    for (int64_t i = lo; i < hi; ++i) cnt += flags[i] != 0;
+    visit([&](uint8_t) { ++cnt; });
     part[tid] = cnt;
     for (int i = tid; i < 4 + cap + 1; i += 1024) msg[i] = 0;
     __syncthreads();
@@ -149,13 +169,10 @@ __global__ __launch_bounds__(1024) void pack_success_kernel(const uint8_t* __res
         const unsigned total = (unsigned)part[1023];
         msg[0] = total & 255; msg[1] = (total >> 8) & 255; msg[2] = (total >> 16) & 255; msg[3] = (total >> 24) & 255;
     }
-    for (int64_t i = lo; i < hi; ++i) {
-        const uint8_t f = flags[i];
-        if (f) {
-            if (pos < cap) msg[4 + pos] = (f >> 1) & 1;
-            ++pos;
-        }
-    }
+    if (cnt) visit([&](uint8_t v) {
+        if (pos < cap) msg[4 + pos] = (v >> 1) & 1;
+        ++pos;
+    });
 }
 
 extern "C" {
