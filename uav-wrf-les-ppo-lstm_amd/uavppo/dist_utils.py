@@ -37,29 +37,36 @@ def allreduce_grad(flat_grad):
 SUCC_CAP = 16384          # per-rank capacity of the fixed-size success message (episodes ended in one rollout)
 
 
-def pack_episode_successes(flags):
+def pack_local_successes(flags):
     """Device side of the success exchange, no host sync: this rank's [count (4 bytes LE) | success bits of the ended
-    episodes in (env, time) order, zero padded to SUCC_CAP | dump byte] as ONE fixed-size u8 message; with several ranks
-    the messages of all ranks, stacked [world, 4 + SUCC_CAP + 1], after ONE all-gather.  flags is non-zero exactly where an
-    episode ended (bit0 done, bit1 reached); the position of an ended episode in the message is its exclusive prefix
-    count: fixed shapes, one kernel launch on the GPU."""
+    episodes in (env, time) order, zero padded to SUCC_CAP | spare byte] as ONE fixed-size u8 message.  flags is non-zero
+    exactly where an episode ended (bit0 done, bit1 reached); the position of an ended episode in the message is its
+    exclusive prefix count: fixed shapes, one kernel launch on the GPU."""
     f = flags.reshape(-1)
     if f.is_cuda:                              # one launch (csrc/gae.hip: pack_success_kernel)
         from . import ops
-        msg = ops.pack_success_bits(f, SUCC_CAP)
-    else:                                      # CPU tensors (gloo tests): the same message with torch ops
-        ended = f != 0
-        pos = torch.cumsum(ended.to(torch.int32), 0) - 1
-        cnt = ended.sum().to(torch.int32)
-        msg = torch.zeros(4 + SUCC_CAP + 1, dtype=torch.uint8, device=f.device)     # last byte: dump slot of the scatter
-        msg[:4] = torch.stack([(cnt >> s) & 255 for s in (0, 8, 16, 24)]).to(torch.uint8)
-        slot = torch.where(ended & (pos < SUCC_CAP), pos, torch.full_like(pos, SUCC_CAP)).to(torch.int64)
-        msg[4:].scatter_(0, slot, ((f >> 1) & 1).to(torch.uint8))
+        return ops.pack_success_bits(f, SUCC_CAP)
+    ended = f != 0                             # CPU tensors (gloo tests): the same message with torch ops
+    pos = torch.cumsum(ended.to(torch.int32), 0) - 1
+    cnt = ended.sum().to(torch.int32)
+    msg = torch.zeros(4 + SUCC_CAP + 1, dtype=torch.uint8, device=f.device)     # last byte: dump slot of the scatter
+    msg[:4] = torch.stack([(cnt >> s) & 255 for s in (0, 8, 16, 24)]).to(torch.uint8)
+    slot = torch.where(ended & (pos < SUCC_CAP), pos, torch.full_like(pos, SUCC_CAP)).to(torch.int64)
+    msg[4:].scatter_(0, slot, ((f >> 1) & 1).to(torch.uint8))
+    return msg
+
+
+def exchange_successes(msg):
+    """The messages of all ranks, stacked [world, 4 + SUCC_CAP + 1], after ONE all-gather (a view of `msg` at world 1)."""
     if world() == 1:
         return msg[None]
     parts = [torch.empty_like(msg) for _ in range(world())]
     dist.all_gather(parts, msg)
     return torch.stack(parts)
+
+
+def pack_episode_successes(flags):
+    return exchange_successes(pack_local_successes(flags))
 
 
 def unpack_episode_successes(host, flags):

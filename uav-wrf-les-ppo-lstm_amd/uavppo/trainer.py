@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, env_shard, pack_episode_successes,
+from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, env_shard, exchange_successes, pack_local_successes,
                          unpack_episode_successes)
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
@@ -103,6 +103,8 @@ class VecPPOTrainer:
         self._succ_ev = torch.cuda.Event()
         self._roll_ev = torch.cuda.Event()
         self._succ_pending = False
+        self._succ_exchanged = False
+        self._succ_msg = None
         self.side_stream_curriculum = True     # False: pack + copy on the main stream inside update_curriculum (A/B, tools/ab_loop.py)
         if policy == "lstm":
             L, H = layers, hidden
@@ -227,9 +229,20 @@ class VecPPOTrainer:
             self._roll_ev.record()
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._roll_ev)
-                self._succ_host.copy_(pack_episode_successes(self.buf["flags"]), non_blocking=True)
-                self._succ_ev.record(self._side)
+                self._succ_msg = pack_local_successes(self.buf["flags"])
             self._succ_pending = True
+            self._succ_exchanged = False
+            if self.world == 1:
+                self._exchange_successes()
+
+    def _exchange_successes(self):
+        """All-gather of the packed success bits + copy to pinned host memory, on the side stream.  With several ranks it is
+        issued from update(), BEHIND the advantage-statistics all-reduce in program order: RCCL runs a rank's collectives
+        in the order they were issued, and that all-reduce must not queue behind the pack kernel."""
+        with torch.cuda.stream(self._side):
+            self._succ_host.copy_(exchange_successes(self._succ_msg), non_blocking=True)
+            self._succ_ev.record(self._side)
+        self._succ_exchanged = True
 
     def _collect_stepwise_lstm(self, forced_act=None, noise=None):
         """Stacked / wide LSTM policies (BASELINE C5: h=256 x2): one cell step per layer + heads GEMM +
@@ -330,6 +343,8 @@ class VecPPOTrainer:
         if self.check_ranges() != "fp16x3":
             self._rollout_forward_valid = False
         self.compute_advantages()
+        if self._succ_pending and not self._succ_exchanged:
+            self._exchange_successes()
         b, hp = self.buf, self.hp
         N, T, M = self.N, self.T, self.num_minibatches
         nb = N // M
@@ -389,9 +404,11 @@ class VecPPOTrainer:
         global (env, time)-ordered sequence to its replicated curriculum."""
         if self.curriculum is None:
             return
-        if not self._succ_pending:             # flags not produced by collect(): pack them now
-            self._succ_host.copy_(pack_episode_successes(self.buf["flags"]), non_blocking=True)
+        if not self._succ_pending:             # flags not produced by collect(): pack and exchange them now
+            self._succ_host.copy_(exchange_successes(pack_local_successes(self.buf["flags"])), non_blocking=True)
             self._succ_ev.record()
+        elif not self._succ_exchanged:         # collect() without an update() in between
+            self._exchange_successes()
         self._succ_ev.synchronize()
         self._succ_pending = False
         self.curriculum.update_many(unpack_episode_successes(self._succ_host.numpy(), self.buf["flags"]))
