@@ -5,7 +5,7 @@
 //   rollout_mlp_kernel   R1 for the MLP policy (train_ppo2.0.py:157-198 for N environments x T steps in ONE launch):
 //                        policy forward -> Categorical sample -> env step -> store, 16 environments per workgroup.
 //   mlp_ppo_grad_kernel  U1-U3 up to the gradient (train_ppo2.0.py:55-86): forward, clipped-PPO loss, backward through the
-//                        whole network for tiles of 16 samples; LayerNorm statistics, activations and their gradients
+//                        whole network for tiles of 32 samples; LayerNorm statistics, activations and their gradients
 //                        never leave the CU, weight gradients accumulate in registers over all of a workgroup's tiles and
 //                        leave as one slab per workgroup.  HBM traffic = the 44 algorithmic bytes per sample.
 //
