@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void adv_normalise_kernel(const float* __restr
 // One block: every thread counts its contiguous chunk, a block scan gives its write offset (order preserving, no atomics).
 __global__ __launch_bounds__(1024) void pack_success_kernel(const uint8_t* __restrict__ flags, int64_t n, int cap,
                                                             uint8_t* __restrict__ msg) {
-    __shared__ int part[1024];
+    __shared__ int part[32];
     const int tid = threadIdx.x;
     int64_t per = (n + 1023) / 1024;
     per = (per + 15) / 16 * 16;                         // 16-byte loads; ended episodes are rare, so whole zero words are skipped
@@ -154,19 +154,30 @@ __global__ __launch_bounds__(1024) void pack_success_kernel(const uint8_t* __res
     };
     int cnt = 0;
     visit([&](uint8_t) { ++cnt; });
-    part[tid] = cnt;
     for (int i = tid; i < 4 + cap + 1; i += 1024) msg[i] = 0;
-    __syncthreads();
-    // inclusive scan (Hillis-Steele over 1024 entries)
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = (tid >= o) ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    // exclusive prefix of cnt over the 1024 threads: wave scan by shuffles, then the 16 wave totals by the first wave
+    const int lane = tid & 63, wv = tid >> 6;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
     }
-    int pos = part[tid] - cnt;
-    if (tid == 1023) {
-        const unsigned total = (unsigned)part[1023];
+    if (lane == 63) part[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        int t = lane < 16 ? part[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int v = __shfl_up(t, o, 64);
+            if (lane >= o) t += v;
+        }
+        if (lane < 16) part[16 + lane] = t;             // inclusive totals of waves 0..lane
+    }
+    __syncthreads();
+    int pos = inc - cnt + (wv ? part[16 + wv - 1] : 0);
+    if (tid == 0) {
+        const unsigned total = (unsigned)part[31];
         msg[0] = total & 255; msg[1] = (total >> 8) & 255; msg[2] = (total >> 16) & 255; msg[3] = (total >> 24) & 255;
     }
     if (cnt) visit([&](uint8_t v) {
