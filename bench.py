@@ -395,6 +395,12 @@ def main():
         # every rank is a fresh process; rank 0 prints the one JSON line.
         raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
+    # stdout carries exactly ONE line, the JSON.  Native libraries write there too (RCCL prints a version banner on stdout
+    # when its first communicator comes up), so from here on fd 1 is stderr and the line goes out through the saved fd.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -405,8 +411,13 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)      # rehearsal: several ranks may share one GPU (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # UAVPPO_FORCE_COLLECTIVES=1 at one rank: every exchange of the iteration goes through a one-rank communicator
+    # (RCCL rehearsal on a one-GPU box: what the collectives' launches cost, and that the code path runs at all)
+    rehearsal = world == 1 and os.environ.get("UAVPPO_FORCE_COLLECTIVES") == "1"
+    if world > 1 or rehearsal:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -462,12 +473,15 @@ def main():
         out["strong_scaling"] = {"value": n_strong * T * world * k2 / dt2, "unit": "env-steps/s", "num_envs_per_gpu": n_strong,
                                  "num_envs_total": n_strong * world, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
                                  "rollout_ms": roll2}
+    if rehearsal:
+        out["rehearsal"] = f"one-rank {args.backend} communicator, all exchanges issued (UAVPPO_FORCE_COLLECTIVES=1)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_vectorised"] = cpu_baseline_vectorised(T=128, H=128, n_full=4096)
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -3,12 +3,23 @@
 'gloo' in the CPU tests).  No data-path collective exists: rollout buffers never leave a rank."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def collectives_on():
+    """True when the iteration's exchanges must be issued: more than one rank, or UAVPPO_FORCE_COLLECTIVES=1 with an
+    initialised process group (a one-rank RCCL communicator then carries every exchange unchanged: how the RCCL code
+    path is exercised on a one-GPU box, tests/test_gpu_multirank.py::test_rccl_single_rank_path)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("UAVPPO_FORCE_COLLECTIVES") == "1"
 
 
 def env_shard(rank, envs_per_rank):
@@ -20,7 +31,7 @@ def env_shard(rank, envs_per_rank):
 def allreduce_adv_stats(stats3):
     """(sum, sum of squares, count) of the advantages over ALL ranks: the reference normalises over
     the whole buffer (train_ppo2.0.py:35-39)."""
-    if world() > 1:
+    if collectives_on():
         dist.all_reduce(stats3)
     return stats3
 
@@ -29,7 +40,7 @@ def allreduce_grad(flat_grad):
     """ONE all-reduce (sum) of the flat gradient per optimiser step.  Every rank's loss is already
     scaled by 1/(global sample count), so the sum IS the global-mean gradient; the clip norm is
     computed after it, identically on all ranks."""
-    if world() > 1:
+    if collectives_on():
         dist.all_reduce(flat_grad)
     return flat_grad
 
@@ -58,7 +69,7 @@ def pack_local_successes(flags):
 
 def exchange_successes(msg):
     """The messages of all ranks, stacked [world, 4 + SUCC_CAP + 1], after ONE all-gather (a view of `msg` at world 1)."""
-    if world() == 1:
+    if not collectives_on():
         return msg[None]
     parts = [torch.empty_like(msg) for _ in range(world())]
     dist.all_gather(parts, msg)
@@ -93,7 +104,7 @@ def gather_episode_successes(flags):
 def gather_episode_flags(flags):
     """[N_local, T] u8 flags of every rank concatenated in rank (= global env) order, so all ranks
     feed the SAME episode sequence to their replicated curriculum."""
-    if world() == 1:
+    if not collectives_on():
         return flags
     parts = [torch.empty_like(flags) for _ in range(world())]
     dist.all_gather(parts, flags)

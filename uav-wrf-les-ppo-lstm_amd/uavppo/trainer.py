@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, env_shard, exchange_successes, pack_local_successes,
+from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, collectives_on, env_shard, exchange_successes, pack_local_successes,
                          unpack_episode_successes)
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
@@ -34,6 +34,7 @@ class VecPPOTrainer:
         self.hp.update(hp)
         self.N, self.T = int(num_envs), int(horizon)
         self.rank, self.world = int(rank), int(world_size)
+        self._coll = self.world > 1 or collectives_on()          # the three exchanges of an iteration are issued
         self.device = torch.device(device)
         self.variant, self.seed = variant, int(seed)
         self.gae_mode = gae_mode
@@ -232,7 +233,7 @@ class VecPPOTrainer:
                 self._succ_msg = pack_local_successes(self.buf["flags"])
             self._succ_pending = True
             self._succ_exchanged = False
-            if self.world == 1:
+            if not self._coll:
                 self._exchange_successes()
 
     def _exchange_successes(self):
@@ -428,7 +429,7 @@ class VecPPOTrainer:
         # the rollout's NaN counter travels with the loss sums, so EVERY rank sees every rank's count and they all
         # raise together (a rank raising alone would leave the others waiting in the next all-reduce)
         t = torch.cat([self.loss_sums, self.nan_count.to(torch.float64)])
-        if self.world > 1:
+        if self._coll:
             import torch.distributed as dist
             dist.all_reduce(t)
         s = t.cpu().numpy()
