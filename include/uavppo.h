@@ -151,6 +151,17 @@ int uav_gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, 
                  int64_t sa_k, const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc,
                  const float* bias, int accumulate, uav_stream stream);
 
+/* The same product on the 16-bit matrix pipe at f32 accuracy: every f32 product as three fp16 piece products with f32
+ * accumulation (csrc/gemm_h3.hip), for the large shapes: M a multiple of 128, N of 128, each operand with unit stride
+ * along k or along its row index (rows 16-byte aligned where k is contiguous); other shapes are refused (use
+ * uav_gemm_f32).  Operands must lie inside fp16's range (|a| < 65504); a_absmax, when not NULL, points to a device
+ * float holding max |A| (uav_absmax): A is then scaled by one power of two into that range -- what a gradient operand
+ * (~1e-6) needs -- and the result scaled back, exactly.  No reference counterpart (it is how uav_lstm_wgrad evaluates
+ * dW = dG^T [h_prev | x] and dx = dG W_ih when H is not 64/128). */
+int uav_gemm_f16x3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m,
+                   int64_t sa_k, const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc,
+                   const float* bias, int accumulate, const float* a_absmax, uav_stream stream);
+
 /* out[c] = sum over rows of x[r][c]  (bias gradients; deterministic two-stage reduction).  cols <= 1024. */
 int uav_colsum(uav_ctx* ctx, const float* x, int64_t rows, int cols, float* out, uav_stream stream);
 /* LayerNorm(cols, eps 1e-5) + ReLU over the rows of z [rows][cols] (cols in 64/128/256/512): z is overwritten with the

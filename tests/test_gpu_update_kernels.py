@@ -191,6 +191,56 @@ def test_gemm(ops, M, N, K, ta, tb):
     assert np.allclose(out.cpu().numpy(), want - bias + c0, rtol=1e-5, atol=1e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(128, 128, 96, False, False), (256, 256, 1000, False, True), (128, 384, 50, True, False),
+                                         (1024, 256, 40000, True, False), (4096, 256, 1024, False, False),
+                                         (256, 128, 4100, True, True)])
+def test_gemm_split_fp16_has_f32_accuracy(ops, M, N, K, ta, tb):
+    """uav_gemm_f16x3 (three fp16 piece products per f32 product) against an f64 product: its error is no larger than the
+    exact-f32 MFMA kernel's on the same operands, in all four operand layouts, with and without split-K, K tails included."""
+    rng = np.random.RandomState(M + N + K)
+    a = rng.randn(*((K, M) if ta else (M, K))).astype(np.float32)
+    b = rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    bias = rng.randn(N).astype(np.float32)
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
+    f32 = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias)).cpu().numpy()
+    got = ops.gemm(dev(a), dev(b), ta, tb, bias=dev(bias), split_fp16=True).cpu().numpy()
+    scale = np.abs(want).max()
+    e32, e16 = np.abs(f32 - want).max() / scale, np.abs(got - want).max() / scale
+    assert e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+    c0 = rng.randn(M, N).astype(np.float32)
+    out = dev(c0)
+    ops.gemm(dev(a), dev(b), ta, tb, out=out, accumulate=True, split_fp16=True)
+    assert np.abs(out.cpu().numpy() - (want - bias + c0)).max() / scale <= 1.5 * e32 + 2e-7
+
+
+@pytest.mark.parametrize("magnitude", [1e-7, 3e-3, 1.0, 2e4, 1e9])
+def test_gemm_split_fp16_block_scale(ops, magnitude):
+    """A gradient-sized (or huge) A operand: with a_absmax the operand is scaled by a power of two into fp16's range and the
+    result keeps f32 accuracy; rows 1e-6 of the maximum still come out to f32 accuracy relative to their own size."""
+    rng = np.random.RandomState(7)
+    K, M, N = 6000, 256, 256
+    a = (rng.randn(K, M) * magnitude).astype(np.float32)
+    a[:, :16] *= 1e-6                                           # sixteen output rows far below the maximum
+    b = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    want = a.T.astype(np.float64) @ b.astype(np.float64)
+    amax = ops.absmax(dev(a))
+    assert np.isclose(amax.item(), np.abs(a).max())
+    got = ops.gemm(dev(a), dev(b), True, False, split_fp16=True, a_absmax=amax).cpu().numpy()
+    f32 = ops.gemm(dev(a), dev(b), True, False).cpu().numpy()
+    for rows in (slice(0, 16), slice(16, None)):
+        scale = np.abs(want[rows]).max()
+        e32, e16 = np.abs(f32[rows] - want[rows]).max() / scale, np.abs(got[rows] - want[rows]).max() / scale
+        assert e16 <= 1.5 * e32 + 1e-7, (rows, e16, e32)
+
+
+def test_gemm_split_fp16_refuses_other_shapes(ops):
+    a, b = torch.zeros(100, 64, device=DEV), torch.zeros(64, 128, device=DEV)
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.gemm(a, b, split_fp16=True)
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.gemm(torch.zeros(128, 64, device=DEV), torch.zeros(64, 100, device=DEV), split_fp16=True)
+
+
 def flat_from_state_dict(p):
     """reference state_dict -> the flat layout of csrc/mlp.hip."""
     order = ["feature.0.weight", "feature.0.bias", "feature.1.weight", "feature.1.bias", "feature.3.weight",

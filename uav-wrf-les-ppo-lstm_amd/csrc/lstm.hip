@@ -31,6 +31,13 @@ int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int6
              const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
              int accumulate, hipStream_t st);
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st);
+int colsum_absmax(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, unsigned* absmax_bits,
+                  hipStream_t st);
+bool gemm_h3_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B, int64_t sb_k,
+                int64_t sb_n);
+int gemm_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
+            int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias, int accumulate, const unsigned* a_absmax,
+            hipStream_t st);
 int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T,
                      int H, float* y, float* hn, float* cn, float* stash, hipStream_t st);
 int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
@@ -2014,15 +2021,30 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
     } else {
         // generic path: column sums use the tail of the workspace, the split-K slabs everything in front of it
         UAV_REQUIRE(stash, "uav_lstm_wgrad: stash is required when I > 6");
-        const size_t red_floats = (size_t)1024 * 4 * H;
+        const size_t red_floats = (size_t)1024 * 4 * H + 64;          // colsum partials + the word for max |dG|
         UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_wgrad: workspace too small");
         float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
         uav_ctx sub = *ctx;
         sub.ws_bytes = ctx->ws_bytes - red_floats * sizeof(float);
-        if ((rc = gemm_f32(&sub, 4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H, nullptr, 0, st))) return rc;
-        if ((rc = gemm_f32(&sub, 4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I, nullptr, 0, st))) return rc;
-        if ((rc = colsum(&sub, dgates, NT, 4 * H, db, red, st))) return rc;
+        // The large products go to the 16-bit matrix pipe as three fp16 piece products (gemm_h3.hip) unless exact f32 or
+        // the bf16 split was asked for: dG is block-scaled by one power of two from its absolute maximum, which the bias
+        // gradient's column-sum pass (it reads all of dG anyway) delivers; h_prev, x and W_ih are inside fp16's range
+        // under the same preconditions as the sequence kernels' (include/uavppo.h, uav_set_lstm_arith).
+        const bool h3 = !uav_want_f32_mfma() && !uav_want_bf16x6() && (4 * H) % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
+        unsigned* amax = h3 ? reinterpret_cast<unsigned*>(red + (size_t)1024 * 4 * H) : nullptr;
+        if ((rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st))) return rc;
+        auto product = [&](int64_t M, int64_t Nn, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
+                           int64_t sb_k, int64_t sb_n, float* C, int64_t ldc) {
+            if (h3 && gemm_h3_ok(M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n))
+                return gemm_h3(&sub, M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, nullptr, 0, amax, st);
+            return gemm_f32(&sub, M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, nullptr, 0, st);
+        };
+        if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H))) return rc;
+        if ((rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
         if (dheads && (rc = gemm_f32(&sub, n_heads, H, NT, dheads, 1, n_heads, y, H, 1, dw_head, H, nullptr, 0, st))) return rc;
+        if (dx) return product(NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I);
+        return 0;
     }
     if (dx) return gemm_f32(ctx, NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I, nullptr, 0, st);
     return 0;

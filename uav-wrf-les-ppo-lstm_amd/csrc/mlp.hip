@@ -153,10 +153,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 // the same for C % 4 == 0: a thread owns FOUR adjacent columns (dwordx4 loads) and keeps four rows in flight; fixed
 // association (row r goes to accumulator r % 4), so still deterministic.  4.3 GB of [1 M][1024] gate gradients: 1.8 -> ~0.9 ms
+// AMAX: also max |x| over the whole matrix as float bits (NaN sorts above inf), one atomicMax per wave: the block scale of
+// the split-fp16 GEMMs that consume the same matrix next (gemm_h3.hip) comes out of the pass that reads it anyway.
+template <bool AMAX>
 __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __restrict__ X, int64_t B, int C,
-                                                              int64_t rows_per_block, float* __restrict__ partial) {
+                                                              int64_t rows_per_block, float* __restrict__ partial,
+                                                              unsigned* __restrict__ absmax_bits) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+    unsigned mb = 0;
+    auto seen = [&](const float4& v) {
+        if (AMAX) {
+            const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+            const unsigned c2 = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+            const unsigned ab = a > b ? a : b, cd = c2 > d ? c2 : d, m4 = ab > cd ? ab : cd;
+            mb = mb > m4 ? mb : m4;
+        }
+    };
     for (int c = 4 * threadIdx.x; c < C; c += 1024) {
         float4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         int64_t r = r0;
@@ -165,11 +178,13 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __res
             for (int k = 0; k < 4; ++k) {
                 const float4 v = *reinterpret_cast<const float4*>(X + (r + k) * C + c);
                 a[k].x += v.x; a[k].y += v.y; a[k].z += v.z; a[k].w += v.w;
+                seen(v);
             }
         }
         for (; r < r1; ++r) {
             const float4 v = *reinterpret_cast<const float4*>(X + r * C + c);
             a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+            seen(v);
         }
         float* pp = partial + (int64_t)blockIdx.x * C + c;
         pp[0] = (a[0].x + a[1].x) + (a[2].x + a[3].x);
@@ -177,16 +192,36 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __res
         pp[2] = (a[0].z + a[1].z) + (a[2].z + a[3].z);
         pp[3] = (a[0].w + a[1].w) + (a[2].w + a[3].w);
     }
+    if (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)mb, o, 64);
+            mb = mb > t ? mb : t;
+        }
+        if ((threadIdx.x & 63) == 0 && mb) atomicMax(absmax_bits, mb);
+    }
 }
 
+int colsum_absmax(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, unsigned* absmax_bits,
+                  hipStream_t st);
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st) {
+    return colsum_absmax(ctx, X, B, C, out, scratch, nullptr, st);
+}
+// absmax_bits (optional; C % 4 == 0 and X 16-byte aligned required with it): device word that receives the bits of max |X|
+int colsum_absmax(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, unsigned* absmax_bits,
+                  hipStream_t st) {
     // column sums are tiny next to the GEMMs; keep them simple and deterministic
     int nb = (int)((B + 255) / 256);
     if (nb > 1024) nb = 1024;
     const int64_t rpb = (B + nb - 1) / nb;
     nb = (int)((B + rpb - 1) / rpb);
-    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0)
-        hipLaunchKernelGGL(colsum_partial4_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch);
+    const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    UAV_REQUIRE(!absmax_bits || vec, "colsum: the fused absolute maximum needs cols %% 4 == 0 and a 16-byte aligned matrix");
+    if (absmax_bits) {
+        UAV_CHECK_HIP(hipMemsetAsync(absmax_bits, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(colsum_partial4_kernel<true>, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch, absmax_bits);
+    } else if (vec)
+        hipLaunchKernelGGL(colsum_partial4_kernel<false>, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch, (unsigned*)nullptr);
     else
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, scratch);
     hipLaunchKernelGGL(rows_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, nb, C, out);

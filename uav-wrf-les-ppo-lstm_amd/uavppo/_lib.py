@@ -47,6 +47,7 @@ SIGNATURES = {
     "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),
     "uav_mse_bce": (I32, [P, P, P, I64, P, P, P]),
     "uav_gemm_f32": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P]),
+    "uav_gemm_f16x3": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P, P]),
     "uav_colsum": (I32, [P, P, I64, I32, P, P]),
     "uav_ln_relu": (I32, [P, P, P, P, P, P, I64, I32, P]),
     "uav_ln_relu_bwd": (I32, [P, P, P, P, P, P, I64, I32, P, P, P]),

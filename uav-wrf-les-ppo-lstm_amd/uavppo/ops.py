@@ -234,8 +234,10 @@ def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
 
 
 # ----------------------------------------------------------------------------- GEMM
-def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False):
-    """out[M,N] (+)= op(a) @ op(b) + bias with 2-D row-major tensors (op = optional transpose)."""
+def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False, split_fp16=False, a_absmax=None):
+    """out[M,N] (+)= op(a) @ op(b) + bias with 2-D row-major tensors (op = optional transpose).  split_fp16: the same
+    product as three fp16 piece products per f32 product (uav_gemm_f16x3: M % 128 == 0, N % 128 == 0, operands inside
+    fp16's range; a_absmax = 1-element device tensor with max |a| block-scales a gradient-sized operand)."""
     if a.dim() != 2 or b.dim() != 2:
         raise RuntimeError("gemm: 2-D tensors expected")
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -248,6 +250,11 @@ def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=Fal
         if accumulate:
             raise RuntimeError("gemm: accumulate needs out")
         out = torch.empty(M, N, dtype=F32, device=a.device)
+    if split_fp16:
+        check(lib().uav_gemm_f16x3(_h(a), M, N, K, _p(a, F32, name="a"), sa_m, sa_k, _p(b, F32, name="b"), sb_k, sb_n,
+                                   _p(out, F32, (M, N), "out"), N, _p(bias, F32, (N,), "bias"), int(accumulate),
+                                   _p(a_absmax, F32, (1,), "a_absmax"), _stream()), "uav_gemm_f16x3")
+        return out
     check(lib().uav_gemm_f32(_h(a), M, N, K, _p(a, F32, name="a"), sa_m, sa_k, _p(b, F32, name="b"), sb_k, sb_n,
                              _p(out, F32, (M, N), "out"), N, _p(bias, F32, (N,), "bias"), int(accumulate), _stream()),
           "uav_gemm_f32")
