@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 2   /* 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 3   /* 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -124,6 +124,19 @@ int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, c
                       int32_t* act_out, float* logp_out, float* probs_out, int32_t* nan_count,
                       uav_stream stream);
 
+/* The same draw for time step t of a step-wise rollout, read from and stored into the (env, T) arrays directly: heads =
+ * row t of a [n][T][n_act+1] (logits | value) array, i.e. rows heads_stride floats apart; act_out [n] (contiguous: the
+ * environment step's input); act_buf / val_buf / logp_buf [n][T] receive column t (PPOBuffer.store's action, value,
+ * log_prob: model.py:86-93 at train_ppo2.0.py:192).  Counter RNG only (or forced_act). */
+int uav_policy_sample_at(uav_ctx* ctx, const float* heads, int64_t heads_stride, int64_t n, int n_act, uint64_t seed,
+                         uint64_t counter, int64_t index_offset, const int32_t* forced_act, int32_t* act_out, int T, int t,
+                         int32_t* act_buf, float* val_buf, float* logp_buf, int32_t* nan_count, uav_stream stream);
+/* PPOBuffer.store's remaining columns for step t of n envs: keep (the restart mask step t ran with), reward, done, flags
+ * -> column t of the [n][T] buffers; keep [n] is then overwritten with the next step's mask 1 - done. */
+int uav_store_transition(uav_ctx* ctx, int n, int T, int t, float* keep, const float* rew, const float* done,
+                         const uint8_t* flags, float* keep_buf, float* rew_buf, float* done_buf, uint8_t* flags_buf,
+                         uav_stream stream);
+
 /* ---- U3: global-norm clip + Adam on one flat f32 buffer (train_ppo2.0.py:87-88,114;
  * torch clip_grad_norm_ / optim.Adam formulas).  `step` is the 1-based optimiser step.
  * gnorm_out: f32[1] device (pre-clip global L2 norm) or NULL.  pmax_out: f32[1] device or NULL: max |param| AFTER the
@@ -143,6 +156,24 @@ int uav_smooth_l1(uav_ctx* ctx, const float* pred, const float* target, int64_t 
  * backward: out, target, dout f32 [n][2] = (peak, stop_logit) / (y_peak, y_stop) / d(loss)/d(out); loss_mean f64[1]. */
 int uav_mse_bce(uav_ctx* ctx, const float* out, const float* target, int64_t n, double* loss_mean, float* dout,
                 uav_stream stream);
+
+/* ---- uav_lstm_fwd one time step per call (H = 256, fp16-split arithmetic only): the rollout of a stacked / wide LSTM
+ * policy, where an environment step sits between two time steps.  Same kernels and bit-identical results to
+ * uav_lstm_fwd over the same inputs; the weights are split once per rollout, the recurrent state stays on the device in
+ * the caller-owned `state` buffer (uav_lstm_stepper_bytes(N, I, H) bytes, 256-byte aligned; 0 = shape not supported),
+ * and y / stash are the [N][T][H] / [N][T][6H] arrays uav_lstm_bwd reads, filled at time index t.
+ *   begin  splits the weights, sets the state to (h0, c0) [N][H]
+ *   step   x [N][T][I] (row t read), writes y[:, t], stash[:, t]; at t == T-1 also hn, cn [N][H] (required pointers)
+ *   mask   state *= keep_next[n] after step t (t = -1: the initial state): nn.LSTM has no such mask -- it is how the
+ *          vectorised rollout restarts the recurrent state where an episode ended (train_ppo2.0.py:157-198 runs one
+ *          episode at a time and never carries state across). */
+size_t uav_lstm_stepper_bytes(int N, int I, int H);
+int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const float* w_hh, const float* b_ih,
+                           const float* b_hh, const float* h0, const float* c0, int N, int I, int H, uav_stream stream);
+int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, int N, int T, int t, int I, int H, float* y,
+                          float* stash, float* hn, float* cn, uav_stream stream);
+int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, int N, int t, int I, int H,
+                          uav_stream stream);
 
 /* ---- dense f32 building block (exact-f32 MFMA): C[M][N] (+)= op(A)[M][K] * op(B)[K][N] + bias[N].
  * Element (i,k) of op(A) is A[i*sa_m + k*sa_k]; element (k,j) of op(B) is B[k*sb_k + j*sb_n]

@@ -353,3 +353,45 @@ def test_gate_activation_error_bounds(ops):
     print("sigmoid abs", worst_abs_s, "tanh abs", worst_abs_t, "tanh rel*|x|", worst_rel_t)
     assert worst_abs_s < 1.5e-7 and worst_abs_t < 2.5e-7
     assert worst_rel_t < 2.5e-7            # relative error of tanh <= 2.5e-7 / min(|x|, 1)
+
+
+@pytest.mark.parametrize("N,T,I", [(64, 6, 8), (100, 5, 256), (37, 3, 40)])
+def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
+    """uav_lstm_stepper_* (one time step per call: the step-wise rollout of an h = 256 policy) runs the kernels of
+    uav_lstm_fwd: with the restart mask applied by its own kernel after each step, y, the BPTT stash and the final state
+    are BIT-identical to the sequence call over the same inputs -- which is why PPO epoch 0 may adopt a rollout's stash."""
+    H = 256
+    g = torch.Generator().manual_seed(N + T + I)
+    x = torch.randn(N, T, I, generator=g).to(DEV)
+    keep = (torch.rand(N, T, generator=g) > 0.25).float()
+    keep[:, 0] = 1.0
+    keep = keep.to(DEV)
+    h0, c0 = (torch.randn(N, H, generator=g) * 0.5).to(DEV), (torch.randn(N, H, generator=g) * 0.5).to(DEV)
+    w_ih, w_hh = (torch.randn(4 * H, I, generator=g) * 0.1).to(DEV), (torch.randn(4 * H, H, generator=g) * 0.1).to(DEV)
+    b_ih, b_hh = (torch.randn(4 * H, generator=g) * 0.1).to(DEV), (torch.randn(4 * H, generator=g) * 0.1).to(DEV)
+    y_ref, hn_ref, cn_ref, stash_ref = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
+    sp = ops.LstmStepper(N, I, H, DEV)
+    sp.begin(w_ih, w_hh, b_ih, b_hh, h0, c0)
+    y, stash = torch.zeros(N, T, H, device=DEV), torch.zeros(N, T, 6 * H, device=DEV)
+    for t in range(T):
+        sp.step(x, t, y, stash)
+        if t < T - 1:
+            sp.mask(t, keep[:, t + 1].contiguous())
+    assert torch.equal(y, y_ref) and torch.equal(stash, stash_ref)
+    assert torch.equal(sp.hn, hn_ref) and torch.equal(sp.cn, cn_ref)
+    # a second rollout from the handed-over state: begin() again, mask of the initial state through t = -1
+    sp.begin(w_ih, w_hh, b_ih, b_hh, hn_ref, cn_ref)
+    k0 = (torch.rand(N, generator=g) > 0.5).float().to(DEV)
+    sp.mask(-1, k0)
+    keep2 = keep.clone()
+    keep2[:, 0] = k0
+    y2_ref, _, _, _ = ops.lstm_fwd(x, keep2, hn_ref, cn_ref, w_ih, w_hh, b_ih, b_hh)
+    sp.step(x, 0, y, stash)
+    assert torch.equal(y[:, 0], y2_ref[:, 0])
+
+
+def test_lstm_stepper_refuses_other_shapes(ops):
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.LstmStepper(16, 6, 128, DEV)
+    with pytest.raises(RuntimeError, match="not supported"):
+        ops.LstmStepper(16, 300, 256, DEV)

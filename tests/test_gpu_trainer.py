@@ -418,6 +418,36 @@ def test_lstm_trainer_edge_shapes(N, T, H):
     assert np.allclose(tr.adv.cpu().numpy(), po.gae_reference_exact(b["rew"], b["val"], b["done"]), rtol=2e-5, atol=2e-5)
 
 
+def test_stepper_rollout_equals_per_call_rollout_and_is_adopted():
+    """h = 256 stacked: the stepper rollout (uav_lstm_stepper_*: weights split once, state on the device, stash / y / heads
+    written into the update's arrays) gives the SAME rollout as one uav_lstm_fwd call per layer and step, bit for bit; its
+    stash equals what the sequence forward recomputes, and an update that adopts it ends on the same parameters."""
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    mk = lambda: VecPPOTrainer(72, 10, "lstm", hidden=256, layers=2, variant="v2.1", device=DEV, seed=5, trend_k=2, epochs=2)
+    a, b = mk(), mk()
+    b.use_stepper = False
+    for it in range(2):                       # second iteration: state handed over from the first, episodes restarting
+        a.collect(); b.collect()
+        assert a._rollout_forward_valid and not b._rollout_forward_valid
+        for k in ("obs", "act", "rew", "val", "logp", "done", "keep", "flags"):
+            assert torch.equal(a.buf[k], b.buf[k]), (it, k)
+        assert torch.equal(a.h, b.h) and torch.equal(a.c, b.c)
+        x = a.buf["obs"]
+        for l in range(2):
+            v = a.policy.views
+            y, _, _, stash = ops.lstm_fwd(x, a.buf["keep"], a.h0[l], a.c0[l], v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"],
+                                          v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"])
+            assert torch.equal(a.work[f"y{l}"], y) and torch.equal(a.work[f"stash{l}"], stash), (it, l)
+            x = y
+        heads = ops.gemm(x.reshape(-1, 256), a.policy.views["head.weight"], trans_b=True, bias=a.policy.views["head.bias"])
+        assert torch.allclose(a.work["heads"].reshape(-1, 6), heads, atol=1e-6)
+        a.update(); b.update()
+        a.update_curriculum(); b.update_curriculum()
+        a.iteration += 1; b.iteration += 1
+        assert torch.equal(a.policy.flat, b.policy.flat), it
+
+
 def test_c5_trend_policy_trains():
     """C5 shape family with the trend channels: obs_dim 8, stacked h=256 LSTM, step-wise rollout."""
     from uavppo.trainer import VecPPOTrainer

@@ -174,12 +174,14 @@ template <int A>
 __global__ __launch_bounds__(256) void policy_sample_kernel(
     const float* __restrict__ logits, int64_t n, const float* __restrict__ u, uint64_t seed,
     uint64_t counter, int64_t index_offset, const int32_t* __restrict__ forced, int32_t* __restrict__ act_out,
-    float* __restrict__ logp_out, float* __restrict__ probs_out, int32_t* __restrict__ nan_count) {
+    float* __restrict__ logp_out, float* __restrict__ probs_out, int32_t* __restrict__ nan_count,
+    int64_t stride = A, int T = 0, int t = 0, int32_t* __restrict__ act_buf = nullptr, float* __restrict__ val_buf = nullptr,
+    float* __restrict__ logp_buf = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float z[A], p[A];
 #pragma unroll
-    for (int k = 0; k < A; ++k) z[k] = logits[i * A + k];
+    for (int k = 0; k < A; ++k) z[k] = logits[i * stride + k];
     softmax_row<A>(z, p);
     float psum = 0.f;
     bool bad = false;
@@ -218,7 +220,32 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(
         if (k == a) qa = p[k] / psum;
     }
     act_out[i] = a;
-    logp_out[i] = logf(fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS));
+    const float lp = logf(fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS));
+    if (logp_out) logp_out[i] = lp;
+    if (act_buf) {             // uav_policy_sample_at: straight into the (env, T) rollout buffers; value = the row's next element
+        act_buf[i * T + t] = a;
+        logp_buf[i * T + t] = lp;
+        val_buf[i * T + t] = logits[i * stride + A];
+    }
+}
+
+// PPOBuffer.store for one time step of N envs (model.py:86-93 as called at train_ppo2.0.py:192): the environment's
+// outputs of step t and the restart mask the step ran with go to column t of the (env, T) buffers; keep becomes the
+// next step's mask 1 - done.
+__global__ __launch_bounds__(256) void store_transition_kernel(int n, int T, int t, float* __restrict__ keep,
+                                                               const float* __restrict__ rew, const float* __restrict__ done,
+                                                               const uint8_t* __restrict__ flags, float* __restrict__ keep_buf,
+                                                               float* __restrict__ rew_buf, float* __restrict__ done_buf,
+                                                               uint8_t* __restrict__ flags_buf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = (int64_t)i * T + t;
+    const float d = done[i];
+    keep_buf[o] = keep[i];
+    rew_buf[o] = rew[i];
+    done_buf[o] = d;
+    flags_buf[o] = flags[i];
+    keep[i] = 1.0f - d;
 }
 
 // block partials [nb][LOSS_PSTRIDE] -> loss_sums[4] (+ head-bias gradient), for the fused kernels of other files
@@ -307,6 +334,42 @@ int uav_policy_sample(uav_ctx* ctx, const float* logits, int64_t n, int n_act, c
         default: UAV_REQUIRE(false, "uav_policy_sample: n_act=%d unsupported", n_act);
     }
 #undef LAUNCH_S
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_policy_sample_at(uav_ctx* ctx, const float* heads, int64_t heads_stride, int64_t n, int n_act, uint64_t seed,
+                         uint64_t counter, int64_t index_offset, const int32_t* forced_act, int32_t* act_out, int T, int t,
+                         int32_t* act_buf, float* val_buf, float* logp_buf, int32_t* nan_count, uav_stream stream) {
+    UAV_REQUIRE(ctx && heads && act_out && act_buf && val_buf && logp_buf && nan_count && n > 0, "uav_policy_sample_at: bad argument");
+    UAV_REQUIRE(heads_stride > n_act && T > 0 && t >= 0 && t < T, "uav_policy_sample_at: heads_stride=%lld n_act=%d T=%d t=%d",
+                (long long)heads_stride, n_act, T, t);
+    const int nb = (int)((n + 255) / 256);
+#define LAUNCH_S(A_)                                                                                                         \
+    hipLaunchKernelGGL(policy_sample_kernel<A_>, dim3(nb), dim3(256), 0, as_stream(stream), heads, n, (const float*)nullptr, \
+                       seed, counter, index_offset, forced_act, act_out, (float*)nullptr, (float*)nullptr, nan_count,       \
+                       heads_stride, T, t, act_buf, val_buf, logp_buf)
+    switch (n_act) {
+        case 2: LAUNCH_S(2); break;
+        case 3: LAUNCH_S(3); break;
+        case 4: LAUNCH_S(4); break;
+        case 5: LAUNCH_S(5); break;
+        case 6: LAUNCH_S(6); break;
+        case 8: LAUNCH_S(8); break;
+        default: UAV_REQUIRE(false, "uav_policy_sample_at: n_act=%d unsupported", n_act);
+    }
+#undef LAUNCH_S
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_store_transition(uav_ctx* ctx, int n, int T, int t, float* keep, const float* rew, const float* done,
+                         const uint8_t* flags, float* keep_buf, float* rew_buf, float* done_buf, uint8_t* flags_buf,
+                         uav_stream stream) {
+    UAV_REQUIRE(ctx && keep && rew && done && flags && keep_buf && rew_buf && done_buf && flags_buf, "uav_store_transition: NULL argument");
+    UAV_REQUIRE(n > 0 && T > 0 && t >= 0 && t < T, "uav_store_transition: n=%d T=%d t=%d", n, T, t);
+    hipLaunchKernelGGL(store_transition_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), n, T, t, keep, rew, done,
+                       flags, keep_buf, rew_buf, done_buf, flags_buf);
     UAV_LAUNCH_CHECK();
     return 0;
 }

@@ -499,6 +499,120 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
 }
 bool lstm_h3_step_path(int H) { return h3_step_ok(H); }
 
+// ---- the same step kernel, one time step per call (uav_lstm_stepper_*): an environment step can sit between two time
+// steps (the rollout of a stacked / h = 256 policy), the weights are split once per rollout instead of once per step, the
+// recurrent state stays in its piece planes between calls, and stash / y land in the [N][T] arrays the update's BPTT
+// reads -- so PPO epoch 0 needs no forward pass.  The sequence driver above masks the state for step t + 1 inside step t
+// (keep[n][t + 1]); a rollout only knows that mask after the environment step, so it is applied by its own small kernel.
+struct StepperLayout { size_t hs, cs, hp0, hp1, wp, wxp, bsum, total; int IP; };
+static StepperLayout stepper_layout(int N, int I) {
+    constexpr int H = 256;
+    StepperLayout L;
+    int IP = (I + 31) / 32 * 32;
+    L.IP = IP <= 32 ? 32 : (IP <= 64 ? 64 : (IP <= 128 ? 128 : 256));
+    const size_t NH = (size_t)N * H, NP = (size_t)(N + 63) / 64 * 64 * H;
+    size_t o = 0;
+    L.hs = o; o += NH * 4;
+    L.cs = o; o += NH * 4;
+    L.hp0 = o; o += 2 * NP * 2;
+    L.hp1 = o; o += 2 * NP * 2;
+    L.wp = o; o += (size_t)2 * 4 * H * H * 2;
+    L.wxp = o; o += (size_t)2 * 4 * H * L.IP * 2;
+    L.bsum = o; o += (size_t)4 * H * 4;
+    L.total = (o + 255) / 256 * 256;
+    return L;
+}
+
+// state <- state * keep[n] (f32 and pieces): the mask of the step about to run, known only after the environment step
+__global__ void h3_mask_state(const float* __restrict__ keep, int N, int H, float* __restrict__ hs, float* __restrict__ cs,
+                              unsigned short* __restrict__ hp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)N * H) return;
+    const int n = (int)(i / H), u = (int)(i % H);
+    const float k = keep[n];
+    const float h = hs[i] * k;
+    hs[i] = h;
+    cs[i] *= k;
+    _Float16 p0, p1;
+    split2h(h, p0, p1);
+    hp[frag_index(n, u, H, 0)] = h_bits(p0);
+    hp[frag_index(n, u, H, 1)] = h_bits(p1);
+}
+
+extern "C" {
+
+size_t uav_lstm_stepper_bytes(int N, int I, int H) {
+    if (H != 256 || N <= 0 || I <= 0 || I > 256) return 0;
+    return stepper_layout(N, I).total;
+}
+
+int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const float* w_hh, const float* b_ih,
+                           const float* b_hh, const float* h0, const float* c0, int N, int I, int H, uav_stream stream) {
+    UAV_REQUIRE(ctx && state && w_ih && w_hh && b_ih && b_hh && h0 && c0, "uav_lstm_stepper_begin: NULL argument");
+    UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0, "uav_lstm_stepper_begin: H = %d, I = %d not supported (H = 256, I <= 256)", H, I);
+    g_uav_arith = ctx->lstm_arith;
+    UAV_REQUIRE(h3_step_ok(H), "uav_lstm_stepper_begin: only the fp16-split arithmetic steps (uav_set_lstm_arith)");
+    const StepperLayout L = stepper_layout(N, I);
+    char* b = (char*)state;
+    hipStream_t st = as_stream(stream);
+    const int64_t NH = (int64_t)N * H;
+    UAV_CHECK_HIP(hipMemsetAsync(b + L.hp0, 0, L.wp - L.hp0, st));            // rows of a ragged last tile stay finite
+    hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 0, (unsigned short*)(b + L.wp));
+    hipLaunchKernelGGL(split_weights_kernel, dim3((4 * H * L.IP + 255) / 256), dim3(256), 0, st, w_ih, 4 * H, I, L.IP, 0,
+                       (unsigned short*)(b + L.wxp));
+    hipLaunchKernelGGL(add2v_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, b_ih, b_hh, (float*)(b + L.bsum), 4 * H);
+    hipLaunchKernelGGL(h3_init_state, dim3((unsigned)((NH + 255) / 256)), dim3(256), 0, st, h0, c0, (const float*)nullptr, N, 1, H,
+                       (float*)(b + L.hs), (float*)(b + L.cs), (unsigned short*)(b + L.hp0));
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, int N, int T, int t, int I, int H, float* y, float* stash,
+                          float* hn, float* cn, uav_stream stream) {
+    UAV_REQUIRE(ctx && state && x && y && stash && hn && cn, "uav_lstm_stepper_step: NULL argument");
+    UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && T > 0 && t >= 0 && t < T, "uav_lstm_stepper_step: bad shape (N=%d T=%d t=%d I=%d H=%d)", N, T, t, I, H);
+    g_uav_arith = ctx->lstm_arith;
+    UAV_REQUIRE(h3_step_ok(H), "uav_lstm_stepper_step: only the fp16-split arithmetic steps (uav_set_lstm_arith)");
+    const StepperLayout L = stepper_layout(N, I);
+    char* b = (char*)state;
+    hipStream_t st = as_stream(stream);
+    const unsigned short* wxp = (const unsigned short*)(b + L.wxp);
+    const unsigned short* wp = (const unsigned short*)(b + L.wp);
+    const float* bsum = (const float*)(b + L.bsum);
+    unsigned short* hp0 = (unsigned short*)(b + L.hp0);
+    unsigned short* hp1 = (unsigned short*)(b + L.hp1);
+    float* hs = (float*)(b + L.hs);
+    float* cs = (float*)(b + L.cs);
+    const dim3 grid((N + 63) / 64, 256 / 64);
+#define LAUNCH_STEP(IPS_)                                                                                                     \
+    hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, (t & 1) ? hp1 : hp0,     \
+                       (t & 1) ? hp0 : hp1, hs, cs, stash, (const float*)nullptr, N, T, t, y, hn, cn)
+    switch (L.IP / 32) {
+        case 1: LAUNCH_STEP(1); break;
+        case 2: LAUNCH_STEP(2); break;
+        case 4: LAUNCH_STEP(4); break;
+        default: LAUNCH_STEP(8); break;
+    }
+#undef LAUNCH_STEP
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, int N, int t, int I, int H, uav_stream stream) {
+    UAV_REQUIRE(ctx && state && keep_next, "uav_lstm_stepper_mask: NULL argument");
+    UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && t >= -1, "uav_lstm_stepper_mask: bad shape (N=%d t=%d I=%d H=%d)", N, t, I, H);
+    const StepperLayout L = stepper_layout(N, I);
+    char* b = (char*)state;
+    // step t wrote the state of step t + 1 into the piece planes of parity (t + 1) & 1
+    unsigned short* hp = (unsigned short*)(b + (((t + 1) & 1) ? L.hp1 : L.hp0));
+    hipLaunchKernelGGL(h3_mask_state, dim3((unsigned)(((int64_t)N * H + 255) / 256)), dim3(256), 0, as_stream(stream), keep_next, N, H,
+                       (float*)(b + L.hs), (float*)(b + L.cs), hp);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
 static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                        const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
                        hipStream_t st) {

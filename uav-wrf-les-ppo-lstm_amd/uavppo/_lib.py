@@ -42,10 +42,16 @@ SIGNATURES = {
     "uav_ppo_loss": (I32, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P, P, P]),
     "uav_ppo_loss_from_y": (I32, [P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, F32, P, P, P, P]),
     "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, I64, P, P, P, P, P, P]),
+    "uav_policy_sample_at": (I32, [P, P, I64, I64, I32, U64, U64, I64, P, P, I32, I32, P, P, P, P, P]),
+    "uav_store_transition": (I32, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P]),
     "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P, P]),
     "uav_clip_adamw": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),
     "uav_mse_bce": (I32, [P, P, P, I64, P, P, P]),
+    "uav_lstm_stepper_bytes": (SZ, [I32, I32, I32]),
+    "uav_lstm_stepper_begin": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, P]),
+    "uav_lstm_stepper_step": (I32, [P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P]),
+    "uav_lstm_stepper_mask": (I32, [P, P, P, I32, I32, I32, I32, P]),
     "uav_gemm_f32": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P]),
     "uav_gemm_f16x3": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P, P]),
     "uav_colsum": (I32, [P, P, I64, I32, P, P]),

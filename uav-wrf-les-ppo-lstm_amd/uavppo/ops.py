@@ -170,6 +170,30 @@ def policy_sample(logits, u=None, seed=0, counter=0, forced_act=None, want_probs
     return act, logp, probs, nan_count
 
 
+def policy_sample_at(heads_seq, t, act_out, act_buf, val_buf, logp_buf, nan_count, seed=0, iteration=0, index_offset=0,
+                     forced_act=None):
+    """policy_sample for time step t of a step-wise rollout: logits | value read from heads_seq[:, t] ([N, T, A+1]), the
+    action also to act_out [N] (the env step's input), action / value / log-prob to column t of the [N, T] buffers."""
+    N, T, A1 = heads_seq.shape
+    check(lib().uav_policy_sample_at(_h(heads_seq), C.c_void_p(_p(heads_seq, F32, (N, T, A1), "heads_seq").value + 4 * int(t) * A1),
+                                     T * A1, N, A1 - 1, int(seed), (int(iteration) << 32) | (int(t) & 0xffffffff),
+                                     int(index_offset), _p(forced_act, I32, (N,), "forced_act"), _p(act_out, I32, (N,), "act_out"),
+                                     T, int(t), _p(act_buf, I32, (N, T), "act_buf"), _p(val_buf, F32, (N, T), "val_buf"),
+                                     _p(logp_buf, F32, (N, T), "logp_buf"), _p(nan_count, I32, (1,), "nan_count"), _stream()),
+          "uav_policy_sample_at")
+    return act_out
+
+
+def store_transition(t, keep, rew, done, flags, keep_buf, rew_buf, done_buf, flags_buf):
+    """PPOBuffer.store's remaining columns for step t: keep / rew / done / flags [N] -> column t of the [N, T] buffers;
+    keep becomes 1 - done (the next step's restart mask)."""
+    N, T = keep_buf.shape
+    check(lib().uav_store_transition(_h(keep), N, T, int(t), _p(keep, F32, (N,), "keep"), _p(rew, F32, (N,), "rew"),
+                                     _p(done, F32, (N,), "done"), _p(flags, U8, (N,), "flags"), _p(keep_buf, F32, (N, T), "keep_buf"),
+                                     _p(rew_buf, F32, (N, T), "rew_buf"), _p(done_buf, F32, (N, T), "done_buf"),
+                                     _p(flags_buf, U8, (N, T), "flags_buf"), _stream()), "uav_store_transition")
+
+
 def ppo_loss_heads(heads, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta, loss_sums, dheads, dhead_bias=None):
     """Packed form of ppo_loss: heads [n, A+1] (logits | value) in, dheads [n, A+1] out -- no split/concat copies."""
     n, A1 = heads.shape
@@ -234,6 +258,22 @@ def clip_adam(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999
 
 
 # ----------------------------------------------------------------------------- GEMM
+def gemm_rows(a, b_t, bias, out):
+    """out[n, :] = a[n, :] @ b_t.T + bias for ROW-STRIDED 2-D views a [N, K] and out [N, M] (unit stride along the last
+    index, any row stride: one time step of an [N, T, K] array) and a contiguous b_t [M, K]: uav_gemm_f32 with lda / ldc."""
+    N, K = a.shape
+    M = b_t.shape[0]
+    if a.stride(1) != 1 or out.stride(1) != 1 or tuple(out.shape) != (N, M) or b_t.shape[1] != K:
+        raise RuntimeError("gemm_rows: a [N, K] and out [N, M] need unit stride along the last index; b_t is [M, K]")
+    for t, nm in ((a, "a"), (out, "out")):
+        if not t.is_cuda or t.dtype != F32:
+            raise RuntimeError(f"gemm_rows: {nm}: expected a float32 GPU tensor")
+    check(lib().uav_gemm_f32(_h(a), N, M, K, C.c_void_p(a.data_ptr()), a.stride(0), 1, _p(b_t, F32, name="b_t"), 1, K,
+                             C.c_void_p(out.data_ptr()), out.stride(0), _p(bias, F32, (M,), "bias"), 0, _stream()),
+          "uav_gemm_f32")
+    return out
+
+
 def gemm(a, b, trans_a=False, trans_b=False, bias=None, out=None, accumulate=False, split_fp16=False, a_absmax=None):
     """out[M,N] (+)= op(a) @ op(b) + bias with 2-D row-major tensors (op = optional transpose).  split_fp16: the same
     product as three fp16 piece products per f32 product (uav_gemm_f16x3: M % 128 == 0, N % 128 == 0, operands inside
@@ -385,6 +425,39 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
     if _t is not None:
         _t.record()
     return y, hn, cn, stash
+
+
+class LstmStepper:
+    """uav_lstm_fwd one time step per call for one layer (H = 256, fp16-split arithmetic): weights split once by begin(),
+    recurrent state kept on the device in `state`; step(t) reads x[:, t] and fills y[:, t] / stash[:, t] of the [N, T]
+    arrays the BPTT reads; mask(t, keep_next) restarts the state of the envs whose episode ended in step t."""
+
+    def __init__(self, N, I, H, device):
+        nbytes = lib().uav_lstm_stepper_bytes(int(N), int(I), int(H))
+        if nbytes == 0:
+            raise RuntimeError(f"uav_lstm_stepper: N={N} I={I} H={H} not supported (H = 256, I <= 256)")
+        self.N, self.I, self.H = int(N), int(I), int(H)
+        self.state = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.hn = torch.empty(N, H, dtype=F32, device=device)
+        self.cn = torch.empty(N, H, dtype=F32, device=device)
+
+    def begin(self, w_ih, w_hh, b_ih, b_hh, h0, c0):
+        N, I, H = self.N, self.I, self.H
+        check(lib().uav_lstm_stepper_begin(_h(self.state), _p(self.state), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                                           _p(w_hh, F32, (4 * H, H), "w_hh"), _p(b_ih, F32, (4 * H,), "b_ih"),
+                                           _p(b_hh, F32, (4 * H,), "b_hh"), _p(h0, F32, (N, H), "h0"), _p(c0, F32, (N, H), "c0"),
+                                           N, I, H, _stream()), "uav_lstm_stepper_begin")
+
+    def step(self, x, t, y, stash):
+        N, I, H = self.N, self.I, self.H
+        T = x.shape[1]
+        check(lib().uav_lstm_stepper_step(_h(self.state), _p(self.state), _p(x, F32, (N, T, I), "x"), N, T, int(t), I, H,
+                                          _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"), _p(self.hn),
+                                          _p(self.cn), _stream()), "uav_lstm_stepper_step")
+
+    def mask(self, t, keep_next):
+        check(lib().uav_lstm_stepper_mask(_h(self.state), _p(self.state), _p(keep_next, F32, (self.N,), "keep_next"), self.N,
+                                          int(t), self.I, self.H, _stream()), "uav_lstm_stepper_mask")
 
 
 def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):

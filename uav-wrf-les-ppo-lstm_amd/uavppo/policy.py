@@ -184,11 +184,46 @@ class LSTMActorCritic(_FlatPolicy):
         return heads.view(N * T, self.n_act + 1)
 
     def adopt_forward(self, obs, keep, h0, stash, y):
-        """Epoch 0 of a PPO update runs with the rollout's parameters: the fused rollout kernel already wrote
-        this forward pass's stash and y, so register them instead of recomputing (single layer only)."""
-        self._saved = ([(obs, stash, y, h0[0])], keep, y)
-        N, T, H = y.shape
-        return y.view(N * T, H)
+        """Epoch 0 of a PPO update runs with the rollout's parameters: the rollout already wrote this forward pass's
+        stash and y (the fused rollout kernel; for stacked / h = 256 policies the stepper, one list entry per layer),
+        so register them instead of recomputing."""
+        stashes = stash if isinstance(stash, (list, tuple)) else [stash]
+        ys = y if isinstance(y, (list, tuple)) else [y]
+        saved, x = [], obs
+        for l in range(len(ys)):
+            saved.append((x, stashes[l], ys[l], h0[l]))
+            x = ys[l]
+        self._saved = (saved, keep, x)
+        N, T, H = x.shape
+        return x.view(N * T, H)
+
+    def steppers(self, N, device):
+        """One ops.LstmStepper per layer (uav_lstm_stepper_*: h = 256, fp16-split arithmetic), created once."""
+        if getattr(self, "_steppers", None) is None or self._steppers[0].N != N:
+            self._steppers = [ops.LstmStepper(N, self.obs_dim if l == 0 else self.hidden, self.hidden, device)
+                              for l in range(self.num_layers)]
+        return self._steppers
+
+    def begin_steps(self, h, c):
+        """Start a step-wise rollout from state h, c [L, N, H]: weights split once, state moved into the steppers."""
+        v = self.views
+        for l, sp in enumerate(self.steppers(h.shape[1], h.device)):
+            sp.begin(v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"], v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"],
+                     h[l], c[l])
+
+    def step_at(self, obs_seq, t, work, heads_seq):
+        """Time step t of all layers on the [N, T, ...] arrays of the update (obs_seq [N, T, I] row t already written;
+        work['y{l}'], work['stash{l}'] filled at t); heads_seq [N, T, A+1] row t = actor / critic rows of the top layer."""
+        x = obs_seq
+        for l, sp in enumerate(self._steppers):
+            sp.step(x, t, work[f"y{l}"], work[f"stash{l}"])
+            x = work[f"y{l}"]
+        v = self.views
+        return ops.gemm_rows(x[:, t], v["head.weight"], v["head.bias"], heads_seq[:, t])
+
+    def mask_steps(self, t, keep_next):
+        for sp in self._steppers:
+            sp.mask(t, keep_next)
 
     def step(self, obs, h, c, keep=None, work=None):
         """One time step for N envs (step-wise rollout of configurations the fused rollout kernel does

@@ -9,6 +9,8 @@ statistics (train_ppo2.0.py:35-39).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -76,6 +78,7 @@ class VecPPOTrainer:
         # channels and fused_mlp=False take the layer-by-layer path (uav_mlp_fwd / uav_ppo_loss / uav_mlp_bwd + step-wise rollout)
         self.fused_mlp = policy == "mlp" and D == 6
         self.reuse_rollout_forward = True    # epoch 0 adopts the rollout kernel's stash (same parameters)
+        self.use_stepper = True              # h = 256 step-wise rollouts through uav_lstm_stepper_* (A/B switch)
         self._rollout_forward_valid = False
         self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
         self.log = []
@@ -253,21 +256,38 @@ class VecPPOTrainer:
             f32 = dict(dtype=torch.float32, device=self.device)
             self._st = {"rew": torch.zeros(self.N, **f32), "done": torch.zeros(self.N, **f32),
                         "flags": torch.zeros(self.N, dtype=torch.uint8, device=self.device),
+                        "act": torch.zeros(self.N, dtype=torch.int32, device=self.device),
                         "keep": torch.ones(self.N, **f32), "work": {}}
         st = self._st
         cfg = self.env_cfg()
         st["keep"].fill_(1.0)
+        # h = 256 on the fp16-split arithmetic, one minibatch: the stepper (uav_lstm_stepper_*) -- weights split once per
+        # rollout, state kept in its piece planes, stash / y / heads written at [:, t] of the update's own arrays, so that
+        # PPO epoch 0 adopts this forward pass.  Otherwise one uav_lstm_fwd call of T = 1 per layer and step.
+        stepper = (self.use_stepper and self.policy.hidden == 256 and self.arith == "fp16x3" and self.num_minibatches == 1
+                   and not os.environ.get("UAV_LSTM_F32_MFMA") and not os.environ.get("UAV_LSTM_STEP_F32"))
+        if stepper:
+            self.policy.begin_steps(self.h, self.c)
         for t in range(self.T):
-            heads = self.policy.step(self.cur_obs, self.h, self.c, st["keep"], st["work"])
+            if stepper:
+                b["obs"][:, t] = self.cur_obs
+                heads = self.policy.step_at(b["obs"], t, self.work, self.work["heads"])
+            else:
+                heads = self.policy.step(self.cur_obs, self.h, self.c, st["keep"], st["work"])
             fa = None if forced_act is None else forced_act[:, t].contiguous()
-            act, logp, _, _ = ops.policy_sample(heads[:, :5].contiguous(), seed=self.seed, counter=t,
-                                                iteration=self.iteration, index_offset=env_shard(self.rank, self.N)[0],
-                                                forced_act=fa, nan_count=self.nan_count)
-            b["obs"][:, t] = self.cur_obs
-            b["act"][:, t] = act
-            b["val"][:, t] = heads[:, 5]
-            b["logp"][:, t] = logp
-            b["keep"][:, t] = st["keep"]
+            if stepper:        # sample from heads[:, t] in place; action / value / log-prob straight into column t
+                act = ops.policy_sample_at(self.work["heads"], t, st["act"], b["act"], b["val"], b["logp"], self.nan_count,
+                                           seed=self.seed, iteration=self.iteration, index_offset=env_shard(self.rank, self.N)[0],
+                                           forced_act=fa)
+            else:
+                act, logp, _, _ = ops.policy_sample(heads[:, :5].contiguous(), seed=self.seed, counter=t,
+                                                    iteration=self.iteration, index_offset=env_shard(self.rank, self.N)[0],
+                                                    forced_act=fa, nan_count=self.nan_count)
+                b["obs"][:, t] = self.cur_obs
+                b["act"][:, t] = act
+                b["val"][:, t] = heads[:, 5]
+                b["logp"][:, t] = logp
+                b["keep"][:, t] = st["keep"]
             nz = None if noise is None else noise[:, t].contiguous()
             if self.info is not None and "info" not in st:
                 st["info"] = torch.zeros(self.N, 5, dtype=torch.float32, device=self.device)
@@ -282,10 +302,20 @@ class VecPPOTrainer:
                 self.info[:, t, 5] = st["term"][:, 2]
                 self.info[:, t, 6:8] = st["term"][:, :2] * 500.0       # step-wise path: position from the observation
                 self.info[:, t, 8:10] = st["src"]
-            b["rew"][:, t] = st["rew"]
-            b["done"][:, t] = st["done"]
-            b["flags"][:, t] = st["flags"]
-            torch.sub(1.0, st["done"], out=st["keep"])          # the recurrent state restarts where an episode ended
+            if stepper:        # one launch: keep / rew / done / flags -> column t; keep <- 1 - done
+                ops.store_transition(t, st["keep"], st["rew"], st["done"], st["flags"], b["keep"], b["rew"], b["done"], b["flags"])
+                if t < self.T - 1:
+                    self.policy.mask_steps(t, st["keep"])
+            else:
+                b["rew"][:, t] = st["rew"]
+                b["done"][:, t] = st["done"]
+                b["flags"][:, t] = st["flags"]
+                torch.sub(1.0, st["done"], out=st["keep"])      # the recurrent state restarts where an episode ended
+        if stepper:
+            for l, sp in enumerate(self.policy.steppers(self.N, self.device)):
+                self.h[l].copy_(sp.hn)
+                self.c[l].copy_(sp.cn)
+            self._rollout_forward_valid = self.reuse_rollout_forward
         # hand the state to the next rollout already masked (its keep[:, 0] is 1), like the fused kernel
         self.h.mul_(st["keep"][None, :, None])
         self.c.mul_(st["keep"][None, :, None])
@@ -360,7 +390,9 @@ class VecPPOTrainer:
                     if self._rollout_forward_valid:
                         # first optimiser step after a fused rollout: parameters unchanged since the rollout, whose
                         # kernel already wrote this forward pass (stash, y) and its heads
-                        self.policy.adopt_forward(b["obs"], b["keep"], self.h0, self.work["stash0"], self.work["y0"])
+                        L = self.policy.num_layers
+                        self.policy.adopt_forward(b["obs"], b["keep"], self.h0, [self.work[f"stash{l}"] for l in range(L)],
+                                                  [self.work[f"y{l}"] for l in range(L)])
                         heads = self.work["heads"]
                         self._rollout_forward_valid = False
                     else:
