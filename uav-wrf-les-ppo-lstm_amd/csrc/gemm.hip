@@ -244,7 +244,7 @@ int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int6
     // split K when the tile grid cannot fill the chip and K is deep
     int64_t S = 1;
     const int64_t tiles = tm * tn;
-    if (tiles < 2 * ctx->num_cu && K >= 64 * BK) {      // not below K = 1024: a second launch costs more than it saves
+    if (tiles < 2 * ctx->num_cu && K >= 16 * BK) {
         S = (2 * ctx->num_cu + tiles - 1) / tiles;
         const int64_t maxS_k = K / (8 * BK);
         if (S > maxS_k) S = maxS_k;

@@ -15,6 +15,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef STEP_ABL
+#define STEP_ABL 0      // ablation builds of step_fwd_h3_kernel only (tools/ab_step_fwd.sh): 1 no MFMAs, 2 no recurrent loads, 3 no epilogue
+#endif
+
 int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
              const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
              int accumulate, hipStream_t st);
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
                                                           float* __restrict__ y, float* __restrict__ hn,
                                                           float* __restrict__ cn) {
     constexpr int NS = H / 32, NC = 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar bases
+    const unsigned lo = lane * 8;                      // this lane's 16 bytes of a 1 KB fragment chunk
     const int r16 = lane & 15, kq = lane >> 4;
     const int e0 = blockIdx.x * 64 + 32 * (w >> 2), u0 = blockIdx.y * 64 + 16 * (w & 3);
     int nrow[NC];
@@ -177,6 +182,11 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         }
     }
     auto mac = [&](const f16x8 (&a)[4][2], const f16x8 (&b)[NC][2]) {
+#if STEP_ABL == 1
+        asm volatile("" ::"v"(a[0][0]), "v"(a[1][0]), "v"(a[2][0]), "v"(a[3][0]), "v"(a[0][1]), "v"(a[1][1]), "v"(a[2][1]), "v"(a[3][1]),
+                     "v"(b[0][0]), "v"(b[0][1]), "v"(b[1][0]), "v"(b[1][1]));
+        return;
+#endif
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -190,31 +200,34 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
     {
         const unsigned short* ap[4];                   // fragment order (frag_index): 1 KB per wave-wide load
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ap[g] = wp + (size_t)((g * H + u0) >> 4) * NS * 1024 + lane * 8;
+        for (int g = 0; g < 4; ++g) ap[g] = wp + (size_t)((g * H + u0) >> 4) * NS * 1024;
         const unsigned short* bp[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) bp[c] = hp_in + (size_t)((e0 + 16 * c) >> 4) * NS * 1024 + lane * 8;
-        f16x8 a[2][4][2], b[2][NC][2];                 // [buffer][gate | col tile][piece]
+        for (int c = 0; c < NC; ++c) bp[c] = hp_in + (size_t)((e0 + 16 * c) >> 4) * NS * 1024;
+        // DEPTH - 1 slabs in flight.  The scheduler barrier pins every slab's loads where they are written: left alone
+        // the machine scheduler sinks them next to their uses (fewest registers), one slab in flight, and the kernel
+        // then runs at the L2 latency per slab (step_bwd_h3_kernel: 20.5 -> 14.4 us by the same change)
+        // (only with a short input projection behind it: with IPS = 8 -- layer 2, whose time goes to the x gathers and
+        // the stash stores -- the pinned ring measured 36.6 us per step against 34.2 for the plain double buffer)
+        constexpr int DEPTH = IPS <= 2 ? 3 : 2;
+        f16x8 a[DEPTH][4][2], b[DEPTH][NC][2];         // [buffer][gate | col tile][piece]
+        auto fetch = [&](int s, int buf) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { a[0][g][0] = ldh8(ap[g]); a[0][g][1] = ldh8(ap[g] + 512); }
+            for (int g = 0; g < 4; ++g) { a[buf][g][0] = ldh8(ap[g] + (1024 * s + lo)); a[buf][g][1] = ldh8(ap[g] + (1024 * s + 512 + lo)); }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { b[0][c][0] = ldh8(bp[c]); b[0][c][1] = ldh8(bp[c] + 512); }
+            for (int c = 0; c < NC; ++c) { b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo)); }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) fetch(d, d);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s + 1 < NS) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    a[nxt][g][0] = ldh8(ap[g] + 1024 * (s + 1));
-                    a[nxt][g][1] = ldh8(ap[g] + 1024 * (s + 1) + 512);
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    b[nxt][c][0] = ldh8(bp[c] + 1024 * (s + 1));
-                    b[nxt][c][1] = ldh8(bp[c] + 1024 * (s + 1) + 512);
-                }
-            }
-            mac(a[cur], b[cur]);
+#if STEP_ABL == 2
+            mac(a[0], b[0]);
+#else
+            if (s + DEPTH - 1 < NS) fetch(s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
+            if (DEPTH > 2) __builtin_amdgcn_sched_barrier(0);
+            mac(a[s % DEPTH], b[s % DEPTH]);
+#endif
         }
     }
     // ---- input projection: x_t [n][I] f32 -> two fp16 pieces per value, K = 32 IPS; the next slab's weight fragments and
@@ -223,15 +236,16 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         constexpr int IP = 32 * IPS;
         const unsigned short* axp[4];                  // fragment order: + s * 1024 per slab, + 512 for the second piece
 #pragma unroll
-        for (int g = 0; g < 4; ++g) axp[g] = wxp + (size_t)((g * H + u0) >> 4) * IPS * 1024 + lane * 8;
+        for (int g = 0; g < 4; ++g) axp[g] = wxp + (size_t)((g * H + u0) >> 4) * IPS * 1024;
         const float* xr[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) xr[c] = x + ((size_t)nrow[c] * T + t) * I + 8 * kq;
-        f16x8 a[2][4][2];
-        float4 xv[2][NC][2];
+        constexpr int DEPTH = IPS >= 2 ? 2 : 1;        // deeper / pinned was slower here (layer 2: 40.4 against 34.2 us): the
+        f16x8 a[DEPTH][4][2];                          // split arithmetic wants to slide between the neighbouring slabs' MFMAs
+        float4 xv[DEPTH][NC][2];
         auto fetch = [&](int s, int buf) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { a[buf][g][0] = ldh8(axp[g] + 1024 * s); a[buf][g][1] = ldh8(axp[g] + 1024 * s + 512); }
+            for (int g = 0; g < 4; ++g) { a[buf][g][0] = ldh8(axp[g] + (1024 * s + lo)); a[buf][g][1] = ldh8(axp[g] + (1024 * s + 512 + lo)); }
             const int k0 = 32 * s + 8 * kq;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -247,11 +261,12 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
                 }
             }
         };
-        fetch(0, 0);
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1 || d == 0; ++d) fetch(d, d);
 #pragma unroll
         for (int s = 0; s < IPS; ++s) {
-            const int cur = s & 1;
-            if (s + 1 < IPS) fetch(s + 1, cur ^ 1);
+            const int cur = s % DEPTH;
+            if (DEPTH > 1 && s + DEPTH - 1 < IPS) fetch(s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
             f16x8 b[NC][2];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -270,6 +285,9 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         (void)IP;
     }
     // ---- cell (gen_cell_fwd's arithmetic) and outputs
+#if STEP_ABL == 3
+    if (acc[0][0][0] == 123.456f)
+#endif
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int n = e0 + 16 * c + r16;
@@ -408,7 +426,7 @@ __global__ __launch_bounds__(512) void step_bwd_h3_kernel(const unsigned short* 
                                                           const unsigned short* __restrict__ dgp,
                                                           const float* __restrict__ inv_scale, int N,
                                                           float* __restrict__ dh) {
-    constexpr int K = 4 * H, NS = K / 32, DEPTH = 4, NC = 2;
+    constexpr int K = 4 * H, NS = K / 32, DEPTH = 8, NC = 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int e0 = blockIdx.x * 64 + 32 * (w >> 2), u0 = blockIdx.y * 64 + 16 * (w & 3);
@@ -435,6 +453,9 @@ __global__ __launch_bounds__(512) void step_bwd_h3_kernel(const unsigned short* 
 #pragma unroll
             for (int c = 0; c < NC; ++c) { b[nxt][c][0] = ldh8(bp[c] + 1024 * sn); b[nxt][c][1] = ldh8(bp[c] + 1024 * sn + 512); }
         }
+        // pin the loads HERE: left alone the scheduler sinks them next to their uses (56 VGPRs, one slab in flight) and the
+        // kernel runs at the L2 latency per slab
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][1], b[cur][c][0], acl[c], 0, 0, 0);
