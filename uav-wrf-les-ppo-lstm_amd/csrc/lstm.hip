@@ -33,6 +33,8 @@ int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int6
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st);
 int colsum_absmax(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, unsigned* absmax_bits,
                   hipStream_t st);
+int colsum_xw(uav_ctx* ctx, const float* X, int64_t B, int C, const float* x, int I, float* colsum_out, float* xw_out,
+              float* scratch, unsigned* absmax_bits, hipStream_t st);
 bool gemm_h3_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B, int64_t sb_k,
                 int64_t sb_n);
 int gemm_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
@@ -2021,7 +2023,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
     } else {
         // generic path: column sums use the tail of the workspace, the split-K slabs everything in front of it
         UAV_REQUIRE(stash, "uav_lstm_wgrad: stash is required when I > 6");
-        const size_t red_floats = (size_t)1024 * 4 * H + 64;          // colsum partials + the word for max |dG|
+        const size_t red_floats = (size_t)1024 * 9 * 4 * H + 64;      // colsum (+ dG^T x) partials + the word for max |dG|
         UAV_REQUIRE(ctx->ws_bytes >= red_floats * sizeof(float) * 2, "uav_lstm_wgrad: workspace too small");
         float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
         uav_ctx sub = *ctx;
@@ -2032,8 +2034,12 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         // under the same preconditions as the sequence kernels' (include/uavppo.h, uav_set_lstm_arith).
         const bool h3 = !uav_want_f32_mfma() && !uav_want_bf16x6() && (4 * H) % 4 == 0 &&
                         (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
-        unsigned* amax = h3 ? reinterpret_cast<unsigned*>(red + (size_t)1024 * 4 * H) : nullptr;
-        if ((rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st))) return rc;
+        unsigned* amax = h3 ? reinterpret_cast<unsigned*>(red + (size_t)1024 * 9 * 4 * H) : nullptr;
+        // a narrow input (layer 1: obs + trend, I <= 8): dW_ih = dG^T x rides on the bias gradient's pass over dG
+        const bool narrow = I <= 8 && (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
+        if (narrow) rc = colsum_xw(&sub, dgates, NT, 4 * H, x, I, db, dw_ih, red, amax, st);
+        else rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st);
+        if (rc) return rc;
         auto product = [&](int64_t M, int64_t Nn, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
                            int64_t sb_k, int64_t sb_n, float* C, int64_t ldc) {
             if (h3 && gemm_h3_ok(M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n))
@@ -2041,7 +2047,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
             return gemm_f32(&sub, M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, nullptr, 0, st);
         };
         if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H))) return rc;
-        if ((rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
+        if (!narrow && (rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
         if (dheads && (rc = gemm_f32(&sub, n_heads, H, NT, dheads, 1, n_heads, y, H, 1, dw_head, H, nullptr, 0, st))) return rc;
         if (dx) return product(NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I);
         return 0;

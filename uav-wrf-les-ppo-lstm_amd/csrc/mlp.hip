@@ -202,6 +202,85 @@ __global__ __launch_bounds__(256) void colsum_partial4_kernel(const float* __res
     }
 }
 
+// colsum_partial4_kernel<true> that ALSO accumulates X^T x for a narrow second operand x [B][I], I <= 8 (exact f32 FMAs):
+// the layer-1 input weight gradient dW_ih = dG^T x of a wide LSTM (4H x 8) rides on the pass that reads dG for the bias
+// gradient instead of costing a 3 ms thin GEMM of its own.  partial [block][1 + 8][C]; x rows are wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void colsum_xw_partial_kernel(const float* __restrict__ X, int64_t B, int C,
+                                                                int64_t rows_per_block, const float* __restrict__ x, int I,
+                                                                float* __restrict__ partial, unsigned* __restrict__ absmax_bits) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < B) ? r0 + rows_per_block : B;
+    unsigned mb = 0;
+    for (int c = 4 * threadIdx.x; c < C; c += 1024) {
+        float4 a = {0.f, 0.f, 0.f, 0.f}, w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = float4{0.f, 0.f, 0.f, 0.f};
+        auto row = [&](const float4& v, int64_t r) {
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            const unsigned b0 = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b1 = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+            const unsigned b2 = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, b3 = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+            const unsigned m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3, m4 = m01 > m23 ? m01 : m23;
+            mb = mb > m4 ? mb : m4;
+            const float* xr = x + r * I;                 // uniform
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xj = j < I ? xr[j] : 0.f;
+                w[j].x = fmaf(v.x, xj, w[j].x); w[j].y = fmaf(v.y, xj, w[j].y);
+                w[j].z = fmaf(v.z, xj, w[j].z); w[j].w = fmaf(v.w, xj, w[j].w);
+            }
+        };
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float4*>(X + (r + k) * C + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) row(v[k], r + k);
+        }
+        for (; r < r1; ++r) row(*reinterpret_cast<const float4*>(X + r * C + c), r);
+        float* pp = partial + (int64_t)blockIdx.x * 9 * C + c;
+        *reinterpret_cast<float4*>(pp) = a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(pp + (int64_t)(1 + j) * C) = w[j];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)mb, o, 64);
+        mb = mb > t ? mb : t;
+    }
+    if (absmax_bits && (threadIdx.x & 63) == 0 && mb) atomicMax(absmax_bits, mb);
+}
+// partial [nb][9][C] -> colsum [C] and xw [C][I] (= X^T x, row-major like dW_ih), fixed association
+__global__ __launch_bounds__(256) void colsum_xw_reduce_kernel(const float* __restrict__ partial, int nb, int C, int I,
+                                                               float* __restrict__ colsum_out, float* __restrict__ xw_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;         // over (1 + I) * C
+    if (i >= (1 + I) * C) return;
+    const int q = i / C, c = i % C;
+    float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nb; b += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p8[k] += partial[((int64_t)(b + k) * 9 + q) * C + c];
+    for (; b < nb; ++b) p8[0] += partial[((int64_t)b * 9 + q) * C + c];
+    const float s = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+    if (q == 0) colsum_out[c] = s;
+    else xw_out[(int64_t)c * I + (q - 1)] = s;
+}
+// colsum of X [B][C] + X^T x for x [B][I], I <= 8, C % 4 == 0, X 16-byte aligned; scratch >= 1024 * 9 * C floats
+int colsum_xw(uav_ctx* ctx, const float* X, int64_t B, int C, const float* x, int I, float* colsum_out, float* xw_out,
+              float* scratch, unsigned* absmax_bits, hipStream_t st) {
+    UAV_REQUIRE(I >= 1 && I <= 8 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, "colsum_xw: I <= 8, cols %% 4 == 0, aligned X");
+    int nb = (int)((B + 255) / 256);
+    if (nb > 1024) nb = 1024;
+    const int64_t rpb = (B + nb - 1) / nb;
+    nb = (int)((B + rpb - 1) / rpb);
+    if (absmax_bits) UAV_CHECK_HIP(hipMemsetAsync(absmax_bits, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(colsum_xw_partial_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, x, I, scratch, absmax_bits);
+    hipLaunchKernelGGL(colsum_xw_reduce_kernel, dim3(((1 + I) * C + 255) / 256), dim3(256), 0, st, scratch, nb, C, I, colsum_out, xw_out);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
 int colsum_absmax(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, unsigned* absmax_bits,
                   hipStream_t st);
 int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, hipStream_t st) {
