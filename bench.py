@@ -257,13 +257,20 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     barrier()
     t0 = time.perf_counter()
+    verbose = os.environ.get("UAV_BENCH_VERBOSE")
+    if verbose == "trace":
+        import faulthandler
+        faulthandler.dump_traceback_later(2.0, repeat=True, file=sys.stderr)
     for k in range(steps):
+        tk = time.perf_counter()
         ev[k][0].record()
         tr.collect()
         ev[k][1].record()
         tr.update()
         tr.update_curriculum()      # the iteration's one host sync (success bits; the range guard's max |param| rides along)
         tr.iteration += 1
+        if verbose:
+            print(f"[bench] step {k}: host {1e3 * (time.perf_counter() - tk):.1f} ms", file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
