@@ -233,9 +233,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *c = (accumulate ? *c : 0.f) + s + (bias ? bias[col] : 0.f);
 }
 
+// ---- a few output columns (policy heads: N = A + 1 <= 8) of a short inner product (K <= 512): C[m][j] = A[m][:] . W[j][:] + b[j].
+// No MFMA tile pays here (a 64 x 64 tile would compute 58 unused columns and needs split-K + a reduce launch to fill the
+// chip: 18.6 us per call at 4096 x 6 x 256); one WAVE per row instead: lane l holds 4 (or 8) consecutive k of the row and
+// of every W row (registers), NO butterfly sums.  HBM-bound on A for long M (the time-batched heads of uav_lstm_fwd).
+template <int NO, int KQ>     // KQ = float4 chunks per lane (K <= 256 KQ)
+__global__ __launch_bounds__(256) void rows_dot_kernel(int64_t M, int K, const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ W, int64_t ldw, int n_out, float* __restrict__ C,
+                                                       int64_t ldc, const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63;
+    float4 wv[NO][KQ];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            const int k = 4 * (lane + 64 * q);
+            wv[o][q] = (o < n_out && k < K) ? *reinterpret_cast<const float4*>(W + o * ldw + k) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    const float bv = (bias && lane < n_out) ? bias[lane] : 0.f;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+    // four rows per trip: their loads are in flight together (a long M is a stream from HBM, one row per trip would run
+    // at the memory latency)
+    for (int64_t m0 = wave * 4; m0 < M; m0 += nwave * 4) {
+        float4 av[4][KQ];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                const int k = 4 * (lane + 64 * q);
+                av[r][q] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4*>(A + (m0 + r) * lda + k) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mine = 0.f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                float p = 0.f;
+#pragma unroll
+                for (int q = 0; q < KQ; ++q)
+                    p += (av[r][q].x * wv[o][q].x + av[r][q].y * wv[o][q].y) + (av[r][q].z * wv[o][q].z + av[r][q].w * wv[o][q].w);
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) p += __shfl_xor(p, d, 64);
+                if (lane == o) mine = p;
+            }
+            if (m0 + r < M && lane < n_out) C[(m0 + r) * ldc + lane] = mine + bv;
+        }
+    }
+}
+
 int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
              const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
              int accumulate, hipStream_t st) {
+    // the few-columns form (see rows_dot_kernel): NT operands with contiguous k, 16-byte aligned rows
+    if (ctx && A && B && C && N >= 1 && N <= 8 && K >= 4 && K <= 512 && K % 4 == 0 && sa_k == 1 && sb_k == 1 && !accumulate && M >= 1 &&
+        sa_m % 4 == 0 && sb_n % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0) {
+        int64_t nb = (M + 15) / 16;                                     // 4 waves x 4 rows per trip
+        if (nb > 8 * ctx->num_cu) nb = 8 * ctx->num_cu;
+        if (K <= 256)
+            hipLaunchKernelGGL((rows_dot_kernel<8, 1>), dim3((unsigned)nb), dim3(256), 0, st, M, (int)K, A, sa_m, B, sb_n, (int)N, C, ldc, bias);
+        else
+            hipLaunchKernelGGL((rows_dot_kernel<8, 2>), dim3((unsigned)nb), dim3(256), 0, st, M, (int)K, A, sa_m, B, sb_n, (int)N, C, ldc, bias);
+        UAV_LAUNCH_CHECK();
+        return 0;
+    }
     UAV_REQUIRE(ctx && A && B && C && M > 0 && N > 0 && K > 0, "uav_gemm_f32: bad argument");
     const bool big = (M >= 128 && N >= 128);          // 128x128 tile for the large shapes
     const int bm = big ? BM2 : BM, bn = big ? BN2 : BN;
