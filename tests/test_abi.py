@@ -67,3 +67,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() compiles the library (a no-op when it is current), the oracle's
+    restatement, and asserts the ABI version the header declares."""
+    import importlib
+    import re
+    g = importlib.import_module("__graft_entry__")
+    g.build()
+    header = open(os.path.join(ROOT, "include", "uavppo.h")).read()
+    declared = int(re.search(r"#define UAV_ABI_VERSION (\d+)", header).group(1))
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert f"uav_abi_version() == {declared}" in src
