@@ -163,15 +163,17 @@ int uav_mse_bce(uav_ctx* ctx, const float* out, const float* target, int64_t n, 
  * the caller-owned `state` buffer (uav_lstm_stepper_bytes(N, I, H) bytes, 256-byte aligned; 0 = shape not supported),
  * and y / stash are the [N][T][H] / [N][T][6H] arrays uav_lstm_bwd reads, filled at time index t.
  *   begin  splits the weights, sets the state to (h0, c0) [N][H]
- *   step   x [N][T][I] (row t read), writes y[:, t], stash[:, t]; at t == T-1 also hn, cn [N][H] (required pointers)
+ *   step   x [N][T][I] (row t read), writes y[:, t], stash[:, t]; at t == T-1 also hn, cn [N][H] (required pointers).
+ *          below: NULL, or the stepper state of the layer below (same N, hidden 256 = this I) already stepped to t: its
+ *          h_t is then read from that state's piece planes instead of x (same values: x must still be its y array)
  *   mask   state *= keep_next[n] after step t (t = -1: the initial state): nn.LSTM has no such mask -- it is how the
  *          vectorised rollout restarts the recurrent state where an episode ended (train_ppo2.0.py:157-198 runs one
  *          episode at a time and never carries state across). */
 size_t uav_lstm_stepper_bytes(int N, int I, int H);
 int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const float* w_hh, const float* b_ih,
                            const float* b_hh, const float* h0, const float* c0, int N, int I, int H, uav_stream stream);
-int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, int N, int T, int t, int I, int H, float* y,
-                          float* stash, float* hn, float* cn, uav_stream stream);
+int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, int N, int T, int t, int I, int H,
+                          float* y, float* stash, float* hn, float* cn, uav_stream stream);
 int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, int N, int t, int I, int H,
                           uav_stream stream);
 

@@ -1,5 +1,7 @@
 """HIP LSTM sequence kernels vs torch.nn.LSTM (CPU, the module the reference uses:
 PPOV2.0/model.py:206-212, PPOV2.1/model.py:263) and the oracle's episode-reset variant.  -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -395,3 +397,42 @@ def test_lstm_stepper_refuses_other_shapes(ops):
         ops.LstmStepper(16, 6, 128, DEV)
     with pytest.raises(RuntimeError, match="not supported"):
         ops.LstmStepper(16, 300, 256, DEV)
+
+
+def test_lstm_stepper_two_layers_through_piece_planes(ops):
+    """Layer 2 of a stepped stack reads layer 1's h_t from its piece planes (`below`) instead of the f32 y rows; the
+    sequence call converts its wide input to piece planes a chunk of steps at a time: both BIT-identical to each other
+    and to the f32-input kernel (UAV_LSTM_X_F32=1 is the A/B switch of the sequence driver)."""
+    H, N, T, I = 256, 80, 19, 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, T, I, generator=g).to(DEV)
+    keep = (torch.rand(N, T, generator=g) > 0.2).float()
+    keep[:, 0] = 1.0
+    keep = keep.to(DEV)
+    mk = lambda *shape: (torch.randn(*shape, generator=g) * 0.1).to(DEV)
+    W = [(mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)), (mk(4 * H, H), mk(4 * H, H), mk(4 * H), mk(4 * H))]
+    h0, c0 = [mk(N, H), mk(N, H)], [mk(N, H), mk(N, H)]
+    # sequence: layer 1 then layer 2 (chunked piece conversion of y1)
+    y1, _, _, st1 = ops.lstm_fwd(x, keep, h0[0], c0[0], *W[0])
+    y2, hn2, cn2, st2 = ops.lstm_fwd(y1, keep, h0[1], c0[1], *W[1])
+    os.environ["UAV_LSTM_X_F32"] = "1"
+    try:
+        y2f, _, _, st2f = ops.lstm_fwd(y1, keep, h0[1], c0[1], *W[1])
+    finally:
+        del os.environ["UAV_LSTM_X_F32"]
+    assert torch.equal(y2, y2f) and torch.equal(st2, st2f)
+    # stepped: both layers per time step, layer 2 fed from layer 1's piece planes
+    sp = [ops.LstmStepper(N, I, H, DEV), ops.LstmStepper(N, H, H, DEV)]
+    for l in range(2):
+        sp[l].begin(*W[l], h0[l], c0[l])
+    ys = [torch.zeros(N, T, H, device=DEV) for _ in range(2)]
+    ss = [torch.zeros(N, T, 6 * H, device=DEV) for _ in range(2)]
+    for t in range(T):
+        sp[0].step(x, t, ys[0], ss[0])
+        sp[1].step(ys[0], t, ys[1], ss[1], below=sp[0])
+        if t < T - 1:
+            for l in range(2):
+                sp[l].mask(t, keep[:, t + 1].contiguous())
+    assert torch.equal(ys[0], y1) and torch.equal(ss[0], st1)
+    assert torch.equal(ys[1], y2) and torch.equal(ss[1], st2)
+    assert torch.equal(sp[1].hn, hn2) and torch.equal(sp[1].cn, cn2)

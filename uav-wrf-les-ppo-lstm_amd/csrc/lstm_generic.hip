@@ -155,6 +155,7 @@ template <int H, int IPS>
 __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp,
                                                           const unsigned short* __restrict__ wp,
                                                           const float* __restrict__ bsum, const float* __restrict__ x, int I,
+                                                          const unsigned short* __restrict__ xp, int last_pieces,
                                                           const unsigned short* __restrict__ hp_in,
                                                           unsigned short* __restrict__ hp_out, float* __restrict__ hs,
                                                           float* __restrict__ cs, float* __restrict__ stash,
@@ -196,6 +197,51 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
                 acl[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[g][0], b[c][1], acl[g][c], 0, 0, 0);
             }
     };
+    if (xp) {
+        // ---- input given as piece planes (xp: x_t already split, fragment order with K = 32 IPS -- the layer below's state
+        // planes in a step-wise rollout, or a chunk converted by split_x_kernel in the sequence driver): ONE ring over the
+        // NS recurrent and IPS input slabs, coalesced 1 KB chunk loads, no split arithmetic, no f32 row gathers
+        const unsigned short* ap[4];
+        const unsigned short* axp[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ap[g] = wp + (size_t)((g * H + u0) >> 4) * NS * 1024;
+            axp[g] = wxp + (size_t)((g * H + u0) >> 4) * IPS * 1024;
+        }
+        const unsigned short* bp[NC];
+        const unsigned short* bxp[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            bp[c] = hp_in + (size_t)((e0 + 16 * c) >> 4) * NS * 1024;
+            bxp[c] = xp + (size_t)((e0 + 16 * c) >> 4) * IPS * 1024;
+        }
+        constexpr int DEPTH = 3, NSL = NS + IPS;
+        f16x8 a[DEPTH][4][2], b[DEPTH][NC][2];
+        auto fetch = [&](int s, int buf) {
+            const bool rec = s < NS;
+            const int q = rec ? s : s - NS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned short* p = rec ? ap[g] : axp[g];
+                a[buf][g][0] = ldh8(p + (1024 * q + lo));
+                a[buf][g][1] = ldh8(p + (1024 * q + 512 + lo));
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned short* p = rec ? bp[c] : bxp[c];
+                b[buf][c][0] = ldh8(p + (1024 * q + lo));
+                b[buf][c][1] = ldh8(p + (1024 * q + 512 + lo));
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) fetch(d, d);
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            if (s + DEPTH - 1 < NSL) fetch(s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(a[s % DEPTH], b[s % DEPTH]);
+        }
+    } else {
     // ---- recurrent product, K = H, double-buffered slabs
     {
         const unsigned short* ap[4];                   // fragment order (frag_index): 1 KB per wave-wide load
@@ -284,6 +330,7 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         }
         (void)IP;
     }
+    }
     // ---- cell (gen_cell_fwd's arithmetic) and outputs
 #if STEP_ABL == 3
     if (acc[0][0][0] == 123.456f)
@@ -316,8 +363,9 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         if (t == T - 1) {
             *reinterpret_cast<float4*>(hn + i0) = float4{hh[0], hh[1], hh[2], hh[3]};
             *reinterpret_cast<float4*>(cn + i0) = float4{cc[0], cc[1], cc[2], cc[3]};
-        } else {
-            const float kn = keep ? keep[row + 1] : 1.f;
+        }
+        if (t < T - 1 || last_pieces) {             // last_pieces: the layer above reads this step's h from the piece planes
+            const float kn = (keep && t < T - 1) ? keep[row + 1] : 1.f;
             unsigned short q0[4], q1[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -473,6 +521,33 @@ __global__ __launch_bounds__(512) void step_bwd_h3_kernel(const unsigned short* 
     }
 }
 
+// x[:, t0 .. t0 + tc) f32 [N][T][I] -> per step the two fp16 piece planes of x_t in fragment order (K = IP): a wave = one
+// 16-row tile x one 32-k slab, lane (kq, r16) converts 8 consecutive k of row r16 and stores 16 bytes per piece -- every
+// wave store is one whole 1 KB chunk.  out[(t - t0)][frag_index(n, k, IP, piece)], rows >= N and k >= I zero.
+__global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ x, int N, int T, int I, int IP, int t0, int tc,
+                                                      unsigned short* __restrict__ out) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, kq = lane >> 4;
+    const int IPS = IP / 32, ntile = (N + 63) / 64 * 4;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t per_step = (int64_t)ntile * IPS;
+    if (wave >= per_step * tc) return;
+    const int tt = (int)(wave / per_step), rem = (int)(wave % per_step), tile = rem / IPS, s = rem % IPS;
+    const int n = tile * 16 + r16, k0 = 32 * s + 8 * kq;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (n < N && k0 + i < I) ? x[((size_t)n * T + t0 + tt) * I + k0 + i] : 0.f;
+    f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        _Float16 p0, p1;
+        split2h(v[i], p0, p1);
+        a[i] = p0; b[i] = p1;
+    }
+    unsigned short* o = out + (size_t)tt * 2 * ntile * 16 * IP + ((size_t)(tile * IPS + s) * 2) * 512 + lane * 8;
+    *reinterpret_cast<f16x8*>(o) = a;
+    *reinterpret_cast<f16x8*>(o + 512) = b;
+}
+
 static bool h3_step_ok(int H) { return H == 256 && !uav_want_f32_mfma() && !getenv("UAV_LSTM_STEP_F32"); }
 
 // fp16-split step path of uav_lstm_fwd for h = 256 (input projection included: the caller does NOT pre-fill the stash)
@@ -504,9 +579,30 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
     hipLaunchKernelGGL(add2v_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, b_ih, b_hh, bsum, 4 * H);
     hipLaunchKernelGGL(h3_init_state, dim3(nb), dim3(256), 0, st, h0, c0, keep, N, T, H, hs, cs, hp0);
     const dim3 grid((N + 63) / 64, H / 64);
-    for (int t = 0; t < T; ++t)
-#define LAUNCH_STEP(IPS_)                                                                                              \
-    hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, (t & 1) ? hp1 : hp0, \
+    // a wide input (the layer below's output, I = 64 .. 256): x is converted to piece planes a chunk of time steps at a
+    // time (split_x_kernel, in front of the state in the workspace), so the step kernel's input projection streams
+    // 1 KB fragment chunks like its recurrent product instead of gathering f32 rows and splitting them in every workgroup
+    const int ntile = (N + 63) / 64 * 4;
+    const size_t x_step = (size_t)ntile * (IP / 32) * 1024 * 2;            // bytes of one step's planes
+    int TC = 0;
+    if (I == IP && I >= 64 && !getenv("UAV_LSTM_X_F32")) {
+        const size_t room = ctx->ws_bytes - need - (64u << 20);
+        TC = (int)(room / x_step < 16 ? room / x_step : 16);
+    }
+    unsigned short* xbuf = TC > 0 ? (unsigned short*)(base - (size_t)TC * x_step) : nullptr;
+    for (int t = 0; t < T; ++t) {
+        const unsigned short* xp = nullptr;
+        if (TC > 0) {
+            const int t0 = t / TC * TC;
+            if (t == t0) {
+                const int tc = T - t0 < TC ? T - t0 : TC;
+                const int64_t waves = (int64_t)ntile * (IP / 32) * tc;
+                hipLaunchKernelGGL(split_x_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, N, T, I, IP, t0, tc, xbuf);
+            }
+            xp = xbuf + (size_t)(t - t0) * (x_step / 2);
+        }
+#define LAUNCH_STEP(IPS_)                                                                                                    \
+    hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, xp, 0, (t & 1) ? hp1 : hp0, \
                        (t & 1) ? hp0 : hp1, hs, cs, stash, keep, N, T, t, y, hn, cn)
         switch (IP / 32) {
             case 1: LAUNCH_STEP(1); break;
@@ -515,6 +611,7 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
             default: LAUNCH_STEP(8); break;
         }
 #undef LAUNCH_STEP
+    }
     UAV_LAUNCH_CHECK();
     return 0;
 }
@@ -588,8 +685,8 @@ int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const f
     return 0;
 }
 
-int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, int N, int T, int t, int I, int H, float* y, float* stash,
-                          float* hn, float* cn, uav_stream stream) {
+int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, int N, int T, int t, int I, int H,
+                          float* y, float* stash, float* hn, float* cn, uav_stream stream) {
     UAV_REQUIRE(ctx && state && x && y && stash && hn && cn, "uav_lstm_stepper_step: NULL argument");
     UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && T > 0 && t >= 0 && t < T, "uav_lstm_stepper_step: bad shape (N=%d T=%d t=%d I=%d H=%d)", N, T, t, I, H);
     g_uav_arith = ctx->lstm_arith;
@@ -605,8 +702,16 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, int N, int 
     float* hs = (float*)(b + L.hs);
     float* cs = (float*)(b + L.cs);
     const dim3 grid((N + 63) / 64, 256 / 64);
+    // `below`: the stepper state of the layer below (same N, its H = this I = 256), already stepped to t: its piece
+    // planes of h_t (parity (t + 1) & 1, not yet masked) ARE this layer's input in fragment order
+    const unsigned short* xp = nullptr;
+    if (below) {
+        UAV_REQUIRE(I == 256, "uav_lstm_stepper_step: `below` needs I = 256 (the layer below's hidden size), got %d", I);
+        const StepperLayout LB = stepper_layout(N, 8);        // hp0 / hp1 offsets do not depend on the input width
+        xp = (const unsigned short*)((const char*)below + (((t + 1) & 1) ? LB.hp1 : LB.hp0));
+    }
 #define LAUNCH_STEP(IPS_)                                                                                                     \
-    hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, (t & 1) ? hp1 : hp0,     \
+    hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, xp, 1, (t & 1) ? hp1 : hp0, \
                        (t & 1) ? hp0 : hp1, hs, cs, stash, (const float*)nullptr, N, T, t, y, hn, cn)
     switch (L.IP / 32) {
         case 1: LAUNCH_STEP(1); break;

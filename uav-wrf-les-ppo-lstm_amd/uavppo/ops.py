@@ -448,10 +448,13 @@ class LstmStepper:
                                            _p(b_hh, F32, (4 * H,), "b_hh"), _p(h0, F32, (N, H), "h0"), _p(c0, F32, (N, H), "c0"),
                                            N, I, H, _stream()), "uav_lstm_stepper_begin")
 
-    def step(self, x, t, y, stash):
+    def step(self, x, t, y, stash, below=None):
+        """below: the LstmStepper of the layer below, already stepped to t (x is then its y array: the kernel reads h_t from
+        that stepper's piece planes instead of gathering and splitting f32 rows)."""
         N, I, H = self.N, self.I, self.H
         T = x.shape[1]
-        check(lib().uav_lstm_stepper_step(_h(self.state), _p(self.state), _p(x, F32, (N, T, I), "x"), N, T, int(t), I, H,
+        check(lib().uav_lstm_stepper_step(_h(self.state), _p(self.state), _p(x, F32, (N, T, I), "x"),
+                                          None if below is None else _p(below.state), N, T, int(t), I, H,
                                           _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"), _p(self.hn),
                                           _p(self.cn), _stream()), "uav_lstm_stepper_step")
 

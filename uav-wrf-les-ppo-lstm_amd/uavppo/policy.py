@@ -216,7 +216,7 @@ class LSTMActorCritic(_FlatPolicy):
         work['y{l}'], work['stash{l}'] filled at t); heads_seq [N, T, A+1] row t = actor / critic rows of the top layer."""
         x = obs_seq
         for l, sp in enumerate(self._steppers):
-            sp.step(x, t, work[f"y{l}"], work[f"stash{l}"])
+            sp.step(x, t, work[f"y{l}"], work[f"stash{l}"], below=self._steppers[l - 1] if l > 0 and self.hidden == 256 else None)
             x = work[f"y{l}"]
         v = self.views
         return ops.gemm_rows(x[:, t], v["head.weight"], v["head.bias"], heads_seq[:, t])
