@@ -378,7 +378,7 @@ def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     for t in range(T):
         sp.step(x, t, y, stash)
         if t < T - 1:
-            sp.mask(t, keep[:, t + 1].contiguous())
+            sp.mask(t, keep[:, t + 1].contiguous(), stash)
     assert torch.equal(y, y_ref) and torch.equal(stash, stash_ref)
     assert torch.equal(sp.hn, hn_ref) and torch.equal(sp.cn, cn_ref)
     # a second rollout from the handed-over state: begin() again, mask of the initial state through t = -1
@@ -432,7 +432,7 @@ def test_lstm_stepper_two_layers_through_piece_planes(ops):
         sp[1].step(ys[0], t, ys[1], ss[1], below=sp[0])
         if t < T - 1:
             for l in range(2):
-                sp[l].mask(t, keep[:, t + 1].contiguous())
+                sp[l].mask(t, keep[:, t + 1].contiguous(), ss[l])
     assert torch.equal(ys[0], y1) and torch.equal(ss[0], st1)
     assert torch.equal(ys[1], y2) and torch.equal(ss[1], st2)
     assert torch.equal(sp[1].hn, hn2) and torch.equal(sp[1].cn, cn2)

@@ -341,7 +341,11 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         if (n >= N) continue;
         const size_t row = (size_t)n * T + t, i0 = (size_t)n * H + u0 + 4 * kq;
         float* sp = stash + row * (6 * H) + u0 + 4 * kq;
-        const float4 cp4 = *reinterpret_cast<const float4*>(cs + i0), hp4 = *reinterpret_cast<const float4*>(hs + i0);
+        // the state entering step t: from (hs, cs) at t = 0, afterwards from this row's own c_prev | h_prev slots, where
+        // step t - 1 left it (the state travels through the stash rows the BPTT needs anyway: no separate f32 state
+        // array is written and read back on every step)
+        const float4 cp4 = *reinterpret_cast<const float4*>(t == 0 ? cs + i0 : sp + 4 * H);
+        const float4 hp4 = *reinterpret_cast<const float4*>(t == 0 ? hs + i0 : sp + 5 * H);
         const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
         float gi[4], gf[4], gg[4], go[4], cc[4], hh[4];
 #pragma unroll
@@ -357,8 +361,10 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
         *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
         *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
         *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
-        *reinterpret_cast<float4*>(sp + 4 * H) = cp4;
-        *reinterpret_cast<float4*>(sp + 5 * H) = hp4;
+        if (t == 0) {
+            *reinterpret_cast<float4*>(sp + 4 * H) = cp4;
+            *reinterpret_cast<float4*>(sp + 5 * H) = hp4;
+        }
         *reinterpret_cast<float4*>(y + row * H + u0 + 4 * kq) = float4{hh[0], hh[1], hh[2], hh[3]};
         if (t == T - 1) {
             *reinterpret_cast<float4*>(hn + i0) = float4{hh[0], hh[1], hh[2], hh[3]};
@@ -376,8 +382,10 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
                 q0[r] = h_bits(p0);
                 q1[r] = h_bits(p1);
             }
-            *reinterpret_cast<float4*>(hs + i0) = float4{hh[0], hh[1], hh[2], hh[3]};
-            *reinterpret_cast<float4*>(cs + i0) = float4{cc[0], cc[1], cc[2], cc[3]};
+            if (t < T - 1) {                           // masked state -> the next row's c_prev | h_prev slots
+                *reinterpret_cast<float4*>(sp + 6 * H + 4 * H) = float4{cc[0], cc[1], cc[2], cc[3]};
+                *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hh[0], hh[1], hh[2], hh[3]};
+            }
             uint2 v0, v1;
             v0.x = (unsigned)q0[0] | ((unsigned)q0[1] << 16); v0.y = (unsigned)q0[2] | ((unsigned)q0[3] << 16);
             v1.x = (unsigned)q1[0] | ((unsigned)q1[1] << 16); v1.y = (unsigned)q1[2] | ((unsigned)q1[3] << 16);
@@ -643,14 +651,15 @@ static StepperLayout stepper_layout(int N, int I) {
 
 // state <- state * keep[n] (f32 and pieces): the mask of the step about to run, known only after the environment step
 __global__ void h3_mask_state(const float* __restrict__ keep, int N, int H, float* __restrict__ hs, float* __restrict__ cs,
-                              unsigned short* __restrict__ hp) {
+                              int64_t row_stride, unsigned short* __restrict__ hp) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)N * H) return;
     const int n = (int)(i / H), u = (int)(i % H);
     const float k = keep[n];
-    const float h = hs[i] * k;
-    hs[i] = h;
-    cs[i] *= k;
+    const int64_t o = (int64_t)n * row_stride + u;      // (hs, cs) [N][H] (row_stride = H) or the c_prev | h_prev slots of a stash row
+    const float h = hs[o] * k;
+    hs[o] = h;
+    cs[o] *= k;
     _Float16 p0, p1;
     split2h(h, p0, p1);
     hp[frag_index(n, u, H, 0)] = h_bits(p0);
@@ -724,15 +733,20 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
     return 0;
 }
 
-int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, int N, int t, int I, int H, uav_stream stream) {
+int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, float* stash, int N, int T, int t, int I, int H,
+                          uav_stream stream) {
     UAV_REQUIRE(ctx && state && keep_next, "uav_lstm_stepper_mask: NULL argument");
-    UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && t >= -1, "uav_lstm_stepper_mask: bad shape (N=%d t=%d I=%d H=%d)", N, t, I, H);
+    UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && t >= -1 && (t == -1 || (stash && t < T - 1)),
+                "uav_lstm_stepper_mask: bad argument (N=%d T=%d t=%d I=%d H=%d; stash is required for t >= 0, t < T-1)", N, T, t, I, H);
     const StepperLayout L = stepper_layout(N, I);
     char* b = (char*)state;
     // step t wrote the state of step t + 1 into the piece planes of parity (t + 1) & 1
     unsigned short* hp = (unsigned short*)(b + (((t + 1) & 1) ? L.hp1 : L.hp0));
+    // step t left the state of step t + 1 in row t + 1 of the stash (c_prev | h_prev slots); the initial state is (hs, cs)
+    float* hsp = t < 0 ? (float*)(b + L.hs) : stash + (size_t)(t + 1) * 6 * H + 5 * H;
+    float* csp = t < 0 ? (float*)(b + L.cs) : stash + (size_t)(t + 1) * 6 * H + 4 * H;
     hipLaunchKernelGGL(h3_mask_state, dim3((unsigned)(((int64_t)N * H + 255) / 256)), dim3(256), 0, as_stream(stream), keep_next, N, H,
-                       (float*)(b + L.hs), (float*)(b + L.cs), hp);
+                       hsp, csp, t < 0 ? (int64_t)H : (int64_t)T * 6 * H, hp);
     UAV_LAUNCH_CHECK();
     return 0;
 }

@@ -458,8 +458,11 @@ class LstmStepper:
                                           _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"), _p(self.hn),
                                           _p(self.cn), _stream()), "uav_lstm_stepper_step")
 
-    def mask(self, t, keep_next):
-        check(lib().uav_lstm_stepper_mask(_h(self.state), _p(self.state), _p(keep_next, F32, (self.N,), "keep_next"), self.N,
+    def mask(self, t, keep_next, stash=None):
+        """stash: the [N, T, 6H] array the steps write (the state of step t + 1 lives in its row t + 1); None only for t = -1."""
+        T = 0 if stash is None else stash.shape[1]
+        check(lib().uav_lstm_stepper_mask(_h(self.state), _p(self.state), _p(keep_next, F32, (self.N,), "keep_next"),
+                                          _p(stash, F32, None if stash is None else (self.N, T, 6 * self.H), "stash"), self.N, T,
                                           int(t), self.I, self.H, _stream()), "uav_lstm_stepper_mask")
 
 

@@ -221,9 +221,9 @@ class LSTMActorCritic(_FlatPolicy):
         v = self.views
         return ops.gemm_rows(x[:, t], v["head.weight"], v["head.bias"], heads_seq[:, t])
 
-    def mask_steps(self, t, keep_next):
-        for sp in self._steppers:
-            sp.mask(t, keep_next)
+    def mask_steps(self, t, keep_next, work):
+        for l, sp in enumerate(self._steppers):
+            sp.mask(t, keep_next, work[f"stash{l}"])
 
     def step(self, obs, h, c, keep=None, work=None):
         """One time step for N envs (step-wise rollout of configurations the fused rollout kernel does

@@ -305,7 +305,7 @@ class VecPPOTrainer:
             if stepper:        # one launch: keep / rew / done / flags -> column t; keep <- 1 - done
                 ops.store_transition(t, st["keep"], st["rew"], st["done"], st["flags"], b["keep"], b["rew"], b["done"], b["flags"])
                 if t < self.T - 1:
-                    self.policy.mask_steps(t, st["keep"])
+                    self.policy.mask_steps(t, st["keep"], self.work)
             else:
                 b["rew"][:, t] = st["rew"]
                 b["done"][:, t] = st["done"]
