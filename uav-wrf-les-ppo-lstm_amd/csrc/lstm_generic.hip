@@ -152,7 +152,7 @@ __device__ __forceinline__ f16x8 ldh8(const unsigned short* p) { return *reinter
 // piece planes) in slabs of 32, next slab's fragments in flight while the current one multiplies.
 // A = weight pieces [2][4H][IP] and [2][4H][H], lane (r16, kq) reads 8 consecutive k of row r16 -- one dwordx4.
 template <int H, int IPS>
-__global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp,
+__global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp,
                                                           const unsigned short* __restrict__ wp,
                                                           const float* __restrict__ bsum, const float* __restrict__ x, int I,
                                                           const unsigned short* __restrict__ xp, int last_pieces,
@@ -162,11 +162,11 @@ __global__ __launch_bounds__(512) void step_fwd_h3_kernel(const unsigned short* 
                                                           const float* __restrict__ keep, int N, int T, int t,
                                                           float* __restrict__ y, float* __restrict__ hn,
                                                           float* __restrict__ cn) {
-    constexpr int NS = H / 32, NC = 2;
+    constexpr int NS = H / 32, NC = 4;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar bases
     const unsigned lo = lane * 8;                      // this lane's 16 bytes of a 1 KB fragment chunk
     const int r16 = lane & 15, kq = lane >> 4;
-    const int e0 = blockIdx.x * 64 + 32 * (w >> 2), u0 = blockIdx.y * 64 + 16 * (w & 3);
+    const int e0 = blockIdx.x * 64, u0 = blockIdx.y * 64 + 16 * w;
     int nrow[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) nrow[c] = min(e0 + 16 * c + r16, N - 1);
@@ -478,54 +478,64 @@ __global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restric
 // dh_{t-1}[n][u] = keep[n][t] * sum_k dG_t[n][k] W_hh[k][u]: A = W_hh^T pieces [2][H][4H] (rows = units), B = the scaled dG
 // pieces [2][N][4H]; tile 64 units x 64 envs, wave w: one 16-unit row tile x four env column tiles; K = 4H.
 template <int H>
-__global__ __launch_bounds__(512) void step_bwd_h3_kernel(const unsigned short* __restrict__ wtp,
+__global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* __restrict__ wtp,
                                                           const unsigned short* __restrict__ dgp,
                                                           const float* __restrict__ inv_scale, int N,
                                                           float* __restrict__ dh) {
-    constexpr int K = 4 * H, NS = K / 32, DEPTH = 8, NC = 2;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // four waves, each TWO 16-unit row tiles x TWO 16-env column tiles of the 64 x 64 workgroup tile: 8 KB of fragments per
+    // slab feed 12 MFMAs (one row tile x two column tiles per wave in eight waves loaded 6 KB for 6: the kernel is bound by
+    // the L1 path, 48 KB per slab and workgroup then, 32 KB now); one wave per SIMD, so the ring can be deep
+    constexpr int K = 4 * H, NS = K / 32, DEPTH = 8, NR = 2, NC = 2;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    const int e0 = blockIdx.x * 64 + 32 * (w >> 2), u0 = blockIdx.y * 64 + 16 * (w & 3);
-    const unsigned short* ap = wtp + (size_t)(u0 >> 4) * NS * 1024 + lane * 8;      // fragment order (frag_index)
+    const unsigned lo = lane * 8;
+    const int e0 = blockIdx.x * 64 + 32 * (w >> 1), u0 = blockIdx.y * 64 + 32 * (w & 1);
+    const unsigned short* ap[NR];
     const unsigned short* bp[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) bp[c] = dgp + (size_t)((e0 + 16 * c) >> 4) * NS * 1024 + lane * 8;
-    f32x4 acc[NC], acl[NC];
+    for (int r = 0; r < NR; ++r) ap[r] = wtp + (size_t)((u0 + 16 * r) >> 4) * NS * 1024;     // fragment order (frag_index)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = acl[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f16x8 a[DEPTH][2], b[DEPTH][NC][2];
+    for (int c = 0; c < NC; ++c) bp[c] = dgp + (size_t)((e0 + 16 * c) >> 4) * NS * 1024;
+    f32x4 acc[NR][NC], acl[NR][NC];
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) {
-        a[d][0] = ldh8(ap + 1024 * d); a[d][1] = ldh8(ap + 1024 * d + 512);
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { b[d][c][0] = ldh8(bp[c] + 1024 * d); b[d][c][1] = ldh8(bp[c] + 1024 * d + 512); }
-    }
+        for (int c = 0; c < NC; ++c) acc[r][c] = acl[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 a[DEPTH][NR][2], b[DEPTH][NC][2];
+    auto fetch = [&](int s, int buf) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { a[buf][r][0] = ldh8(ap[r] + (1024 * s + lo)); a[buf][r][1] = ldh8(ap[r] + (1024 * s + 512 + lo)); }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo)); }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) fetch(d, d);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int cur = s % DEPTH, nxt = (s + DEPTH - 1) % DEPTH;
-        if (s + DEPTH - 1 < NS) {
-            const int sn = s + DEPTH - 1;
-            a[nxt][0] = ldh8(ap + 1024 * sn); a[nxt][1] = ldh8(ap + 1024 * sn + 512);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { b[nxt][c][0] = ldh8(bp[c] + 1024 * sn); b[nxt][c][1] = ldh8(bp[c] + 1024 * sn + 512); }
-        }
+        const int cur = s % DEPTH;
+        if (s + DEPTH - 1 < NS) fetch(s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
         // pin the loads HERE: left alone the scheduler sinks them next to their uses (56 VGPRs, one slab in flight) and the
         // kernel runs at the L2 latency per slab
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][1], b[cur][c][0], acl[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][0], b[cur][c][0], acc[c], 0, 0, 0);
-            acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][0], b[cur][c][1], acl[c], 0, 0, 0);
-        }
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                acl[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][r][1], b[cur][c][0], acl[r][c], 0, 0, 0);
+                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][r][0], b[cur][c][0], acc[r][c], 0, 0, 0);
+                acl[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][r][0], b[cur][c][1], acl[r][c], 0, 0, 0);
+            }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int n = e0 + 16 * c + r16;
         if (n >= N) continue;
         const float is = inv_scale[n];
-        const f32x4 v = (acc[c] + acl[c] * H3_LO) * is;
-        *reinterpret_cast<float4*>(dh + (size_t)n * H + u0 + 4 * kq) = float4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const f32x4 v = (acc[r][c] + acl[r][c] * H3_LO) * is;
+            *reinterpret_cast<float4*>(dh + (size_t)n * H + u0 + 16 * r + 4 * kq) = float4{v[0], v[1], v[2], v[3]};
+        }
     }
 }
 
@@ -610,7 +620,7 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
             xp = xbuf + (size_t)(t - t0) * (x_step / 2);
         }
 #define LAUNCH_STEP(IPS_)                                                                                                    \
-    hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, xp, 0, (t & 1) ? hp1 : hp0, \
+    hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(256), 0, st, wxp, wp, bsum, x, I, xp, 0, (t & 1) ? hp1 : hp0, \
                        (t & 1) ? hp0 : hp1, hs, cs, stash, keep, N, T, t, y, hn, cn)
         switch (IP / 32) {
             case 1: LAUNCH_STEP(1); break;
@@ -720,7 +730,7 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
         xp = (const unsigned short*)((const char*)below + (((t + 1) & 1) ? LB.hp1 : LB.hp0));
     }
 #define LAUNCH_STEP(IPS_)                                                                                                     \
-    hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(512), 0, st, wxp, wp, bsum, x, I, xp, 1, (t & 1) ? hp1 : hp0, \
+    hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(256), 0, st, wxp, wp, bsum, x, I, xp, 1, (t & 1) ? hp1 : hp0, \
                        (t & 1) ? hp0 : hp1, hs, cs, stash, (const float*)nullptr, N, T, t, y, hn, cn)
     switch (L.IP / 32) {
         case 1: LAUNCH_STEP(1); break;
@@ -776,7 +786,7 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = T - 1; t >= 0; --t) {
         hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 3) / 4), dim3(256), 0, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
-        hipLaunchKernelGGL((step_bwd_h3_kernel<H>), grid, dim3(512), 0, st, wtp, dgp, inv_scale, N, dh);
+        hipLaunchKernelGGL((step_bwd_h3_kernel<H>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh);
     }
     if (dh0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh0, dh, NH);
     if (dc0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc0, dc, NH);
