@@ -34,7 +34,7 @@ int colsum(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* sc
 int colsum_absmax(uav_ctx* ctx, const float* X, int64_t B, int C, float* out, float* scratch, unsigned* absmax_bits,
                   hipStream_t st);
 int colsum_xw(uav_ctx* ctx, const float* X, int64_t B, int C, const float* x, int I, float* colsum_out, float* xw_out,
-              float* scratch, unsigned* absmax_bits, hipStream_t st);
+              float* scratch, unsigned* absmax_bits, hipStream_t st, int xw_transposed = 0);
 bool gemm_h3_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B, int64_t sb_k,
                 int64_t sb_n);
 int gemm_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
@@ -2048,7 +2048,13 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         };
         if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H))) return rc;
         if (!narrow && (rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
-        if (dheads && (rc = gemm_f32(&sub, n_heads, H, NT, dheads, 1, n_heads, y, H, 1, dw_head, H, nullptr, 0, st))) return rc;
+        if (dheads) {        // dW_head = dheads^T y [n_heads][H]: a stream over y with the few dheads columns riding along
+            if (H % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+                rc = colsum_xw(&sub, y, NT, H, dheads, n_heads, nullptr, dw_head, red, nullptr, st, 1);
+            else
+                rc = gemm_f32(&sub, n_heads, H, NT, dheads, 1, n_heads, y, H, 1, dw_head, H, nullptr, 0, st);
+            if (rc) return rc;
+        }
         if (dx) return product(NT, I, 4 * H, dgates, 4 * H, 1, w_ih, I, 1, dx, I);
         return 0;
     }

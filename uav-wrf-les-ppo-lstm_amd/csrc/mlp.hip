@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void colsum_xw_partial_kernel(const float* __r
 }
 // partial [nb][9][C] -> colsum [C] and xw [C][I] (= X^T x, row-major like dW_ih), fixed association
 __global__ __launch_bounds__(256) void colsum_xw_reduce_kernel(const float* __restrict__ partial, int nb, int C, int I,
-                                                               float* __restrict__ colsum_out, float* __restrict__ xw_out) {
+                                                               float* __restrict__ colsum_out, float* __restrict__ xw_out,
+                                                               int xw_transposed) {
     const int i = blockIdx.x * 256 + threadIdx.x;         // over (1 + I) * C
     if (i >= (1 + I) * C) return;
     const int q = i / C, c = i % C;
@@ -263,12 +264,14 @@ __global__ __launch_bounds__(256) void colsum_xw_reduce_kernel(const float* __re
         for (int k = 0; k < 8; ++k) p8[k] += partial[((int64_t)(b + k) * 9 + q) * C + c];
     for (; b < nb; ++b) p8[0] += partial[((int64_t)b * 9 + q) * C + c];
     const float s = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
-    if (q == 0) colsum_out[c] = s;
-    else xw_out[(int64_t)c * I + (q - 1)] = s;
+    if (q == 0) { if (colsum_out) colsum_out[c] = s; }
+    else if (xw_transposed) xw_out[(int64_t)(q - 1) * C + c] = s;          // x^T X  [I][C]
+    else xw_out[(int64_t)c * I + (q - 1)] = s;                             // X^T x  [C][I]
 }
-// colsum of X [B][C] + X^T x for x [B][I], I <= 8, C % 4 == 0, X 16-byte aligned; scratch >= 1024 * 9 * C floats
+// colsum of X [B][C] (colsum_out may be NULL) + X^T x for x [B][I] (or x^T X with xw_transposed), I <= 8, C % 4 == 0,
+// X 16-byte aligned; scratch >= 1024 * 9 * C floats
 int colsum_xw(uav_ctx* ctx, const float* X, int64_t B, int C, const float* x, int I, float* colsum_out, float* xw_out,
-              float* scratch, unsigned* absmax_bits, hipStream_t st) {
+              float* scratch, unsigned* absmax_bits, hipStream_t st, int xw_transposed = 0) {
     UAV_REQUIRE(I >= 1 && I <= 8 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0, "colsum_xw: I <= 8, cols %% 4 == 0, aligned X");
     int nb = (int)((B + 255) / 256);
     if (nb > 1024) nb = 1024;
@@ -276,7 +279,8 @@ int colsum_xw(uav_ctx* ctx, const float* X, int64_t B, int C, const float* x, in
     nb = (int)((B + rpb - 1) / rpb);
     if (absmax_bits) UAV_CHECK_HIP(hipMemsetAsync(absmax_bits, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(colsum_xw_partial_kernel, dim3(nb), dim3(256), 0, st, X, B, C, rpb, x, I, scratch, absmax_bits);
-    hipLaunchKernelGGL(colsum_xw_reduce_kernel, dim3(((1 + I) * C + 255) / 256), dim3(256), 0, st, scratch, nb, C, I, colsum_out, xw_out);
+    hipLaunchKernelGGL(colsum_xw_reduce_kernel, dim3(((1 + I) * C + 255) / 256), dim3(256), 0, st, scratch, nb, C, I, colsum_out, xw_out,
+                       xw_transposed);
     UAV_LAUNCH_CHECK();
     return 0;
 }
