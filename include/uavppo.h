@@ -164,19 +164,16 @@ int uav_mse_bce(uav_ctx* ctx, const float* out, const float* target, int64_t n, 
  * and y / stash are the [N][T][H] / [N][T][6H] arrays uav_lstm_bwd reads, filled at time index t.
  *   begin  splits the weights, sets the state to (h0, c0) [N][H]
  *   step   x [N][T][I] (row t read), writes y[:, t], stash[:, t]; at t == T-1 also hn, cn [N][H] (required pointers).
+ *          keep_t: NULL, or [N] restart mask of THIS step (uav_lstm_fwd's keep[:, t]: 0 where the env's episode ended in
+ *          the previous step -- the state entering the step is zeroed; nn.LSTM has no such mask: it is how the vectorised
+ *          rollout restarts the recurrent state, train_ppo2.0.py:157-198 runs one episode at a time).
  *          below: NULL, or the stepper state of the layer below (same N, hidden 256 = this I) already stepped to t: its
- *          h_t is then read from that state's piece planes instead of x (same values: x must still be its y array)
- *   mask   state *= keep_next[n] after step t < T-1 (it lives in row t+1 of `stash`, the step's own array; t = -1: the
- *          initial state, stash may be NULL): nn.LSTM has no such mask -- it is how the
- *          vectorised rollout restarts the recurrent state where an episode ended (train_ppo2.0.py:157-198 runs one
- *          episode at a time and never carries state across). */
+ *          h_t is then read from that state's piece planes instead of x (same values: x must still be its y array) */
 size_t uav_lstm_stepper_bytes(int N, int I, int H);
 int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const float* w_hh, const float* b_ih,
                            const float* b_hh, const float* h0, const float* c0, int N, int I, int H, uav_stream stream);
-int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, int N, int T, int t, int I, int H,
-                          float* y, float* stash, float* hn, float* cn, uav_stream stream);
-int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, float* stash, int N, int T, int t, int I,
-                          int H, uav_stream stream);
+int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, const float* keep_t, int N, int T,
+                          int t, int I, int H, float* y, float* stash, float* hn, float* cn, uav_stream stream);
 
 /* ---- dense f32 building block (exact-f32 MFMA): C[M][N] (+)= op(A)[M][K] * op(B)[K][N] + bias[N].
  * Element (i,k) of op(A) is A[i*sa_m + k*sa_k]; element (k,j) of op(B) is B[k*sb_k + j*sb_n]

@@ -360,7 +360,7 @@ def test_gate_activation_error_bounds(ops):
 @pytest.mark.parametrize("N,T,I", [(64, 6, 8), (100, 5, 256), (37, 3, 40)])
 def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     """uav_lstm_stepper_* (one time step per call: the step-wise rollout of an h = 256 policy) runs the kernels of
-    uav_lstm_fwd: with the restart mask applied by its own kernel after each step, y, the BPTT stash and the final state
+    uav_lstm_fwd: given each step's restart mask, y, the BPTT stash and the final state
     are BIT-identical to the sequence call over the same inputs -- which is why PPO epoch 0 may adopt a rollout's stash."""
     H = 256
     g = torch.Generator().manual_seed(N + T + I)
@@ -376,20 +376,17 @@ def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     sp.begin(w_ih, w_hh, b_ih, b_hh, h0, c0)
     y, stash = torch.zeros(N, T, H, device=DEV), torch.zeros(N, T, 6 * H, device=DEV)
     for t in range(T):
-        sp.step(x, t, y, stash)
-        if t < T - 1:
-            sp.mask(t, keep[:, t + 1].contiguous(), stash)
+        sp.step(x, t, y, stash, keep=keep[:, t].contiguous())
     assert torch.equal(y, y_ref) and torch.equal(stash, stash_ref)
     assert torch.equal(sp.hn, hn_ref) and torch.equal(sp.cn, cn_ref)
-    # a second rollout from the handed-over state: begin() again, mask of the initial state through t = -1
+    # a second rollout from the handed-over state: begin() again, some envs restarting at step 0
     sp.begin(w_ih, w_hh, b_ih, b_hh, hn_ref, cn_ref)
     k0 = (torch.rand(N, generator=g) > 0.5).float().to(DEV)
-    sp.mask(-1, k0)
     keep2 = keep.clone()
     keep2[:, 0] = k0
-    y2_ref, _, _, _ = ops.lstm_fwd(x, keep2, hn_ref, cn_ref, w_ih, w_hh, b_ih, b_hh)
-    sp.step(x, 0, y, stash)
-    assert torch.equal(y[:, 0], y2_ref[:, 0])
+    y2_ref, _, _, st2_ref = ops.lstm_fwd(x, keep2, hn_ref, cn_ref, w_ih, w_hh, b_ih, b_hh)
+    sp.step(x, 0, y, stash, keep=k0)
+    assert torch.equal(y[:, 0], y2_ref[:, 0]) and torch.equal(stash[:, 0], st2_ref[:, 0])
 
 
 def test_lstm_stepper_refuses_other_shapes(ops):
@@ -428,11 +425,9 @@ def test_lstm_stepper_two_layers_through_piece_planes(ops):
     ys = [torch.zeros(N, T, H, device=DEV) for _ in range(2)]
     ss = [torch.zeros(N, T, 6 * H, device=DEV) for _ in range(2)]
     for t in range(T):
-        sp[0].step(x, t, ys[0], ss[0])
-        sp[1].step(ys[0], t, ys[1], ss[1], below=sp[0])
-        if t < T - 1:
-            for l in range(2):
-                sp[l].mask(t, keep[:, t + 1].contiguous(), ss[l])
+        kt = keep[:, t].contiguous()
+        sp[0].step(x, t, ys[0], ss[0], keep=kt)
+        sp[1].step(ys[0], t, ys[1], ss[1], below=sp[0], keep=kt)
     assert torch.equal(ys[0], y1) and torch.equal(ss[0], st1)
     assert torch.equal(ys[1], y2) and torch.equal(ss[1], st2)
     assert torch.equal(sp[1].hn, hn2) and torch.equal(sp[1].cn, cn2)

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
                                                           const unsigned short* __restrict__ hp_in,
                                                           unsigned short* __restrict__ hp_out, float* __restrict__ hs,
                                                           float* __restrict__ cs, float* __restrict__ stash,
-                                                          const float* __restrict__ keep, int N, int T, int t,
+                                                          const float* __restrict__ keep, int64_t keep_sn, int64_t keep_off,
+                                                          int N, int T, int t,
                                                           float* __restrict__ y, float* __restrict__ hn,
                                                           float* __restrict__ cn) {
     constexpr int NS = H / 32, NC = 4;
@@ -170,6 +171,22 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
     int nrow[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) nrow[c] = min(e0 + 16 * c + r16, N - 1);
+    // restart mask of THIS step (keep[n][t] in {0, 1}: 0 where an episode ended in step t - 1): applied to the incoming
+    // state here -- the recurrent B fragments of a masked env are ANDed to zero (exact), c_prev / h_prev are multiplied in
+    // the epilogue -- so the outgoing state is written unmasked and no step needs the NEXT step's mask (which a rollout
+    // only learns from the environment step in between)
+    float kin[NC];
+    unsigned kmask[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        kin[c] = keep ? keep[(size_t)nrow[c] * keep_sn + keep_off] : 1.f;
+        kmask[c] = kin[c] != 0.f ? 0xffffffffu : 0u;
+    }
+    auto masked = [&](const f16x8& v, unsigned m) {
+        uint4 q = __builtin_bit_cast(uint4, v);
+        q.x &= m; q.y &= m; q.z &= m; q.w &= m;
+        return __builtin_bit_cast(f16x8, q);
+    };
 
     // accumulators start from the bias: acc[g][c][r] <-> unit u0 + 4 kq + r, env e0 + 16 c + r16
     f32x4 acc[4][NC], acl[4][NC];
@@ -239,6 +256,10 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
         for (int s = 0; s < NSL; ++s) {
             if (s + DEPTH - 1 < NSL) fetch(s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
             __builtin_amdgcn_sched_barrier(0);
+            if (s < NS) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { b[s % DEPTH][c][0] = masked(b[s % DEPTH][c][0], kmask[c]); b[s % DEPTH][c][1] = masked(b[s % DEPTH][c][1], kmask[c]); }
+            }
             mac(a[s % DEPTH], b[s % DEPTH]);
         }
     } else {
@@ -272,6 +293,8 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
 #else
             if (s + DEPTH - 1 < NS) fetch(s + DEPTH - 1, (s + DEPTH - 1) % DEPTH);
             if (DEPTH > 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { b[s % DEPTH][c][0] = masked(b[s % DEPTH][c][0], kmask[c]); b[s % DEPTH][c][1] = masked(b[s % DEPTH][c][1], kmask[c]); }
             mac(a[s % DEPTH], b[s % DEPTH]);
 #endif
         }
@@ -344,8 +367,11 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
         // the state entering step t: from (hs, cs) at t = 0, afterwards from this row's own c_prev | h_prev slots, where
         // step t - 1 left it (the state travels through the stash rows the BPTT needs anyway: no separate f32 state
         // array is written and read back on every step)
-        const float4 cp4 = *reinterpret_cast<const float4*>(t == 0 ? cs + i0 : sp + 4 * H);
-        const float4 hp4 = *reinterpret_cast<const float4*>(t == 0 ? hs + i0 : sp + 5 * H);
+        float4 cp4 = *reinterpret_cast<const float4*>(t == 0 ? cs + i0 : sp + 4 * H);
+        float4 hp4 = *reinterpret_cast<const float4*>(t == 0 ? hs + i0 : sp + 5 * H);
+        const float kc = kin[c];
+        cp4.x *= kc; cp4.y *= kc; cp4.z *= kc; cp4.w *= kc;
+        hp4.x *= kc; hp4.y *= kc; hp4.z *= kc; hp4.w *= kc;
         const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
         float gi[4], gf[4], gg[4], go[4], cc[4], hh[4];
 #pragma unroll
@@ -361,8 +387,8 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
         *reinterpret_cast<float4*>(sp + H) = float4{gf[0], gf[1], gf[2], gf[3]};
         *reinterpret_cast<float4*>(sp + 2 * H) = float4{gg[0], gg[1], gg[2], gg[3]};
         *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
-        if (t == 0) {
-            *reinterpret_cast<float4*>(sp + 4 * H) = cp4;
+        if (t == 0 || kc == 0.f) {                  // the row holds the MASKED state (what the BPTT and dW_hh read): step t - 1
+            *reinterpret_cast<float4*>(sp + 4 * H) = cp4;   // left it unmasked, so a restarted env's slots are rewritten (rare)
             *reinterpret_cast<float4*>(sp + 5 * H) = hp4;
         }
         *reinterpret_cast<float4*>(y + row * H + u0 + 4 * kq) = float4{hh[0], hh[1], hh[2], hh[3]};
@@ -371,18 +397,15 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
             *reinterpret_cast<float4*>(cn + i0) = float4{cc[0], cc[1], cc[2], cc[3]};
         }
         if (t < T - 1 || last_pieces) {             // last_pieces: the layer above reads this step's h from the piece planes
-            const float kn = (keep && t < T - 1) ? keep[row + 1] : 1.f;
             unsigned short q0[4], q1[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                hh[r] *= kn;
-                cc[r] *= kn;
                 _Float16 p0, p1;
                 split2h(hh[r], p0, p1);
                 q0[r] = h_bits(p0);
                 q1[r] = h_bits(p1);
             }
-            if (t < T - 1) {                           // masked state -> the next row's c_prev | h_prev slots
+            if (t < T - 1) {                           // state (unmasked: step t + 1 applies its own mask) -> the next row's c_prev | h_prev slots
                 *reinterpret_cast<float4*>(sp + 6 * H + 4 * H) = float4{cc[0], cc[1], cc[2], cc[3]};
                 *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hh[0], hh[1], hh[2], hh[3]};
             }
@@ -621,7 +644,7 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
         }
 #define LAUNCH_STEP(IPS_)                                                                                                    \
     hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(256), 0, st, wxp, wp, bsum, x, I, xp, 0, (t & 1) ? hp1 : hp0, \
-                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep, N, T, t, y, hn, cn)
+                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep, (int64_t)T, (int64_t)t, N, T, t, y, hn, cn)
         switch (IP / 32) {
             case 1: LAUNCH_STEP(1); break;
             case 2: LAUNCH_STEP(2); break;
@@ -638,8 +661,8 @@ bool lstm_h3_step_path(int H) { return h3_step_ok(H); }
 // ---- the same step kernel, one time step per call (uav_lstm_stepper_*): an environment step can sit between two time
 // steps (the rollout of a stacked / h = 256 policy), the weights are split once per rollout instead of once per step, the
 // recurrent state stays in its piece planes between calls, and stash / y land in the [N][T] arrays the update's BPTT
-// reads -- so PPO epoch 0 needs no forward pass.  The sequence driver above masks the state for step t + 1 inside step t
-// (keep[n][t + 1]); a rollout only knows that mask after the environment step, so it is applied by its own small kernel.
+// reads -- so PPO epoch 0 needs no forward pass.  Each step applies its OWN restart mask (keep[n][t]) to the incoming state,
+// so a rollout passes the mask it learned from the previous environment step (keep_t [N]).
 struct StepperLayout { size_t hs, cs, hp0, hp1, wp, wxp, bsum, total; int IP; };
 static StepperLayout stepper_layout(int N, int I) {
     constexpr int H = 256;
@@ -657,23 +680,6 @@ static StepperLayout stepper_layout(int N, int I) {
     L.bsum = o; o += (size_t)4 * H * 4;
     L.total = (o + 255) / 256 * 256;
     return L;
-}
-
-// state <- state * keep[n] (f32 and pieces): the mask of the step about to run, known only after the environment step
-__global__ void h3_mask_state(const float* __restrict__ keep, int N, int H, float* __restrict__ hs, float* __restrict__ cs,
-                              int64_t row_stride, unsigned short* __restrict__ hp) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)N * H) return;
-    const int n = (int)(i / H), u = (int)(i % H);
-    const float k = keep[n];
-    const int64_t o = (int64_t)n * row_stride + u;      // (hs, cs) [N][H] (row_stride = H) or the c_prev | h_prev slots of a stash row
-    const float h = hs[o] * k;
-    hs[o] = h;
-    cs[o] *= k;
-    _Float16 p0, p1;
-    split2h(h, p0, p1);
-    hp[frag_index(n, u, H, 0)] = h_bits(p0);
-    hp[frag_index(n, u, H, 1)] = h_bits(p1);
 }
 
 extern "C" {
@@ -704,8 +710,8 @@ int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const f
     return 0;
 }
 
-int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, int N, int T, int t, int I, int H,
-                          float* y, float* stash, float* hn, float* cn, uav_stream stream) {
+int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, const float* keep_t, int N, int T, int t,
+                          int I, int H, float* y, float* stash, float* hn, float* cn, uav_stream stream) {
     UAV_REQUIRE(ctx && state && x && y && stash && hn && cn, "uav_lstm_stepper_step: NULL argument");
     UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && T > 0 && t >= 0 && t < T, "uav_lstm_stepper_step: bad shape (N=%d T=%d t=%d I=%d H=%d)", N, T, t, I, H);
     g_uav_arith = ctx->lstm_arith;
@@ -731,7 +737,7 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
     }
 #define LAUNCH_STEP(IPS_)                                                                                                     \
     hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(256), 0, st, wxp, wp, bsum, x, I, xp, 1, (t & 1) ? hp1 : hp0, \
-                       (t & 1) ? hp0 : hp1, hs, cs, stash, (const float*)nullptr, N, T, t, y, hn, cn)
+                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep_t, (int64_t)1, (int64_t)0, N, T, t, y, hn, cn)
     switch (L.IP / 32) {
         case 1: LAUNCH_STEP(1); break;
         case 2: LAUNCH_STEP(2); break;
@@ -739,24 +745,6 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
         default: LAUNCH_STEP(8); break;
     }
 #undef LAUNCH_STEP
-    UAV_LAUNCH_CHECK();
-    return 0;
-}
-
-int uav_lstm_stepper_mask(uav_ctx* ctx, void* state, const float* keep_next, float* stash, int N, int T, int t, int I, int H,
-                          uav_stream stream) {
-    UAV_REQUIRE(ctx && state && keep_next, "uav_lstm_stepper_mask: NULL argument");
-    UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && t >= -1 && (t == -1 || (stash && t < T - 1)),
-                "uav_lstm_stepper_mask: bad argument (N=%d T=%d t=%d I=%d H=%d; stash is required for t >= 0, t < T-1)", N, T, t, I, H);
-    const StepperLayout L = stepper_layout(N, I);
-    char* b = (char*)state;
-    // step t wrote the state of step t + 1 into the piece planes of parity (t + 1) & 1
-    unsigned short* hp = (unsigned short*)(b + (((t + 1) & 1) ? L.hp1 : L.hp0));
-    // step t left the state of step t + 1 in row t + 1 of the stash (c_prev | h_prev slots); the initial state is (hs, cs)
-    float* hsp = t < 0 ? (float*)(b + L.hs) : stash + (size_t)(t + 1) * 6 * H + 5 * H;
-    float* csp = t < 0 ? (float*)(b + L.cs) : stash + (size_t)(t + 1) * 6 * H + 4 * H;
-    hipLaunchKernelGGL(h3_mask_state, dim3((unsigned)(((int64_t)N * H + 255) / 256)), dim3(256), 0, as_stream(stream), keep_next, N, H,
-                       hsp, csp, t < 0 ? (int64_t)H : (int64_t)T * 6 * H, hp);
     UAV_LAUNCH_CHECK();
     return 0;
 }

@@ -50,8 +50,7 @@ SIGNATURES = {
     "uav_mse_bce": (I32, [P, P, P, I64, P, P, P]),
     "uav_lstm_stepper_bytes": (SZ, [I32, I32, I32]),
     "uav_lstm_stepper_begin": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, P]),
-    "uav_lstm_stepper_step": (I32, [P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P]),
-    "uav_lstm_stepper_mask": (I32, [P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "uav_lstm_stepper_step": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P]),
     "uav_gemm_f32": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P]),
     "uav_gemm_f16x3": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P, P]),
     "uav_colsum": (I32, [P, P, I64, I32, P, P]),

@@ -430,7 +430,7 @@ def lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh, stash=None, want_stash=Tru
 class LstmStepper:
     """uav_lstm_fwd one time step per call for one layer (H = 256, fp16-split arithmetic): weights split once by begin(),
     recurrent state kept on the device in `state`; step(t) reads x[:, t] and fills y[:, t] / stash[:, t] of the [N, T]
-    arrays the BPTT reads; mask(t, keep_next) restarts the state of the envs whose episode ended in step t."""
+    arrays the BPTT reads; its `keep` argument restarts the state of the envs whose episode ended in the previous step."""
 
     def __init__(self, N, I, H, device):
         nbytes = lib().uav_lstm_stepper_bytes(int(N), int(I), int(H))
@@ -448,22 +448,16 @@ class LstmStepper:
                                            _p(b_hh, F32, (4 * H,), "b_hh"), _p(h0, F32, (N, H), "h0"), _p(c0, F32, (N, H), "c0"),
                                            N, I, H, _stream()), "uav_lstm_stepper_begin")
 
-    def step(self, x, t, y, stash, below=None):
-        """below: the LstmStepper of the layer below, already stepped to t (x is then its y array: the kernel reads h_t from
+    def step(self, x, t, y, stash, below=None, keep=None):
+        """keep: [N] restart mask of this step (0 where the env's episode ended in the previous step) or None.
+        below: the LstmStepper of the layer below, already stepped to t (x is then its y array: the kernel reads h_t from
         that stepper's piece planes instead of gathering and splitting f32 rows)."""
         N, I, H = self.N, self.I, self.H
         T = x.shape[1]
         check(lib().uav_lstm_stepper_step(_h(self.state), _p(self.state), _p(x, F32, (N, T, I), "x"),
-                                          None if below is None else _p(below.state), N, T, int(t), I, H,
-                                          _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"), _p(self.hn),
+                                          None if below is None else _p(below.state), _p(keep, F32, (N,), "keep"), N, T, int(t),
+                                          I, H, _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"), _p(self.hn),
                                           _p(self.cn), _stream()), "uav_lstm_stepper_step")
-
-    def mask(self, t, keep_next, stash=None):
-        """stash: the [N, T, 6H] array the steps write (the state of step t + 1 lives in its row t + 1); None only for t = -1."""
-        T = 0 if stash is None else stash.shape[1]
-        check(lib().uav_lstm_stepper_mask(_h(self.state), _p(self.state), _p(keep_next, F32, (self.N,), "keep_next"),
-                                          _p(stash, F32, None if stash is None else (self.N, T, 6 * self.H), "stash"), self.N, T,
-                                          int(t), self.I, self.H, _stream()), "uav_lstm_stepper_mask")
 
 
 def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):

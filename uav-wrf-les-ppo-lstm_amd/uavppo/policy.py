@@ -211,19 +211,17 @@ class LSTMActorCritic(_FlatPolicy):
             sp.begin(v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"], v[f"lstm.bias_ih_l{l}"], v[f"lstm.bias_hh_l{l}"],
                      h[l], c[l])
 
-    def step_at(self, obs_seq, t, work, heads_seq):
+    def step_at(self, obs_seq, t, work, heads_seq, keep=None):
         """Time step t of all layers on the [N, T, ...] arrays of the update (obs_seq [N, T, I] row t already written;
-        work['y{l}'], work['stash{l}'] filled at t); heads_seq [N, T, A+1] row t = actor / critic rows of the top layer."""
+        work['y{l}'], work['stash{l}'] filled at t); keep [N]: this step's restart mask; heads_seq [N, T, A+1] row t =
+        actor / critic rows of the top layer."""
         x = obs_seq
         for l, sp in enumerate(self._steppers):
-            sp.step(x, t, work[f"y{l}"], work[f"stash{l}"], below=self._steppers[l - 1] if l > 0 and self.hidden == 256 else None)
+            sp.step(x, t, work[f"y{l}"], work[f"stash{l}"], below=self._steppers[l - 1] if l > 0 and self.hidden == 256 else None,
+                    keep=keep)
             x = work[f"y{l}"]
         v = self.views
         return ops.gemm_rows(x[:, t], v["head.weight"], v["head.bias"], heads_seq[:, t])
-
-    def mask_steps(self, t, keep_next, work):
-        for l, sp in enumerate(self._steppers):
-            sp.mask(t, keep_next, work[f"stash{l}"])
 
     def step(self, obs, h, c, keep=None, work=None):
         """One time step for N envs (step-wise rollout of configurations the fused rollout kernel does

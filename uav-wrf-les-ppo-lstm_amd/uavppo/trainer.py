@@ -271,7 +271,7 @@ class VecPPOTrainer:
         for t in range(self.T):
             if stepper:
                 b["obs"][:, t] = self.cur_obs
-                heads = self.policy.step_at(b["obs"], t, self.work, self.work["heads"])
+                heads = self.policy.step_at(b["obs"], t, self.work, self.work["heads"], keep=st["keep"])
             else:
                 heads = self.policy.step(self.cur_obs, self.h, self.c, st["keep"], st["work"])
             fa = None if forced_act is None else forced_act[:, t].contiguous()
@@ -304,8 +304,6 @@ class VecPPOTrainer:
                 self.info[:, t, 8:10] = st["src"]
             if stepper:        # one launch: keep / rew / done / flags -> column t; keep <- 1 - done
                 ops.store_transition(t, st["keep"], st["rew"], st["done"], st["flags"], b["keep"], b["rew"], b["done"], b["flags"])
-                if t < self.T - 1:
-                    self.policy.mask_steps(t, st["keep"], self.work)
             else:
                 b["rew"][:, t] = st["rew"]
                 b["done"][:, t] = st["done"]
