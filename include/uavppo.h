@@ -253,7 +253,11 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh,
                  const float* dy, const float* dheads, const float* w_head, int n_heads,
                  const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0,
-                 float* dc0, uav_stream stream);
+                 float* dc0, const float* w_ih, int I, float* dx, uav_stream stream);
+/* dx [N][T][I] = dG W_ih (the gradient of the layer's input, for the layer below) can be formed by uav_lstm_bwd itself --
+ * its per-step recurrent product multiplies the same dG fragments -- when this returns 1 (H = 256 = I on the fp16-split
+ * arithmetic): pass w_ih [4H][I] and dx there and dx = NULL to uav_lstm_wgrad.  Otherwise pass NULL, NULL to uav_lstm_bwd. */
+int uav_lstm_bwd_fuses_dx(uav_ctx* ctx, int I, int H);
 /* Time-batched weight gradients from dgates in ONE fused pass (csrc/wgrad.hip):
  * dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev with Hprev[n][t] = y[n][t-1]*keep[n][t]
  * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh) and -- when dheads != NULL (top layer) --

@@ -478,7 +478,10 @@ __global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restric
         e = e > 100 ? 100 : (e < -100 ? -100 : e);
     }
     const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
-    if (lane == 0) inv_scale[n] = isc * kp;                 // the mask of step t rides on the scale
+    if (lane == 0) {
+        inv_scale[n] = isc * kp;                            // dh_{t-1}: the mask of step t rides on the scale
+        inv_scale[(N + 63) / 64 * 64 + n] = isc;            // dx_t (the gradient of the step's input) is not masked
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         unsigned short q0[4], q1[4];
@@ -500,34 +503,45 @@ __global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restric
 
 // dh_{t-1}[n][u] = keep[n][t] * sum_k dG_t[n][k] W_hh[k][u]: A = W_hh^T pieces [2][H][4H] (rows = units), B = the scaled dG
 // pieces [2][N][4H]; tile 64 units x 64 envs, wave w: one 16-unit row tile x four env column tiles; K = 4H.
-template <int H>
+// DX: the same B fragments also multiply W_ih^T (wxtp, I = H): dx_t = dG_t W_ih, the gradient of the layer's input, written at
+// [n][t] of dx -- instead of a separate [N T x 4H] x [4H x I] GEMM that re-reads all of dG (3.5 ms per epoch at C5).
+template <int H, bool DX>
 __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* __restrict__ wtp,
                                                           const unsigned short* __restrict__ dgp,
                                                           const float* __restrict__ inv_scale, int N,
-                                                          float* __restrict__ dh) {
+                                                          float* __restrict__ dh, const unsigned short* __restrict__ wxtp,
+                                                          float* __restrict__ dx, int T, int t) {
     // four waves, each TWO 16-unit row tiles x TWO 16-env column tiles of the 64 x 64 workgroup tile: 8 KB of fragments per
     // slab feed 12 MFMAs (one row tile x two column tiles per wave in eight waves loaded 6 KB for 6: the kernel is bound by
     // the L1 path, 48 KB per slab and workgroup then, 32 KB now); one wave per SIMD, so the ring can be deep
-    constexpr int K = 4 * H, NS = K / 32, DEPTH = 8, NR = 2, NC = 2;
+    constexpr int K = 4 * H, NS = K / 32, DEPTH = DX ? 6 : 8, NR = 2, NC = 2;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const unsigned lo = lane * 8;
     const int e0 = blockIdx.x * 64 + 32 * (w >> 1), u0 = blockIdx.y * 64 + 32 * (w & 1);
     const unsigned short* ap[NR];
+    const unsigned short* axp[NR];
     const unsigned short* bp[NC];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) ap[r] = wtp + (size_t)((u0 + 16 * r) >> 4) * NS * 1024;     // fragment order (frag_index)
+    for (int r = 0; r < NR; ++r) {
+        ap[r] = wtp + (size_t)((u0 + 16 * r) >> 4) * NS * 1024;                              // fragment order (frag_index)
+        axp[r] = DX ? wxtp + (size_t)((u0 + 16 * r) >> 4) * NS * 1024 : nullptr;
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) bp[c] = dgp + (size_t)((e0 + 16 * c) >> 4) * NS * 1024;
-    f32x4 acc[NR][NC], acl[NR][NC];
+    f32x4 acc[NR][NC], acl[NR][NC], xcc[NR][NC], xcl[NR][NC];
 #pragma unroll
     for (int r = 0; r < NR; ++r)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[r][c] = acl[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f16x8 a[DEPTH][NR][2], b[DEPTH][NC][2];
+        for (int c = 0; c < NC; ++c) acc[r][c] = acl[r][c] = xcc[r][c] = xcl[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 a[DEPTH][NR][2], ax[DX ? DEPTH : 1][NR][2], b[DEPTH][NC][2];
     auto fetch = [&](int s, int buf) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) { a[buf][r][0] = ldh8(ap[r] + (1024 * s + lo)); a[buf][r][1] = ldh8(ap[r] + (1024 * s + 512 + lo)); }
+        if (DX) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { ax[buf][r][0] = ldh8(axp[r] + (1024 * s + lo)); ax[buf][r][1] = ldh8(axp[r] + (1024 * s + 512 + lo)); }
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) { b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo)); }
     };
@@ -547,6 +561,11 @@ __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* 
                 acl[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][r][1], b[cur][c][0], acl[r][c], 0, 0, 0);
                 acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][r][0], b[cur][c][0], acc[r][c], 0, 0, 0);
                 acl[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cur][r][0], b[cur][c][1], acl[r][c], 0, 0, 0);
+                if (DX) {
+                    xcl[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[cur][r][1], b[cur][c][0], xcl[r][c], 0, 0, 0);
+                    xcc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[cur][r][0], b[cur][c][0], xcc[r][c], 0, 0, 0);
+                    xcl[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[cur][r][0], b[cur][c][1], xcl[r][c], 0, 0, 0);
+                }
             }
     }
 #pragma unroll
@@ -558,6 +577,10 @@ __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* 
         for (int r = 0; r < NR; ++r) {
             const f32x4 v = (acc[r][c] + acl[r][c] * H3_LO) * is;
             *reinterpret_cast<float4*>(dh + (size_t)n * H + u0 + 16 * r + 4 * kq) = float4{v[0], v[1], v[2], v[3]};
+            if (DX) {
+                const f32x4 vx = (xcc[r][c] + xcl[r][c] * H3_LO) * inv_scale[(N + 63) / 64 * 64 + n];
+                *reinterpret_cast<float4*>(dx + ((size_t)n * T + t) * H + u0 + 16 * r + 4 * kq) = float4{vx[0], vx[1], vx[2], vx[3]};
+            }
         }
     }
 }
@@ -753,28 +776,32 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
 
 static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                        const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
-                       hipStream_t st) {
+                       const float* w_ih, float* dx, hipStream_t st) {
     constexpr int H = 256;
     const int64_t NH = (int64_t)N * H;
     // tail of the workspace: dh, dc f32 | dG pieces [2][N][4H] | inv_scale [N] | W_hh^T pieces [2][H][4H]
     const int64_t NP = (int64_t)(N + 63) / 64 * 64 * H;
-    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 4 * NP) * 2 + (size_t)((N + 63) / 64 * 64) * 4 + (size_t)2 * 4 * H * H * 2;
+    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 4 * NP) * 2 + (size_t)((N + 63) / 64 * 64) * 4 * 2 + (size_t)2 * 2 * 4 * H * H * 2;
     UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
     char* base = (char*)ctx->ws + ctx->ws_bytes - need;
     float* dh = (float*)base;
     float* dc = dh + NH;
     unsigned short* dgp = (unsigned short*)(dc + NH);
     float* inv_scale = (float*)(dgp + 2 * 4 * NP);
-    unsigned short* wtp = (unsigned short*)(inv_scale + (N + 63) / 64 * 64);
+    unsigned short* wtp = (unsigned short*)(inv_scale + 2 * ((N + 63) / 64 * 64));      // [masked | unmasked] inverse scales
+    unsigned short* wxtp = wtp + (size_t)2 * 4 * H * H;                                 // W_ih^T pieces (dx fused, I = H)
     const unsigned nb = (unsigned)((NH + 255) / 256);
     UAV_CHECK_HIP(hipMemsetAsync(dgp, 0, (size_t)2 * 4 * NP * 2, st));
     hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 1, wtp);
+    if (dx) hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_ih, 4 * H, H, H, 1, wxtp);
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh, dhn, NH);
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = T - 1; t >= 0; --t) {
         hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 3) / 4), dim3(256), 0, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
-        hipLaunchKernelGGL((step_bwd_h3_kernel<H>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh);
+        if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh, wxtp, dx, T, t);
+        else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh,
+                                (const unsigned short*)nullptr, (float*)nullptr, T, t);
     }
     if (dh0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh0, dh, NH);
     if (dc0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc0, dc, NH);
@@ -803,10 +830,15 @@ int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const flo
     return 0;
 }
 
+// the step path forms dx = dG W_ih itself (no separate GEMM) when the input is as wide as the state
+bool lstm_h3_bwd_fuses_dx(int I, int H) { return h3_step_ok(H) && I == H; }
+
 int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                      const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0, float* dc0,
-                     hipStream_t st) {
-    if (h3_step_ok(H)) return lstm_h3_bwd(ctx, keep, stash, w_hh, dy, dhn, dcn, N, T, dgates, dh0, dc0, st);
+                     const float* w_ih, int I, float* dx, hipStream_t st) {
+    UAV_REQUIRE(!dx || (w_ih && lstm_h3_bwd_fuses_dx(I, H)), "uav_lstm_bwd: dx is formed here only when uav_lstm_bwd_fuses_dx(ctx, I, H) "
+                "says so (H = 256 = I on the fp16-split arithmetic); otherwise ask uav_lstm_wgrad for it");
+    if (h3_step_ok(H)) return lstm_h3_bwd(ctx, keep, stash, w_hh, dy, dhn, dcn, N, T, dgates, dh0, dc0, w_ih, dx, st);
     const int64_t NH = (int64_t)N * H;
     UAV_REQUIRE((size_t)(2 * NH) * sizeof(float) + (64u << 20) <= ctx->ws_bytes, "lstm (generic): workspace too small");
     float* dh = (float*)((char*)ctx->ws + ctx->ws_bytes) - 2 * NH;

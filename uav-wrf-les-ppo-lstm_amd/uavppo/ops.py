@@ -500,12 +500,16 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     nhw = 0 if wgrad_dheads is None else wgrad_dheads.shape[-1]
     if wgrad_dheads is not None and dw_head is None:
         dw_head = torch.empty(nhw, H, dtype=F32, device=dev)
+    # the h = 256 step path forms dx = dG W_ih inside its per-step recurrent product (same dG fragments) when I == H
+    dx_in_bwd = bool(need_dx and lib().uav_lstm_bwd_fuses_dx(_h(x), I, H))
     _t = KERNEL_TIMER.bracket("lstm_bwd")
     check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
                              _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh,
                              _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, H,
-                             _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dh0), _p(dc0), _stream()), "uav_lstm_bwd")
+                             _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dh0), _p(dc0),
+                             _p(w_ih, F32, (4 * H, I), "w_ih") if dx_in_bwd else None, I, _p(dx) if dx_in_bwd else None,
+                             _stream()), "uav_lstm_bwd")
     if _t is not None:
         _t.record()
     _t = KERNEL_TIMER.bracket("lstm_wgrad")
@@ -514,7 +518,8 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
                                _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
                                _p(wgrad_dheads, F32, (N, T, nhw), "dheads"), nhw, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
-                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nhw, H), "dw_head"), _p(dx), _stream()),
+                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nhw, H), "dw_head"),
+                               None if dx_in_bwd else _p(dx), _stream()),
           "uav_lstm_wgrad")
     if _t is not None:
         _t.record()
