@@ -15,6 +15,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CELL_ABL
+#define CELL_ABL 0      // ablation builds of cell_bwd_h3_kernel only (tools/ab_step_fwd.sh): 1 no piece stores, 2 no f32 dG stores, 3 neither
+#endif
 #ifndef STEP_ABL
 #define STEP_ABL 0      // ablation builds of step_fwd_h3_kernel only (tools/ab_step_fwd.sh): 1 no MFMAs, 2 no recurrent loads, 3 no epilogue
 #endif
@@ -428,16 +431,27 @@ __global__ void add2v_kernel(const float* a0, const float* a1, float* b, int n) 
 // dgates f32 [n][t][4H] for the weight-gradient pass AND, for the recurrent product, the same row as two fp16 planes in MFMA
 // fragment order, scaled by the power of two that puts the row's largest magnitude in [2^13, 2^14) (gradients span dozens
 // of binades; scaled back exactly by step_bwd_h3_kernel).
+// A workgroup = the 16 envs of one fragment row tile (16 waves): every wave parks its row's pieces in LDS and the workgroup
+// then writes the tile's 64 KB of piece chunks as ONE linear block -- lanes writing their own 8 bytes straight to the
+// fragment order scattered 16-byte segments over 32 lines per store, and the 16.8 MB of pieces cost 7.5 us of the step's
+// 20 (profiles/r02_cell_bwd_ablation.log).  LDS image: chunk (slab, piece) at CB_CH halves, kq rows at CB_KQ: strides chosen
+// so that the 32 (slab, kq) positions one store instruction touches fall on different banks (2-way at worst).
+constexpr int CB_KQ = 136, CB_CH = 592;                 // halves: 272 B per kq row (16 envs x 16 B + 16), 1184 B per chunk
+constexpr size_t CELL_BWD_LDS = (size_t)64 * CB_CH * 2;
 template <int H>
-__global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
+__global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
                                                           const float* __restrict__ dy, int N, int T, int t,
                                                           const float* __restrict__ dh_rec, float* __restrict__ dc_next,
                                                           float* __restrict__ dgates, unsigned short* __restrict__ dgp,
                                                           float* __restrict__ inv_scale) {
     static_assert(H == 256, "one wave per env: 64 lanes x 4 units");
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), u = 4 * lane;
-    if (n >= N) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned short cb_lds[];
+    const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 6;
+    const int n = blockIdx.x * 16 + r16, u = 4 * lane;
+    const bool live = n < N;
+    // this lane's 8 bytes of chunk (slab 8 q + lane / 8, piece): kq = (lane % 8) / 2, halves 4 (lane & 1) ..
+    unsigned short* lp = cb_lds + (size_t)(2 * (lane >> 3)) * CB_CH + ((lane & 7) >> 1) * CB_KQ + r16 * 8 + 4 * (lane & 1);
+    if (live) {
     const size_t row = (size_t)n * T + t, i = (size_t)n * H + u;
     const float* sp = stash + row * (6 * H) + u;
     const float4 gi4 = *reinterpret_cast<const float4*>(sp), gf4 = *reinterpret_cast<const float4*>(sp + H);
@@ -466,8 +480,12 @@ __global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restric
         for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(g4[q][r]));
     }
     float* gp = dgates + row * (4 * H) + u;
+#if CELL_ABL != 2 && CELL_ABL != 3
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(gp + q * H) = float4{g4[q][0], g4[q][1], g4[q][2], g4[q][3]};
+#else
+    if (m == 123.456f) gp[0] = g4[0][0];
+#endif
     *reinterpret_cast<float4*>(dc_next + i) = float4{dcn[0], dcn[1], dcn[2], dcn[3]};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -495,10 +513,28 @@ __global__ __launch_bounds__(256) void cell_bwd_h3_kernel(const float* __restric
         uint2 v0, v1;
         v0.x = (unsigned)q0[0] | ((unsigned)q0[1] << 16); v0.y = (unsigned)q0[2] | ((unsigned)q0[3] << 16);
         v1.x = (unsigned)q1[0] | ((unsigned)q1[1] << 16); v1.y = (unsigned)q1[2] | ((unsigned)q1[3] << 16);
-        const int k = q * H + u;                            // column of the [N][4H] operand
-        *reinterpret_cast<uint2*>(dgp + frag_index(n, k, 4 * H, 0)) = v0;
-        *reinterpret_cast<uint2*>(dgp + frag_index(n, k, 4 * H, 1)) = v1;
+        // gate q = slabs 8 q .. 8 q + 7 of the [N][4H] operand
+        *reinterpret_cast<uint2*>(lp + (size_t)(16 * q) * CB_CH) = v0;
+        *reinterpret_cast<uint2*>(lp + (size_t)(16 * q + 1) * CB_CH) = v1;
     }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // a ragged last tile: rows past N stay zero
+            *reinterpret_cast<uint2*>(lp + (size_t)(16 * q) * CB_CH) = uint2{0u, 0u};
+            *reinterpret_cast<uint2*>(lp + (size_t)(16 * q + 1) * CB_CH) = uint2{0u, 0u};
+        }
+    }
+    __syncthreads();
+#if CELL_ABL != 1 && CELL_ABL != 3
+    // the tile's piece block is 64 chunks x 1 KB of consecutive memory (frag_index): a linear copy, 16 bytes per thread
+    unsigned short* gout = dgp + (size_t)blockIdx.x * 64 * 512;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int e8 = ps * 1024 + threadIdx.x, c = e8 >> 6, kq = (e8 >> 4) & 3, r = e8 & 15;
+        const uint4 v = *reinterpret_cast<const uint4*>(cb_lds + (size_t)c * CB_CH + kq * CB_KQ + r * 8);
+        *reinterpret_cast<uint4*>(gout + (size_t)e8 * 8) = v;
+    }
+#endif
 }
 
 // dh_{t-1}[n][u] = keep[n][t] * sum_k dG_t[n][k] W_hh[k][u]: A = W_hh^T pieces [2][H][4H] (rows = units), B = the scaled dG
@@ -792,13 +828,19 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
     unsigned short* wxtp = wtp + (size_t)2 * 4 * H * H;                                 // W_ih^T pieces (dx fused, I = H)
     const unsigned nb = (unsigned)((NH + 255) / 256);
     UAV_CHECK_HIP(hipMemsetAsync(dgp, 0, (size_t)2 * 4 * NP * 2, st));
+    static bool cell_attr = false;
+    if (!cell_attr) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)CELL_BWD_LDS));
+        cell_attr = true;
+    }
     hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 1, wtp);
     if (dx) hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_ih, 4 * H, H, H, 1, wxtp);
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh, dhn, NH);
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = T - 1; t >= 0; --t) {
-        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 3) / 4), dim3(256), 0, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
+        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 15) / 16), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
         if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh, wxtp, dx, T, t);
         else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh,
                                 (const unsigned short*)nullptr, (float*)nullptr, T, t);
