@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Does the fused path learn?  A few hundred PPO iterations at a C3-like shape; prints reward / success trend."""
+"""Does the fused path learn?  A few hundred PPO iterations at a C3-like shape (or, with a 4th argument "c5", the stacked
+h = 256 x 2 + trend policy of BASELINE C5 at 1024 envs x 128 steps: stepper rollout, piece-plane inputs, fused dx, split
+GEMMs); prints reward / success trend."""
 import os
 import sys
 import time
@@ -17,7 +19,12 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-4
     mb = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    tr = VecPPOTrainer(N, T, "lstm", hidden=128, device="cuda:0", seed=1, lr=lr, num_minibatches=mb, use_curriculum=True)
+    if len(sys.argv) > 4 and sys.argv[4] == "c5":
+        N = 1024
+        tr = VecPPOTrainer(N, T, "lstm", hidden=256, layers=2, trend_k=2, variant="v2.1", device="cuda:0", seed=1, lr=lr,
+                           num_minibatches=mb, use_curriculum=True)
+    else:
+        tr = VecPPOTrainer(N, T, "lstm", hidden=128, device="cuda:0", seed=1, lr=lr, num_minibatches=mb, use_curriculum=True)
     t0 = time.perf_counter()
     for it in range(iters):
         tr.train_iteration()
