@@ -254,10 +254,16 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
                  const float* dy, const float* dheads, const float* w_head, int n_heads,
                  const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0,
                  float* dc0, const float* w_ih, int I, float* dx, uav_stream stream);
-/* dx [N][T][I] = dG W_ih (the gradient of the layer's input, for the layer below) can be formed by uav_lstm_bwd itself --
- * its per-step recurrent product multiplies the same dG fragments -- when this returns 1 (H = 256 = I on the fp16-split
- * arithmetic): pass w_ih [4H][I] and dx there and dx = NULL to uav_lstm_wgrad.  Otherwise pass NULL, NULL to uav_lstm_bwd. */
-int uav_lstm_bwd_fuses_dx(uav_ctx* ctx, int I, int H);
+/* What uav_lstm_bwd can do for this layer shape under the handle's arithmetic (a bit mask):
+ *   UAV_BWD_FUSES_DX      dx [N][T][I] = dG W_ih (the gradient of the layer's input, for the layer below) is formed by
+ *                         uav_lstm_bwd itself -- its per-step recurrent product multiplies the same dG fragments (H = 256 = I
+ *                         on the fp16-split arithmetic): pass w_ih [4H][I] and dx there and dx = NULL to uav_lstm_wgrad.
+ *                         Without the bit pass NULL, NULL to uav_lstm_bwd and ask uav_lstm_wgrad for dx.
+ *   UAV_BWD_TAKES_DHEADS  the gradient of y may come as dheads + w_head (dy = dheads . w_head formed on chip); without
+ *                         the bit form dy with uav_gemm_f32 and pass that. */
+#define UAV_BWD_FUSES_DX 1
+#define UAV_BWD_TAKES_DHEADS 2
+int uav_lstm_bwd_caps(uav_ctx* ctx, int I, int H);
 /* Time-batched weight gradients from dgates in ONE fused pass (csrc/wgrad.hip):
  * dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev with Hprev[n][t] = y[n][t-1]*keep[n][t]
  * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh) and -- when dheads != NULL (top layer) --

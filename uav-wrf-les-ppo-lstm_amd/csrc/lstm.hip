@@ -47,9 +47,10 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
                 float* cn, float* stash, hipStream_t st);
 bool lstm_h3_step_path(int H);
 int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
+                     const float* dheads, const float* w_head, int n_heads,
                      const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0, float* dc0,
                      const float* w_ih, int I, float* dx, hipStream_t st);
-bool lstm_h3_bwd_fuses_dx(int I, int H);
+int lstm_generic_bwd_caps(int I, int H);
 int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
                      const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
                      float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
@@ -1991,10 +1992,11 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
     return 0;
 }
 
-int uav_lstm_bwd_fuses_dx(uav_ctx* ctx, int I, int H) {
+int uav_lstm_bwd_caps(uav_ctx* ctx, int I, int H) {
     if (!ctx) return 0;
+    if (H == 64 || H == 128) return UAV_BWD_TAKES_DHEADS;            // the persistent sequence kernels
     g_uav_arith = ctx->lstm_arith;
-    return lstm_h3_bwd_fuses_dx(I, H) ? 1 : 0;
+    return lstm_generic_bwd_caps(I, H);
 }
 
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
@@ -2007,8 +2009,8 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
     UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd: dheads needs w_head and 1..8 heads");
     UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd: N=%d T=%d", N, T);
     if (H != 64 && H != 128) {
-        UAV_REQUIRE(dy, "uav_lstm_bwd: hidden sizes other than 64/128 take dy (form dheads . w_head with uav_gemm_f32)");
-        return lstm_generic_bwd(ctx, keep, stash, w_hh, dy, dhn, dcn, N, T, H, dgates, dh0, dc0, w_ih, I, dx, as_stream(stream));
+        return lstm_generic_bwd(ctx, keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, H, dgates, dh0, dc0, w_ih, I, dx,
+                                as_stream(stream));
     }
     UAV_REQUIRE(!dx, "uav_lstm_bwd: dx is not formed by the H = 64 / 128 sequence kernels (uav_lstm_wgrad does it)");
     return lstm_bwd_seq(keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, H, dgates, dh0, dc0,

@@ -440,7 +440,8 @@ constexpr int CB_KQ = 136, CB_CH = 592;                 // halves: 272 B per kq 
 constexpr size_t CELL_BWD_LDS = (size_t)64 * CB_CH * 2;
 template <int H>
 __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
-                                                          const float* __restrict__ dy, int N, int T, int t,
+                                                          const float* __restrict__ dy, const float* __restrict__ dheads,
+                                                          const float* __restrict__ w_head, int NH, int N, int T, int t,
                                                           const float* __restrict__ dh_rec, float* __restrict__ dc_next,
                                                           float* __restrict__ dgates, unsigned short* __restrict__ dgp,
                                                           float* __restrict__ inv_scale) {
@@ -457,7 +458,18 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
     const float4 gi4 = *reinterpret_cast<const float4*>(sp), gf4 = *reinterpret_cast<const float4*>(sp + H);
     const float4 gg4 = *reinterpret_cast<const float4*>(sp + 2 * H), go4 = *reinterpret_cast<const float4*>(sp + 3 * H);
     const float4 cp4 = *reinterpret_cast<const float4*>(sp + 4 * H);
-    const float4 dy4 = *reinterpret_cast<const float4*>(dy + row * H + u), dr4 = *reinterpret_cast<const float4*>(dh_rec + i);
+    float4 dy4;
+    if (dy) dy4 = *reinterpret_cast<const float4*>(dy + row * H + u);
+    else {           // top layer: dy = dheads . W_head formed here (the row's few dheads are wave-uniform), never written to HBM
+        dy4 = float4{0.f, 0.f, 0.f, 0.f};
+        const float* dhd = dheads + row * NH;
+        for (int a = 0; a < NH; ++a) {
+            const float d = dhd[a];
+            const float4 wv = *reinterpret_cast<const float4*>(w_head + (size_t)a * H + u);
+            dy4.x = fmaf(d, wv.x, dy4.x); dy4.y = fmaf(d, wv.y, dy4.y); dy4.z = fmaf(d, wv.z, dy4.z); dy4.w = fmaf(d, wv.w, dy4.w);
+        }
+    }
+    const float4 dr4 = *reinterpret_cast<const float4*>(dh_rec + i);
     const float4 dn4 = *reinterpret_cast<const float4*>(dc_next + i);
     const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
     const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
@@ -811,6 +823,7 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
 }  // extern "C"
 
 static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
+                       const float* dheads, const float* w_head, int n_heads,
                        const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
                        const float* w_ih, float* dx, hipStream_t st) {
     constexpr int H = 256;
@@ -840,7 +853,7 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
     hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
     const dim3 grid((N + 63) / 64, H / 64);
     for (int t = T - 1; t >= 0; --t) {
-        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 15) / 16), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, N, T, t, dh, dc, dgates, dgp, inv_scale);
+        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 15) / 16), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head, n_heads, N, T, t, dh, dc, dgates, dgp, inv_scale);
         if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh, wxtp, dx, T, t);
         else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh,
                                 (const unsigned short*)nullptr, (float*)nullptr, T, t);
@@ -875,12 +888,18 @@ int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const flo
 // the step path forms dx = dG W_ih itself (no separate GEMM) when the input is as wide as the state
 bool lstm_h3_bwd_fuses_dx(int I, int H) { return h3_step_ok(H) && I == H; }
 
+// what the generic / step paths of uav_lstm_bwd can do themselves: bit 0 form dx (I == H on the step path), bit 1 take dheads
+int lstm_generic_bwd_caps(int I, int H) { return h3_step_ok(H) ? ((I == H ? 1 : 0) | 2) : 0; }
+
 int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
+                     const float* dheads, const float* w_head, int n_heads,
                      const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0, float* dc0,
                      const float* w_ih, int I, float* dx, hipStream_t st) {
-    UAV_REQUIRE(!dx || (w_ih && lstm_h3_bwd_fuses_dx(I, H)), "uav_lstm_bwd: dx is formed here only when uav_lstm_bwd_fuses_dx(ctx, I, H) "
+    UAV_REQUIRE(dy || h3_step_ok(H), "uav_lstm_bwd: this hidden size / arithmetic takes dy (form dheads . w_head with uav_gemm_f32); "
+                "see uav_lstm_bwd_caps");
+    UAV_REQUIRE(!dx || (w_ih && lstm_h3_bwd_fuses_dx(I, H)), "uav_lstm_bwd: dx is formed here only when uav_lstm_bwd_caps(ctx, I, H) "
                 "says so (H = 256 = I on the fp16-split arithmetic); otherwise ask uav_lstm_wgrad for it");
-    if (h3_step_ok(H)) return lstm_h3_bwd(ctx, keep, stash, w_hh, dy, dhn, dcn, N, T, dgates, dh0, dc0, w_ih, dx, st);
+    if (h3_step_ok(H)) return lstm_h3_bwd(ctx, keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, dgates, dh0, dc0, w_ih, dx, st);
     const int64_t NH = (int64_t)N * H;
     UAV_REQUIRE((size_t)(2 * NH) * sizeof(float) + (64u << 20) <= ctx->ws_bytes, "lstm (generic): workspace too small");
     float* dh = (float*)((char*)ctx->ws + ctx->ws_bytes) - 2 * NH;

@@ -63,7 +63,7 @@ SIGNATURES = {
     "uav_mlp_ppo_grad": (I32, [P, P, P, P, P, P, P, P, I64, I32, I32, I32, I32, F32, F32, F32, P, P, P]),
     "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, P, P, I32, P, P]),
-    "uav_lstm_bwd_fuses_dx": (I32, [P, I32, I32]),
+    "uav_lstm_bwd_caps": (I32, [P, I32, I32]),
     "uav_lstm_wgrad": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),
     "uav_env_reset": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P]),

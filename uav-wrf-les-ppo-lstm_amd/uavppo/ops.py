@@ -480,6 +480,12 @@ def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):
     return {"dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dw_head": dw_head}
 
 
+def lstm_bwd_caps(device, I, H):
+    """uav_lstm_bwd_caps bit mask for a layer of input width I, hidden size H on `device`: 1 = forms dx itself, 2 = takes
+    dheads + w_head instead of dy."""
+    return int(lib().uav_lstm_bwd_caps(Context.get(torch.device(device)).handle, int(I), int(H)))
+
+
 def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
              dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None):
     """BPTT sequence kernel + fused weight-gradient pass of one layer.  y, h0: the layer's forward
@@ -501,7 +507,7 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     if wgrad_dheads is not None and dw_head is None:
         dw_head = torch.empty(nhw, H, dtype=F32, device=dev)
     # the h = 256 step path forms dx = dG W_ih inside its per-step recurrent product (same dG fragments) when I == H
-    dx_in_bwd = bool(need_dx and lib().uav_lstm_bwd_fuses_dx(_h(x), I, H))
+    dx_in_bwd = bool(need_dx and lstm_bwd_caps(x.device, I, H) & 1)
     _t = KERNEL_TIMER.bracket("lstm_bwd")
     check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
                              _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),

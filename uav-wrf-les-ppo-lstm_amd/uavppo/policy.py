@@ -256,9 +256,12 @@ class LSTMActorCritic(_FlatPolicy):
         else:
             ops.colsum(dheads, out=g["head.bias"])
         dy = None
-        fused_heads = self.hidden in (64, 128)        # lstm_bwd_kernel forms dy = dheads . W_head in registers
+        top_in = self.obs_dim if self.num_layers == 1 else self.hidden
+        fused_heads = bool(ops.lstm_bwd_caps(dheads.device, top_in, self.hidden) & 2)   # dy = dheads . W_head formed on chip
         if not fused_heads:
-            dy = ops.gemm(dheads, v["head.weight"], out=work.get("dy")).view(N, T, H)
+            if work.get("dy") is None or work["dy"].shape[0] != N * T:
+                work["dy"] = torch.empty(N * T, H, dtype=torch.float32, device=dheads.device)
+            dy = ops.gemm(dheads, v["head.weight"], out=work["dy"]).view(N, T, H)
         for l in reversed(range(self.num_layers)):
             x, stash, y, h0 = saved[l]
             top = (l == self.num_layers - 1)

@@ -121,8 +121,7 @@ class VecPPOTrainer:
             for l in range(L):
                 self.work[f"stash{l}"] = torch.empty(nb, T, 6 * H, **f32)
                 self.work[f"y{l}"] = torch.empty(nb, T, H, **f32)
-            if H not in (64, 128):
-                self.work["dy"] = torch.empty(nb * T, H, **f32)
+            # (a dy buffer for paths whose backward does not take dheads is allocated on first use: policy.backward)
         else:
             nb = N // self.num_minibatches
             self.work = {"stash": None}      # layer-by-layer path only (770 floats per sample); allocated on first use
