@@ -263,7 +263,28 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
  *                         the bit form dy with uav_gemm_f32 and pass that. */
 #define UAV_BWD_FUSES_DX 1
 #define UAV_BWD_TAKES_DHEADS 2
+#define UAV_BWD_STACKS 4        /* uav_lstm_bwd_stack is available for layers of this shape (H = 256 = I, fp16-split arithmetic) */
 int uav_lstm_bwd_caps(uav_ctx* ctx, int I, int H);
+/* The BPTTs of a STACK of LSTM layers (nn.LSTM(num_layers > 1), model.py:206-212) as one pipelined call: layers[0] is the top
+ * layer, driven by dy [N][T][H] or dheads + w_head exactly like uav_lstm_bwd; every layer but the last forms the input
+ * gradient dx [N][T][H] that drives the layer below (its w_ih [4H][H] and dx are required there; the last layer's may be
+ * NULL), and the layer below starts step t as soon as dx[:, t] exists -- each layer runs on its own internal stream one step
+ * behind the one above, joined to `stream` before the call returns control of it.  Same kernels and results as one
+ * uav_lstm_bwd per layer, top down.  Needs UAV_BWD_STACKS; 1..4 layers; the layers' dgates must be distinct arrays. */
+typedef struct uav_lstm_bwd_layer {
+    const float* keep;     /* [N][T] or NULL */
+    const float* stash;    /* [N][T][6H] */
+    const float* w_hh;     /* [4H][H] */
+    const float* w_ih;     /* [4H][H]; NULL for the last layer */
+    float* dgates;         /* [N][T][4H] out */
+    float* dx;             /* [N][T][H] out; NULL for the last layer */
+    const float* dhn;      /* [N][H] or NULL */
+    const float* dcn;      /* [N][H] or NULL */
+    float* dh0;            /* [N][H] out or NULL */
+    float* dc0;            /* [N][H] out or NULL */
+} uav_lstm_bwd_layer;
+int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
+                       const float* w_head, int n_heads, int N, int T, int H, uav_stream stream);
 /* Time-batched weight gradients from dgates in ONE fused pass (csrc/wgrad.hip):
  * dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev with Hprev[n][t] = y[n][t-1]*keep[n][t]
  * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh) and -- when dheads != NULL (top layer) --

@@ -448,6 +448,20 @@ def test_stepper_rollout_equals_per_call_rollout_and_is_adopted():
         assert torch.equal(a.policy.flat, b.policy.flat), it
 
 
+def test_pipelined_stack_backward_equals_layer_by_layer():
+    """uav_lstm_bwd_stack (the layers' BPTTs pipelined on internal streams, the layer below one step behind the one above)
+    runs the kernels of one uav_lstm_bwd per layer: after two iterations (4 optimiser steps) the parameters are BIT-identical."""
+    from uavppo.trainer import VecPPOTrainer
+    mk = lambda: VecPPOTrainer(80, 12, "lstm", hidden=256, layers=2, variant="v2.1", device=DEV, seed=7, trend_k=2, epochs=2)
+    a, b = mk(), mk()
+    b.policy.use_stack_bwd = False
+    for it in range(2):
+        a.train_iteration(); b.train_iteration()
+        assert torch.equal(a.policy.grad, b.policy.grad), it
+        assert torch.equal(a.policy.flat, b.policy.flat), it
+    assert "dgates0" in a.work and "dgates0" not in b.work
+
+
 def test_c5_trend_policy_trains():
     """C5 shape family with the trend channels: obs_dim 8, stacked h=256 LSTM, step-wise rollout."""
     from uavppo.trainer import VecPPOTrainer

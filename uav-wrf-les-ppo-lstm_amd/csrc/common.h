@@ -14,6 +14,8 @@ struct uav_ctx {
     size_t ws_bytes;
     double* pow075;    // device table pow(i, 0.75), i = 0..5000 (env_core.h)
     int lstm_arith;    // UAV_ARITH_*: how the LSTM sequence kernels evaluate their f32 matrix products (uav_set_lstm_arith)
+    hipStream_t side[3];      // uav_lstm_bwd_stack: one stream per layer below the top (created on first use)
+    hipEvent_t side_ev[8];    // fork / join + a small ring of per-step hand-off events per side stream
 };
 
 // arithmetic of the call in flight on this thread (set from ctx->lstm_arith by the LSTM entry points; the launch helpers

@@ -55,6 +55,10 @@ int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; 
 
 void uav_destroy(uav_ctx* ctx) {
     if (!ctx) return;
+    for (auto& e : ctx->side_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& s : ctx->side)
+        if (s) (void)hipStreamDestroy(s);
     (void)hipFree(ctx->ws);
     (void)hipFree(ctx->pow075);
     delete ctx;

@@ -51,6 +51,9 @@ int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const 
                      const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0, float* dc0,
                      const float* w_ih, int I, float* dx, hipStream_t st);
 int lstm_generic_bwd_caps(int I, int H);
+bool lstm_h3_stack_ok(int H);
+int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
+                      const float* w_head, int n_heads, int N, int T, hipStream_t st);
 int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
                      const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
                      float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
@@ -1997,6 +2000,17 @@ int uav_lstm_bwd_caps(uav_ctx* ctx, int I, int H) {
     if (H == 64 || H == 128) return UAV_BWD_TAKES_DHEADS;            // the persistent sequence kernels
     g_uav_arith = ctx->lstm_arith;
     return lstm_generic_bwd_caps(I, H);
+}
+
+int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
+                       const float* w_head, int n_heads, int N, int T, int H, uav_stream stream) {
+    UAV_REQUIRE(ctx && layers, "uav_lstm_bwd_stack: NULL argument");
+    g_uav_arith = ctx->lstm_arith;
+    UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd_stack: give exactly one of dy / dheads");
+    UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd_stack: dheads needs w_head and 1..8 heads");
+    UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd_stack: N=%d T=%d", N, T);
+    UAV_REQUIRE(H == 256 && lstm_h3_stack_ok(H), "uav_lstm_bwd_stack: H = 256 on the fp16-split arithmetic only (uav_lstm_bwd_caps)");
+    return lstm_h3_bwd_stack(ctx, n_layers, layers, dy, dheads, w_head, n_heads, N, T, as_stream(stream));
 }
 
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,

@@ -822,44 +822,121 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
 
 }  // extern "C"
 
-static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
-                       const float* dheads, const float* w_head, int n_heads,
-                       const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
-                       const float* w_ih, float* dx, hipStream_t st) {
-    constexpr int H = 256;
-    const int64_t NH = (int64_t)N * H;
-    // tail of the workspace: dh, dc f32 | dG pieces [2][N][4H] | inv_scale [N] | W_hh^T pieces [2][H][4H]
-    const int64_t NP = (int64_t)(N + 63) / 64 * 64 * H;
-    const size_t need = (size_t)(2 * NH) * 4 + (size_t)(2 * 4 * NP) * 2 + (size_t)((N + 63) / 64 * 64) * 4 * 2 + (size_t)2 * 2 * 4 * H * H * 2;
-    UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
-    char* base = (char*)ctx->ws + ctx->ws_bytes - need;
-    float* dh = (float*)base;
-    float* dc = dh + NH;
-    unsigned short* dgp = (unsigned short*)(dc + NH);
-    float* inv_scale = (float*)(dgp + 2 * 4 * NP);
-    unsigned short* wtp = (unsigned short*)(inv_scale + 2 * ((N + 63) / 64 * 64));      // [masked | unmasked] inverse scales
-    unsigned short* wxtp = wtp + (size_t)2 * 4 * H * H;                                 // W_ih^T pieces (dx fused, I = H)
-    const unsigned nb = (unsigned)((NH + 255) / 256);
-    UAV_CHECK_HIP(hipMemsetAsync(dgp, 0, (size_t)2 * 4 * NP * 2, st));
-    static bool cell_attr = false;
-    if (!cell_attr) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)CELL_BWD_LDS));
-        cell_attr = true;
+// One layer's BPTT on the step path: its slice of the workspace, the launches before the time loop, one time step, the end.
+struct H3Bwd {
+    static constexpr int H = 256;
+    const float *keep, *stash, *dy, *dheads, *w_head;
+    int n_heads, N, T;
+    float *dgates, *dx;
+    float *dh, *dc, *inv_scale;
+    unsigned short *dgp, *wtp, *wxtp;
+    // dh, dc f32 | dG pieces [2][N][4H] | inverse scales [masked | unmasked][N] | W_hh^T, W_ih^T pieces [2][H][4H] each
+    static size_t need(int N) {
+        const size_t NH = (size_t)N * H, NP = (size_t)(N + 63) / 64 * 64 * H;
+        return (2 * NH) * 4 + (2 * 4 * NP) * 2 + (size_t)((N + 63) / 64 * 64) * 4 * 2 + (size_t)2 * 2 * 4 * H * H * 2;
     }
-    hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 1, wtp);
-    if (dx) hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_ih, 4 * H, H, H, 1, wxtp);
-    hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh, dhn, NH);
-    hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
-    const dim3 grid((N + 63) / 64, H / 64);
-    for (int t = T - 1; t >= 0; --t) {
-        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 15) / 16), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head, n_heads, N, T, t, dh, dc, dgates, dgp, inv_scale);
+    int prepare(char* base, const float* w_hh, const float* w_ih, const float* dhn, const float* dcn, hipStream_t st) {
+        const int64_t NH = (int64_t)N * H, NP = (int64_t)(N + 63) / 64 * 64 * H;
+        dh = (float*)base;
+        dc = dh + NH;
+        dgp = (unsigned short*)(dc + NH);
+        inv_scale = (float*)(dgp + 2 * 4 * NP);
+        wtp = (unsigned short*)(inv_scale + 2 * ((N + 63) / 64 * 64));
+        wxtp = wtp + (size_t)2 * 4 * H * H;
+        const unsigned nb = (unsigned)((NH + 255) / 256);
+        UAV_CHECK_HIP(hipMemsetAsync(dgp, 0, (size_t)2 * 4 * NP * 2, st));
+        hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 1, wtp);
+        if (dx) hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_ih, 4 * H, H, H, 1, wxtp);
+        hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh, dhn, NH);
+        hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
+        return 0;
+    }
+    void step(int t, hipStream_t st) const {
+        const dim3 grid((N + 63) / 64, H / 64);
+        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 15) / 16), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head,
+                           n_heads, N, T, t, dh, dc, dgates, dgp, inv_scale);
         if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh, wxtp, dx, T, t);
         else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh,
                                 (const unsigned short*)nullptr, (float*)nullptr, T, t);
     }
-    if (dh0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh0, dh, NH);
-    if (dc0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc0, dc, NH);
+    void finish(float* dh0, float* dc0, hipStream_t st) const {
+        const int64_t NH = (int64_t)N * H;
+        const unsigned nb = (unsigned)((NH + 255) / 256);
+        if (dh0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh0, dh, NH);
+        if (dc0) hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc0, dc, NH);
+    }
+};
+static int h3_bwd_attr() {
+    static bool cell_attr = false;
+    if (!cell_attr) {
+        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)CELL_BWD_LDS));
+        cell_attr = true;
+    }
+    return 0;
+}
+
+static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
+                       const float* dheads, const float* w_head, int n_heads,
+                       const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
+                       const float* w_ih, float* dx, hipStream_t st) {
+    const size_t need = H3Bwd::need(N);
+    UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
+    int rc;
+    if ((rc = h3_bwd_attr())) return rc;
+    H3Bwd L{keep, stash, dy, dheads, w_head, n_heads, N, T, dgates, dx};
+    if ((rc = L.prepare((char*)ctx->ws + ctx->ws_bytes - need, w_hh, w_ih, dhn, dcn, st))) return rc;
+    for (int t = T - 1; t >= 0; --t) L.step(t, st);
+    L.finish(dh0, dc0, st);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// The BPTTs of a stack of layers as a pipeline: the layer below can run step t as soon as the layer above has produced
+// dx[:, t] (its step_bwd<DX>), so each layer gets its own stream and follows the one above by one step.  The gate-gradient
+// kernel is HBM-bound and the recurrent product waits on L2 latency: two layers' kernels share the CUs and overlap (two
+// independent passes on two streams: 53.9 us per step pair against 63.9 on one, tools/perf_bwd_overlap.py).  Same kernels,
+// same arithmetic, same results as one uav_lstm_bwd per layer, top down.
+int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
+                      const float* w_head, int n_heads, int N, int T, hipStream_t st) {
+    UAV_REQUIRE(nl >= 1 && nl <= 4, "uav_lstm_bwd_stack: 1..4 layers, got %d", nl);
+    const size_t need = H3Bwd::need(N);
+    UAV_REQUIRE((size_t)nl * need + (64u << 20) <= ctx->ws_bytes, "uav_lstm_bwd_stack: workspace too small for %d layers", nl);
+    int rc;
+    if ((rc = h3_bwd_attr())) return rc;
+    for (int l = 0; l + 1 < nl; ++l)
+        if (!ctx->side[l]) UAV_CHECK_HIP(hipStreamCreateWithFlags(&ctx->side[l], hipStreamNonBlocking));
+    for (auto& e : ctx->side_ev)
+        if (!e) UAV_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipStream_t str[4] = {st, ctx->side[0], ctx->side[1], ctx->side[2]};
+    // fork: the side streams start behind everything the caller has queued
+    UAV_CHECK_HIP(hipEventRecord(ctx->side_ev[0], st));
+    for (int l = 1; l < nl; ++l) UAV_CHECK_HIP(hipStreamWaitEvent(str[l], ctx->side_ev[0], 0));
+    H3Bwd L[4];
+    for (int l = 0; l < nl; ++l) {
+        const uav_lstm_bwd_layer& a = layers[l];
+        UAV_REQUIRE(a.stash && a.w_hh && a.dgates, "uav_lstm_bwd_stack: layer %d: NULL stash / w_hh / dgates", l);
+        UAV_REQUIRE(l + 1 == nl || (a.w_ih && a.dx), "uav_lstm_bwd_stack: layer %d feeds the layer below: w_ih and dx are required", l);
+        L[l] = H3Bwd{a.keep, a.stash, l == 0 ? dy : layers[l - 1].dx, l == 0 ? dheads : nullptr, l == 0 ? w_head : nullptr,
+                     l == 0 ? n_heads : 0, N, T, a.dgates, a.dx};
+        if ((rc = L[l].prepare((char*)ctx->ws + ctx->ws_bytes - (size_t)(l + 1) * need, a.w_hh, a.w_ih, a.dhn, a.dcn, str[l]))) return rc;
+    }
+    // the wave front: at round r layer l runs its step T - 1 - (r - l); the hand-off events form a ring per boundary
+    hipEvent_t* ring = ctx->side_ev + 2;                       // 6 events: two per boundary
+    for (int r = 0; r < T + nl - 1; ++r)
+        for (int l = 0; l < nl; ++l) {
+            const int t = T - 1 - (r - l);
+            if (t < 0 || t >= T) continue;
+            if (l > 0) UAV_CHECK_HIP(hipStreamWaitEvent(str[l], ring[2 * (l - 1) + (t & 1)], 0));   // dx[:, t] of the layer above
+            L[l].step(t, str[l]);
+            if (l + 1 < nl) UAV_CHECK_HIP(hipEventRecord(ring[2 * l + (t & 1)], str[l]));
+        }
+    for (int l = 0; l < nl; ++l) L[l].finish(layers[l].dh0, layers[l].dc0, str[l]);
+    // join
+    for (int l = 1; l < nl; ++l) {
+        UAV_CHECK_HIP(hipEventRecord(ctx->side_ev[1], str[l]));
+        UAV_CHECK_HIP(hipStreamWaitEvent(st, ctx->side_ev[1], 0));
+    }
     UAV_LAUNCH_CHECK();
     return 0;
 }
@@ -889,7 +966,8 @@ int lstm_generic_fwd(uav_ctx* ctx, const float* keep, const float* h0, const flo
 bool lstm_h3_bwd_fuses_dx(int I, int H) { return h3_step_ok(H) && I == H; }
 
 // what the generic / step paths of uav_lstm_bwd can do themselves: bit 0 form dx (I == H on the step path), bit 1 take dheads
-int lstm_generic_bwd_caps(int I, int H) { return h3_step_ok(H) ? ((I == H ? 1 : 0) | 2) : 0; }
+int lstm_generic_bwd_caps(int I, int H) { return h3_step_ok(H) ? ((I == H ? 1 | 4 : 0) | 2) : 0; }
+bool lstm_h3_stack_ok(int H) { return h3_step_ok(H); }
 
 int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                      const float* dheads, const float* w_head, int n_heads,

@@ -26,6 +26,11 @@ class EnvCfg(C.Structure):
                 ("seed", C.c_uint64), ("bank", C.c_void_p), ("bank_src", C.c_void_p)]
 
 
+class LstmBwdLayer(C.Structure):
+    """struct uav_lstm_bwd_layer (include/uavppo.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("keep", "stash", "w_hh", "w_ih", "dgates", "dx", "dhn", "dcn", "dh0", "dc0")]
+
+
 # name -> (restype, argtypes); mirrors include/uavppo.h one to one
 SIGNATURES = {
     "uav_abi_version": (I32, []),
@@ -64,6 +69,7 @@ SIGNATURES = {
     "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd_caps": (I32, [P, I32, I32]),
+    "uav_lstm_bwd_stack": (I32, [P, I32, P, P, P, P, I32, I32, I32, I32, P]),
     "uav_lstm_wgrad": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),
     "uav_env_reset": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P]),

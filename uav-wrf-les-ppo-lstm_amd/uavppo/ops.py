@@ -486,15 +486,39 @@ def lstm_bwd_caps(device, I, H):
     return int(lib().uav_lstm_bwd_caps(Context.get(torch.device(device)).handle, int(I), int(H)))
 
 
+def lstm_bwd_stack(layers, keep, dy=None, dheads=None, w_head=None):
+    """uav_lstm_bwd_stack: the BPTTs of a stack of h = 256 layers as one pipelined call.  layers: top first, dicts with
+    stash [N,T,6H], w_hh, w_ih (None for the last), dgates [N,T,4H] (distinct per layer), dx [N,T,H] (None for the last)."""
+    N, T, H6 = layers[0]["stash"].shape
+    H = H6 // 6
+    arr = (_lib.LstmBwdLayer * len(layers))()
+    for a, d in zip(arr, layers):
+        a.keep = None if keep is None else _p(keep, F32, (N, T), "keep").value
+        a.stash = _p(d["stash"], F32, (N, T, 6 * H), "stash").value
+        a.w_hh = _p(d["w_hh"], F32, (4 * H, H), "w_hh").value
+        a.w_ih = None if d.get("w_ih") is None else _p(d["w_ih"], F32, (4 * H, H), "w_ih").value
+        a.dgates = _p(d["dgates"], F32, (N, T, 4 * H), "dgates").value
+        a.dx = None if d.get("dx") is None else _p(d["dx"], F32, (N, T, H), "dx").value
+        a.dhn = a.dcn = a.dh0 = a.dc0 = None
+    nh = 0 if dheads is None else dheads.shape[-1]
+    _t = KERNEL_TIMER.bracket("lstm_bwd")
+    check(lib().uav_lstm_bwd_stack(_h(layers[0]["stash"]), len(layers), C.byref(arr), _p(dy, F32, (N, T, H), "dy"),
+                                   _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh, N, T, H, _stream()),
+          "uav_lstm_bwd_stack")
+    if _t is not None:
+        _t.record()
+
+
 def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
-             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None):
+             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None, bwd_done=False):
     """BPTT sequence kernel + fused weight-gradient pass of one layer.  y, h0: the layer's forward
-    output and initial hidden state (h_prev of the weight gradient is y shifted by one step)."""
+    output and initial hidden state (h_prev of the weight gradient is y shifted by one step).
+    bwd_done: dgates (and the dx a layer above needs) were already produced by lstm_bwd_stack: only the weight gradients."""
     N, T, I = x.shape
     H = w_hh.shape[1]
     dev = x.device
     dgates = torch.empty(N, T, 4 * H, dtype=F32, device=dev) if dgates is None else dgates
-    dx = torch.empty(N, T, I, dtype=F32, device=dev) if need_dx else None
+    dx = torch.empty(N, T, I, dtype=F32, device=dev) if (need_dx and not bwd_done) else None
     dw_ih = torch.empty(4 * H, I, dtype=F32, device=dev) if dw_ih is None else dw_ih
     dw_hh = torch.empty(4 * H, H, dtype=F32, device=dev) if dw_hh is None else dw_hh
     db = torch.empty(4 * H, dtype=F32, device=dev) if db is None else db
@@ -507,15 +531,16 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     if wgrad_dheads is not None and dw_head is None:
         dw_head = torch.empty(nhw, H, dtype=F32, device=dev)
     # the h = 256 step path forms dx = dG W_ih inside its per-step recurrent product (same dG fragments) when I == H
-    dx_in_bwd = bool(need_dx and lstm_bwd_caps(x.device, I, H) & 1)
-    _t = KERNEL_TIMER.bracket("lstm_bwd")
-    check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
-                             _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
-                             _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh,
-                             _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, H,
-                             _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dh0), _p(dc0),
-                             _p(w_ih, F32, (4 * H, I), "w_ih") if dx_in_bwd else None, I, _p(dx) if dx_in_bwd else None,
-                             _stream()), "uav_lstm_bwd")
+    dx_in_bwd = bool(need_dx and lstm_bwd_caps(x.device, I, H) & 1) or bwd_done
+    _t = None if bwd_done else KERNEL_TIMER.bracket("lstm_bwd")
+    if not bwd_done:
+        check(lib().uav_lstm_bwd(_h(x), _p(keep, F32, (N, T), "keep"), _p(stash, F32, (N, T, 6 * H), "stash"),
+                                 _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
+                                 _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh,
+                                 _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, H,
+                                 _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dh0), _p(dc0),
+                                 _p(w_ih, F32, (4 * H, I), "w_ih") if dx_in_bwd else None, I, _p(dx) if dx_in_bwd else None,
+                                 _stream()), "uav_lstm_bwd")
     if _t is not None:
         _t.record()
     _t = KERNEL_TIMER.bracket("lstm_wgrad")

@@ -257,7 +257,35 @@ class LSTMActorCritic(_FlatPolicy):
             ops.colsum(dheads, out=g["head.bias"])
         dy = None
         top_in = self.obs_dim if self.num_layers == 1 else self.hidden
-        fused_heads = bool(ops.lstm_bwd_caps(dheads.device, top_in, self.hidden) & 2)   # dy = dheads . W_head formed on chip
+        caps = ops.lstm_bwd_caps(dheads.device, top_in, self.hidden)
+        fused_heads = bool(caps & 2)                 # dy = dheads . W_head formed on chip
+        L = self.num_layers
+        if L >= 2 and (caps & 4) and getattr(self, "use_stack_bwd", True):
+            # h = 256 stack: all layers' BPTTs as ONE pipelined call (uav_lstm_bwd_stack: the layer below follows the one
+            # above by one step on its own stream, the HBM-bound gate-gradient kernel of one layer under the latency-bound
+            # recurrent product of the other), then the weight gradients layer by layer
+            specs = []
+            for l in reversed(range(L)):
+                x, stash, y, h0 = saved[l]
+                key = f"dgates{l}"
+                if work.get(key) is None or work[key].shape[0] != N:
+                    work[key] = work["dgates"] if (l == L - 1 and work.get("dgates") is not None and work["dgates"].shape[0] == N) \
+                        else torch.empty(N, T, 4 * H, dtype=torch.float32, device=dheads.device)
+                if l > 0 and (work.get(f"dx{l}") is None or work[f"dx{l}"].shape[0] != N):
+                    work[f"dx{l}"] = torch.empty(N, T, H, dtype=torch.float32, device=dheads.device)
+                specs.append({"stash": stash, "w_hh": v[f"lstm.weight_hh_l{l}"], "w_ih": v[f"lstm.weight_ih_l{l}"] if l > 0 else None,
+                              "dgates": work[key], "dx": work[f"dx{l}"] if l > 0 else None})
+            ops.lstm_bwd_stack(specs, keep, dheads=dheads.view(N, T, -1), w_head=v["head.weight"])
+            for l in reversed(range(L)):
+                x, stash, y, h0 = saved[l]
+                top = (l == L - 1)
+                ops.lstm_bwd(x, keep, stash, v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"], y, h0,
+                             wgrad_dheads=dheads.view(N, T, -1) if top else None, dgates=work[f"dgates{l}"],
+                             dw_ih=g[f"lstm.weight_ih_l{l}"], dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"],
+                             dw_head=g["head.weight"] if top else None, want_dstate=False, bwd_done=True)
+                g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
+            self._saved = None
+            return self.grad
         if not fused_heads:
             if work.get("dy") is None or work["dy"].shape[0] != N * T:
                 work["dy"] = torch.empty(N * T, H, dtype=torch.float32, device=dheads.device)
