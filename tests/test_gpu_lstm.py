@@ -431,3 +431,38 @@ def test_lstm_stepper_two_layers_through_piece_planes(ops):
     assert torch.equal(ys[0], y1) and torch.equal(ss[0], st1)
     assert torch.equal(ys[1], y2) and torch.equal(ss[1], st2)
     assert torch.equal(sp[1].hn, hn2) and torch.equal(sp[1].cn, cn2)
+
+
+def test_lstm_bwd_stack_three_layers_equals_per_layer_calls(ops):
+    """uav_lstm_bwd_stack pipelines the layers' BPTTs on internal streams (layer l + 1 from the top starts step t when layer
+    l has produced dx[:, t]); three layers exercise the whole wave front.  Gate gradients and input gradients are
+    BIT-identical to one uav_lstm_bwd per layer, top down."""
+    H, N, T = 256, 48, 9
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *shape: (torch.randn(*shape, generator=g) * 0.1).to(DEV)
+    keep = (torch.rand(N, T, generator=g) > 0.2).float()
+    keep[:, 0] = 1.0
+    keep = keep.to(DEV)
+    x = mk(N, T, H)
+    W = [(mk(4 * H, H), mk(4 * H, H), mk(4 * H), mk(4 * H)) for _ in range(3)]
+    stashes, ys = [], []
+    for l in range(3):                                   # bottom -> top forward
+        y, _, _, st = ops.lstm_fwd(x if l == 0 else ys[-1], keep, mk(N, H), mk(N, H), *W[l])
+        ys.append(y); stashes.append(st)
+    dy = (torch.randn(N, T, H, generator=g) * 1e-4).to(DEV)
+    # reference: one call per layer, top down, dx fused into the backward
+    assert ops.lstm_bwd_caps(DEV, H, H) & 4
+    ref_dg, ref_dx, cur = {}, {}, dy
+    for l in (2, 1, 0):
+        r = ops.lstm_bwd(x if l == 0 else ys[l - 1], keep, stashes[l], W[l][0], W[l][1], ys[l], torch.zeros(N, H, device=DEV), dy=cur,
+                         need_dx=(l > 0), want_dstate=False)
+        ref_dg[l], ref_dx[l] = r["dgates"].clone(), None if r["dx"] is None else r["dx"].clone()
+        cur = r["dx"]
+    specs = [{"stash": stashes[l], "w_hh": W[l][1], "w_ih": W[l][0] if l > 0 else None,
+              "dgates": torch.zeros(N, T, 4 * H, device=DEV), "dx": torch.zeros(N, T, H, device=DEV) if l > 0 else None} for l in (2, 1, 0)]
+    ops.lstm_bwd_stack(specs, keep, dy=dy)
+    torch.cuda.synchronize()
+    for s, l in zip(specs, (2, 1, 0)):
+        assert torch.equal(s["dgates"], ref_dg[l]), l
+        if l > 0:
+            assert torch.equal(s["dx"], ref_dx[l]), l
