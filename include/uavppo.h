@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 3   /* 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 3   /* 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
