@@ -13,6 +13,7 @@ struct uav_ctx {
     void* ws;          // scratch for two-stage reductions / split-K slabs
     size_t ws_bytes;
     double* pow075;    // device table pow(i, 0.75), i = 0..5000 (env_core.h)
+    double* wave;      // device tables sin(0.05 x) | cos(0.07 y), x, y = 0..499 (env_core.h field_at)
     int lstm_arith;    // UAV_ARITH_*: how the LSTM sequence kernels evaluate their f32 matrix products (uav_set_lstm_arith)
     hipStream_t side[3];      // uav_lstm_bwd_stack: one stream per layer below the top (created on first use)
     hipEvent_t side_ev[8];    // fork / join + a small ring of per-step hand-off events per side stream

@@ -31,6 +31,7 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->num_cu = prop.multiProcessorCount;
     c->ws_bytes = ws_bytes;
     c->pow075 = nullptr;
+    c->wave = nullptr;
     c->lstm_arith = UAV_ARITH_FP16X3;
     if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
         delete c;
@@ -39,6 +40,8 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     }
     if (env_init_tables(c) != 0) {
         (void)hipFree(c->ws);
+        (void)hipFree(c->pow075);
+        (void)hipFree(c->wave);
         delete c;
         return 1;
     }
@@ -61,6 +64,7 @@ void uav_destroy(uav_ctx* ctx) {
         if (s) (void)hipStreamDestroy(s);
     (void)hipFree(ctx->ws);
     (void)hipFree(ctx->pow075);
+    (void)hipFree(ctx->wave);
     delete ctx;
 }
 

@@ -11,6 +11,14 @@ int env_init_tables(uav_ctx* ctx) {
     for (int i = 0; i < POW_TABLE_N; ++i) t[i] = pow((double)i, 0.75);
     UAV_CHECK_HIP(hipMalloc(&ctx->pow075, sizeof(double) * POW_TABLE_N));
     UAV_CHECK_HIP(hipMemcpy(ctx->pow075, t.data(), sizeof(double) * POW_TABLE_N, hipMemcpyHostToDevice));
+    // the deterministic ripple of environment.py:58, 0.3*sin(0.05*x)*cos(0.07*y): its two factors over the grid
+    std::vector<double> wv(2 * GRID);
+    for (int i = 0; i < GRID; ++i) {
+        wv[i] = sin(0.05 * (double)i);
+        wv[GRID + i] = cos(0.07 * (double)i);
+    }
+    UAV_CHECK_HIP(hipMalloc(&ctx->wave, sizeof(double) * 2 * GRID));
+    UAV_CHECK_HIP(hipMemcpy(ctx->wave, wv.data(), sizeof(double) * 2 * GRID, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -41,6 +49,7 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
     P.bank = cfg->bank;
     P.bank_src = cfg->bank_src;
     P.pow075 = ctx->pow075;
+    P.wave = ctx->wave;
     return 0;
 }
 

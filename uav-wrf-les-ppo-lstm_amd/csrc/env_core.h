@@ -24,6 +24,7 @@ struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived c
     const double* bank;       // [F][GRID][GRID][2]
     const double* bank_src;   // [F][2]
     const double* pow075;     // [POW_TABLE_N] host-libm pow(i, 0.75)
+    const double* wave;       // [2][GRID] host-libm sin(0.05 x) | cos(0.07 y) of environment.py:58
 };
 
 struct EnvState {             // registers of one env
@@ -77,16 +78,20 @@ __device__ __forceinline__ int clipi(int v) { return v < 0 ? 0 : (v > GRID - 1 ?
 // is the very double the reference's `visit_count**0.75` produces; also keeps f64 pow out of the kernels.
 constexpr int POW_TABLE_N = 5001;      // table pointer travels in EnvParams (owned by the uav_ctx)
 
-// two standard normals from one Philox block (Box-Muller).  Counter-RNG noise is validated
-// statistically only (parity runs inject noise), so the transcendental part is f32 fast-math:
-// it keeps the persistent rollout kernel's register footprint small.
+// two standard normals from one Philox block: Box-Muller in f64 on 24-bit uniforms, u1 in (0,1], u2 in [0,1):
+// z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = ... sin(2 pi u2).  oracle/procedural_oracle.py restates exactly this from the
+// same draws (numpy f64), so the procedural mode is pinned to libm accuracy (1e-15), not statistically.
+__device__ __forceinline__ double bm_radius(uint32_t a) {
+    const double u1 = ((double)(a >> 8) + 1.0) * (1.0 / 16777216.0);      // (0,1]
+    return sqrt(-2.0 * log(u1));
+}
 __device__ __forceinline__ void normal2(const Philox4& r, double& z0, double& z1) {
-    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0,1]
-    const float u2 = (float)(r.y >> 8) * (1.0f / 16777216.0f);               // [0,1)
-    const float rad = sqrtf(-2.0f * __logf(u1));
-    const float ang = 6.2831853071795865f * u2;
-    z0 = (double)(rad * __cosf(ang));
-    z1 = (double)(rad * __sinf(ang));
+    const double rad = bm_radius(r.x);
+    const double u2 = (double)(r.y >> 8) * (1.0 / 16777216.0);            // [0,1)
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
 }
 
 // E3: concentration and 'tke' at integer cell (x, y)
@@ -99,16 +104,16 @@ __device__ __forceinline__ void field_at(const EnvParams& P, int env_global, con
         tke = v.y;
         return;
     }
-    // procedural: |N(0,1)| and U[0,1) of this (env, episode, cell) from the counter RNG; f32 fast-math
-    // transcendentals (statistical mode), the combination itself in f64 like the reference
+    // procedural: |N(0,1)| and U[0,1) of this (env, episode, cell) from the counter RNG, then the reference's formula in
+    // f64 with its own operation order (environment.py:52-61); sin(0.05 x), cos(0.07 y) from the host-libm tables
     const Philox4 r = philox4x32_10(P.seed, (uint32_t)(x * GRID + y), (uint32_t)env_global, (uint32_t)s.episode, RNG_FIELD);
-    const float u1 = ((float)(r.x >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float g = sqrtf(-2.0f * __logf(u1)) * __cosf(6.2831853071795865f * ((float)(r.y >> 8) * (1.0f / 16777216.0f)));
+    const double g = bm_radius(r.x) * cospi(2.0 * ((double)(r.y >> 8) * (1.0 / 16777216.0)));
     const double u = (double)r.w * (1.0 / 4294967296.0);
-    const float wave = 0.3f * __sinf(0.05f * (float)x) * __cosf(0.07f * (float)y);
-    tke = 3.0 * ((double)fabsf(g) + (double)wave + 0.2 * u);                        // environment.py:56-60
-    const float dx = (float)x - (float)s.sx, dy = (float)y - (float)s.sy;
-    const double base = 100.0 * (double)__expf(-(dx * dx + dy * dy) / (float)P.two_sigma2);   // :53-54
+    const double wave = (0.3 * P.wave[x]) * P.wave[GRID + y];
+    tke = 3.0 * ((fabs(g) + wave) + 0.2 * u);                                       // :56-60
+    const double dx = (double)x - s.sx, dy = (double)y - s.sy;
+    const double dist = sqrt(dx * dx + dy * dy);                                    // :53
+    const double base = 100.0 * exp(-(dist * dist) / P.two_sigma2);                 // :54 (V2.1 :56)
     const double c = base + tke;
     conc = c < 0.0 ? 0.0 : (c > 100.0 ? 100.0 : c);                                  // :61
 }
