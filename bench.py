@@ -13,8 +13,9 @@ update (forward, loss, BPTT, weight gradients, grad all-reduce, clip+Adam) and t
 update.
 
 --scaling weak (default): every rank owns the config's env count (4096 at C3); value = all ranks' env-steps /
-max-over-ranks time.  With more than one rank the same run ALSO times the strong-scaling shape (the config's env
-count split over the ranks, SURVEY 8d "strong scaling for C3") and reports it under "strong_scaling".
+max-over-ranks time.  Started plainly with --gpus N > 1 (launcher mode) the strong-scaling shape (the config's env count
+split over the ranks, SURVEY 8d "strong scaling for C3") is timed afterwards in a SECOND set of fresh rank processes and
+reported under "strong_scaling"; rank processes themselves (torchrun) time exactly one shape.
 --scaling strong: the split shape is the headline value.
 """
 import argparse
@@ -45,6 +46,8 @@ PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: exact-f32 MFMA = the f32 vector rate
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA ~2.5 PFLOP/s
 NHEADS = 6                       # 5 logits + value
+# the reference's MLP policy: products of the fused gradient / rollout kernels and the pipe they execute on
+MLP_EXEC_MULT, MLP_EXEC_PEAK = 1, PEAK_F32_MFMA_TFLOPS      # exact-f32 MFMA (v_mfma_f32_16x16x4_f32)
 # algorithmic bytes per env-step: rollout write 44, GAE 20 (12 read + 8 written), update 44 read per epoch
 ALG_ROLLOUT_B, ALG_GAE_B, ALG_UPDATE_B = 44, 20, 44
 
@@ -58,19 +61,22 @@ def free_port():
     return port
 
 
-def spawn_ranks(n, cmd, extra_env=None, timeout=None):
+def spawn_ranks(n, cmd, extra_env=None, timeout=None, capture_rank0=False):
     """Start `cmd` n times as FRESH child processes (one per rank, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
-    environment), wait for all, return the largest exit code.  The caller must not have touched the GPU: a rank
-    process initialises HIP itself, nothing is re-exec'ed from a process that already did.  If one rank fails the
-    others are terminated (by PID) so a dead peer never leaves the rest waiting in a collective."""
+    environment), wait for all, return (largest exit code, rank 0's stdout or None).  The caller must not have touched
+    the GPU: a rank process initialises HIP itself, nothing is re-exec'ed from a process that already did.  If one rank
+    fails -- or the set outlives `timeout` seconds -- the others are terminated (by PID) so a dead peer never leaves the
+    rest waiting in a collective."""
+    import tempfile
     env = dict(os.environ)
     env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
     env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(n))
     procs = []
+    out0 = tempfile.TemporaryFile() if capture_rank0 else None
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=out0 if (r == 0 and out0) else None))
     t0 = time.time()
     rc = 0
     live = set(range(n))
@@ -81,7 +87,7 @@ def spawn_ranks(n, cmd, extra_env=None, timeout=None):
                 live.discard(r)
                 if code != 0:
                     rc = max(rc, abs(code) or 1)
-        if rc or (timeout and time.time() - t0 > timeout):
+        if live and (rc or (timeout and time.time() - t0 > timeout)):
             for r in live:
                 procs[r].terminate()
             for r in live:
@@ -89,9 +95,57 @@ def spawn_ranks(n, cmd, extra_env=None, timeout=None):
                     procs[r].wait(timeout=20)
                 except subprocess.TimeoutExpired:
                     procs[r].kill()
-            return rc or 124
+            rc = rc or 124
+            break
         time.sleep(0.05)
-    return rc
+    text = None
+    if out0:
+        out0.seek(0)
+        text = out0.read().decode(errors="replace")
+        out0.close()
+    return rc, text
+
+
+def last_json_line(text):
+    for line in reversed((text or "").strip().splitlines()):
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                pass
+    return None
+
+
+def launch(args, argv):
+    """Plain `python bench.py --gpus N` (N > 1): this process never touches the GPU and becomes the launcher.  The headline
+    phase runs in one set of fresh rank processes; the strong-scaling shape, when the headline is weak, in a
+    SECOND set of fresh processes -- so neither phase can slow down, hang or lose the other (round 2's in-process
+    weak -> strong sequence stalled in a shared-GPU rehearsal: DESIGN.md 6).  One JSON line on stdout."""
+    me = [sys.executable, os.path.abspath(__file__)]
+    t0 = time.time()
+    rc, text = spawn_ranks(args.gpus, me + argv, capture_rank0=True)
+    out = last_json_line(text)
+    if rc or out is None:
+        sys.stderr.write(f"[bench] headline phase failed (rc {rc})\n")
+        return rc or 1
+    if args.scaling == "weak" and not args.no_strong_phase:
+        wall = time.time() - t0
+        k2, w2 = max(3, args.steps // 2), min(args.warmup, 2)
+        argv2 = ["--gpus", str(args.gpus), "--config", args.config, "--backend", args.backend, "--scaling", "strong",
+                 "--steps", str(k2), "--warmup", str(w2), "--no-cpu-baseline"]
+        rc2, text2 = spawn_ranks(args.gpus, me + argv2, capture_rank0=True, timeout=max(180.0, 4.0 * wall))
+        o2 = last_json_line(text2)
+        if rc2 == 0 and o2:
+            out["strong_scaling"] = {"value": o2["value"], "unit": o2["unit"], "num_envs_per_gpu": o2["config"]["num_envs_per_gpu"],
+                                     "num_envs_total": o2["config"]["num_envs_total"], "steps": o2["steps"],
+                                     "ms_per_step": o2["ms_per_step"], "rollout_ms": o2["rollout_ms"],
+                                     "ranks": "a second set of fresh rank processes"}
+        else:
+            out["strong_scaling"] = {"error": f"strong-scaling phase failed or timed out (rc {rc2}); the headline value is unaffected"}
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------ CPU baselines
@@ -273,6 +327,8 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
             print(f"[bench] step {k}: host {1e3 * (time.perf_counter() - tk):.1f} ms", file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
+    if verbose == "trace":
+        faulthandler.cancel_dump_traceback_later()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -284,8 +340,23 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
     return dt, roll_ms, summary
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, sorted by name): what a PMC profile was taken ON.  (git is not
+    available on the GPU box -- the snapshot has no .git -- so staleness is decided by content, not by commit.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(tag_glob="r0*_hbm_traffic_pmc.json"):
-    """Newest committed PMC summary under profiles/ (a profiler cannot run inside the timed region)."""
+    """Newest committed PMC summary under profiles/ (a profiler cannot run inside the timed region).  `stale` is True when
+    the kernel sources have changed since the profile was taken (its `_meta.csrc_sha` != today's digest; profiles from
+    before round 3 carry no digest and count as stale): such counter bytes are NOT used for the headline fraction."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", tag_glob)))
     if not files:
@@ -293,44 +364,64 @@ def load_traffic(tag_glob="r0*_hbm_traffic_pmc.json"):
     f = files[-1]
     d = json.load(open(f))
     meta = d.get("_meta", {})
-    return d, {"file": os.path.relpath(f, ROOT), "git_commit": meta.get("git_commit"), "shape": meta.get("shape"),
+    now = csrc_digest()
+    return d, {"file": os.path.relpath(f, ROOT), "git_commit": meta.get("git_commit"), "csrc_sha": meta.get("csrc_sha"),
+               "csrc_sha_now": now, "stale": meta.get("csrc_sha") != now, "shape": meta.get("shape"),
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE x2 (gfx950 "
                          "correction, MI355X_MICROARCH.md HBM), KB -> bytes, averaged per launch"}
 
 
-def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind):
-    """Dominant kernel + whole iteration against both roofs, with SURVEY 8(d)'s algorithmic figures AND the
-    implementation's own traffic / executed flops side by side."""
+def binding_roof(bytes_moved, executed_flops, sec, flop_peak_tflops):
+    """The roof that actually binds: the larger of (bytes moved / 8 TB/s) and (EXECUTED matrix flops / the peak of the
+    pipe they run on).  Returns the top-level roofline fields."""
+    hbm = bytes_moved / sec / 1e9
+    mf = executed_flops / sec / 1e12
+    if hbm / PEAK_HBM_GBPS >= mf / flop_peak_tflops:
+        return {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBPS}
+    return {"bound": "mfma", "achieved": mf, "peak": flop_peak_tflops, "unit": "TFLOP/s", "frac": mf / flop_peak_tflops}
+
+
+def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arith="fp16x3"):
+    """Dominant kernel + whole iteration.  Top level (`bound`, `achieved`, `peak`, `unit`, `frac`) = the roof that binds:
+    HBM on the bytes the kernel actually moves (rocprofv3 counters when the committed profile matches today's kernel
+    sources, otherwise the implementation's byte formula -- `bytes_basis` says which) or the matrix pipe on the flops it
+    actually EXECUTES (three fp16 products per f32 product on the 2.5 PF pipe), whichever fraction is larger.  SURVEY
+    8(d)'s algorithmic figures (f32-equivalent flops against the f32 MFMA peak, 44 B per unit) ride along as sub-fields;
+    the f32 MFMA peak is not a roof for this implementation any more (its f32-equivalent rate exceeds it)."""
     L = max(cfg["layers"], 1)
     units = N * T
     traffic, src = load_traffic()
+    fresh = bool(traffic) and not src["stale"] and cfg is CONFIGS["c3"]
+    # executed products per f32 product and the pipe they run on
+    mult, pipe_peak, pipe = {"fp16x3": (3, PEAK_F16_MFMA_TFLOPS, "fp16 MFMA, 3 piece products per f32 product"),
+                             "bf16x6": (6, PEAK_F16_MFMA_TFLOPS, "bf16 MFMA, 6 piece products per f32 product"),
+                             "f32": (1, PEAK_F32_MFMA_TFLOPS, "exact-f32 MFMA")}[arith]
     out = None
     bwd = timers.get("lstm_bwd")
-    if bwd and kind == "lstm":
+    if bwd and kind == "lstm" and L == 1 and H in (64, 128):
         sec = bwd["avg_ms"] * 1e-3
         kname = "lstm_bwd_h3k_kernel<%d>" % H
         alg_b = ALG_UPDATE_B * units                                   # 8(d): 44 B read per unit per epoch
         impl_b = units * (5 * H + 4 * H + NHEADS + 1) * 4              # stash 5H read + dgates 4H written + dheads + keep
         fl = units * 2 * 4 * H * H                                     # dh_{t-1} = dG W_hh: one forward-equivalent product
-        pmc = None
-        if traffic and cfg is CONFIGS["c3"]:
-            pmc = traffic.get(kname, {}).get("hbm_total_bytes")
-        out = {"kernel": kname, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
-               "unit": "TFLOP/s", "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": pmc, "traffic_source": src,
-               "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
-               "note": "achieved = ALGORITHMIC f32 flops per launch (2*4H*H per env-step) / live HIP-event duration, priced "
-                       "at the dense f32 MFMA peak (dtype f32; SURVEY 8d classes the LSTM as MFMA-bound).  The products are "
-                       "EXECUTED as 3 fp16 MFMA products each: see mfma.executed_*.  hbm.* prices the same launch at the HBM "
-                       "roof, on 8(d)'s algorithmic bytes and on the implementation's own stash/dgates traffic",
-               "mfma": {"algorithmic_f32_tflops": fl / sec / 1e12, "f32_peak_tflops": PEAK_F32_MFMA_TFLOPS,
-                        "frac_f32_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                        "executed_fp16_tflops": 3 * fl / sec / 1e12, "fp16_peak_tflops": PEAK_F16_MFMA_TFLOPS,
-                        "frac_fp16_peak": 3 * fl / sec / 1e12 / PEAK_F16_MFMA_TFLOPS},
-               "hbm": {"algorithmic_bytes": alg_b, "implementation_bytes": impl_b, "implementation_over_algorithmic": impl_b / alg_b,
-                       "achieved_GBps_algorithmic": alg_b / sec / 1e9, "achieved_GBps_implementation": impl_b / sec / 1e9,
-                       "peak_GBps": PEAK_HBM_GBPS, "frac_algorithmic": alg_b / sec / 1e9 / PEAK_HBM_GBPS,
-                       "frac_implementation": impl_b / sec / 1e9 / PEAK_HBM_GBPS,
-                       "pmc_over_algorithmic": (pmc / alg_b) if pmc else None}}
+        pmc = traffic.get(kname, {}).get("hbm_total_bytes") if fresh else None
+        moved = pmc if pmc else impl_b
+        out = {"kernel": kname}
+        out.update(binding_roof(moved, mult * fl, sec, pipe_peak))
+        out.update({"traffic": pmc, "traffic_source": src, "bytes_basis": "pmc" if pmc else "formula (stash 5H read + dgates 4H written + dheads + keep)",
+                    "bytes_per_launch": moved, "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
+                    "note": "frac = the LARGER of (bytes the launch moves / 8 TB/s) and (executed matrix flops / the peak of the pipe "
+                            "they run on: " + pipe + "), duration live from HIP events on the launch stream.  SURVEY 8(d)'s "
+                            "algorithmic figures are under mfma.algorithmic_* and hbm.algorithmic_*",
+                    "mfma": {"algorithmic_f32_tflops": fl / sec / 1e12, "f32_peak_tflops": PEAK_F32_MFMA_TFLOPS,
+                             "frac_f32_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                             "executed_tflops": mult * fl / sec / 1e12, "executed_pipe": pipe, "executed_pipe_peak_tflops": pipe_peak,
+                             "frac_executed_pipe": mult * fl / sec / 1e12 / pipe_peak},
+                    "hbm": {"algorithmic_bytes": alg_b, "implementation_bytes": impl_b, "implementation_over_algorithmic": impl_b / alg_b,
+                            "achieved_GBps_algorithmic": alg_b / sec / 1e9, "achieved_GBps_implementation": impl_b / sec / 1e9,
+                            "peak_GBps": PEAK_HBM_GBPS, "frac_algorithmic": alg_b / sec / 1e9 / PEAK_HBM_GBPS,
+                            "frac_implementation": impl_b / sec / 1e9 / PEAK_HBM_GBPS,
+                            "pmc_over_algorithmic": (pmc / alg_b) if pmc else None}})
     # whole iteration (per GPU): 8(d) per env-step figures x units, against the measured iteration time
     I = 6 + cfg.get("trend_k", 0)
     if kind == "lstm":
@@ -339,32 +430,57 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind):
         # bwd 5H + 4H, wgrad 4H + H (+x), all f32
         impl_it = units * 4 * L * ((6 * H + H) + (epochs - (1 if reused_fwd else 0)) * 7 * H + epochs * (9 * H + 5 * H)) \
             + units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)
+        it_mult, it_peak = mult, pipe_peak
     else:
         fwd_fl = 2 * (I * 256 + 256 * 128 + 128 * NHEADS)
-        impl_it = None
+        impl_it = units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)     # the fused MLP kernels keep everything else on chip
+        it_mult, it_peak = MLP_EXEC_MULT, MLP_EXEC_PEAK
     alg_it = units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)
     fl_it = units * fwd_fl * (1 + 3 * epochs)
-    whole = {"algorithmic_bytes": alg_it, "algorithmic_GBps": alg_it / dt_iter / 1e9,
-             "frac_hbm_algorithmic": alg_it / dt_iter / 1e9 / PEAK_HBM_GBPS,
-             "implementation_bytes_formula": impl_it,
-             "implementation_over_algorithmic": (impl_it / alg_it) if impl_it else None,
-             "implementation_GBps": (impl_it / dt_iter / 1e9) if impl_it else None,
-             "algorithmic_f32_tflops": fl_it / dt_iter / 1e12, "frac_f32_mfma_peak": fl_it / dt_iter / 1e12 / PEAK_F32_MFMA_TFLOPS,
-             "executed_fp16_tflops": (3 * fl_it / dt_iter / 1e12) if kind == "lstm" and H in (64, 128) and L == 1 else None,
-             "frac_fp16_mfma_peak": (3 * fl_it / dt_iter / 1e12 / PEAK_F16_MFMA_TFLOPS) if kind == "lstm" and H in (64, 128) and L == 1 else None}
-    if traffic and cfg is CONFIGS["c3"]:
+    pm = None
+    if fresh:
         def tb(prefix):
             return sum(v["hbm_total_bytes"] for k, v in traffic.items() if k.startswith(prefix))
         pm = tb("rollout_lstm_kernel") + (epochs - (1 if reused_fwd else 0)) * tb("lstm_fwd_h3_kernel") \
             + epochs * (tb("lstm_bwd_h3k_kernel") + tb("lstm_wgrad_h3_kernel") + tb("ppo_loss_kernel") + tb("wgrad_reduce_kernel"))
+    whole = binding_roof(pm if pm else impl_it, it_mult * fl_it, dt_iter, it_peak)
+    whole.update({"bytes_basis": "pmc (big kernels)" if pm else "formula", "bytes_per_iteration": pm if pm else impl_it,
+                  "algorithmic_bytes": alg_it, "algorithmic_GBps": alg_it / dt_iter / 1e9,
+                  "frac_hbm_algorithmic": alg_it / dt_iter / 1e9 / PEAK_HBM_GBPS,
+                  "implementation_bytes_formula": impl_it, "implementation_over_algorithmic": impl_it / alg_it,
+                  "implementation_GBps": impl_it / dt_iter / 1e9,
+                  "algorithmic_f32_tflops": fl_it / dt_iter / 1e12, "frac_f32_mfma_peak": fl_it / dt_iter / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                  "executed_tflops": it_mult * fl_it / dt_iter / 1e12, "executed_pipe_peak_tflops": it_peak,
+                  "frac_executed_pipe": it_mult * fl_it / dt_iter / 1e12 / it_peak})
+    if pm:
         whole["pmc_bytes_big_kernels"] = pm
         whole["pmc_over_algorithmic"] = pm / alg_it
         whole["pmc_GBps"] = pm / dt_iter / 1e9
     if out is None:
-        out = {"kernel": None, "bound": "mfma", "achieved": fl_it / dt_iter / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-               "frac": fl_it / dt_iter / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None, "traffic_source": None,
-               "note": "whole-iteration algorithmic f32 flops (this configuration has no single dominant sequence kernel timed live)"}
+        out = {"kernel": None}
+        out.update({k: whole[k] for k in ("bound", "achieved", "peak", "unit", "frac")})
+        out.update({"traffic": None, "traffic_source": None, "bytes_basis": whole["bytes_basis"],
+                    "note": "whole-iteration figures (this configuration has no single dominant sequence kernel timed live): the larger "
+                            "of implementation bytes / 8 TB/s and executed matrix flops / the executing pipe's peak"})
     out["iteration"] = whole
+    return out
+
+
+def predicted_8gpu(cfg_name, cfg, N, T, ms_iter, n_params):
+    """What the first 8-GPU SCALE record should show, from THIS run's one-GPU iteration time: weak scaling =
+    8 x the per-GPU work in (t_1 + the iteration's exchanges); the exchanges are 5 all-reduces of the flat gradient
+    (latency-bound at h=128: ASSUMED 50 us each over xGMI at 8 ranks, 120 us at C5's 3.2 MB) + one 3-double all-reduce
+    + one 16 KB all-gather on a side stream (ASSUMED 60 us together, the all-gather overlapped)."""
+    ar_us = 50.0 if n_params * 4 < (1 << 20) else 120.0
+    t_x = (5 * ar_us + 60.0) * 1e-3
+    weak = 8 * N * T / ((ms_iter + t_x) * 1e-3)
+    out = {"from_ms_per_step_1gpu": ms_iter, "assumed_exchange_ms_per_iteration": t_x,
+           "weak_8gpu_env_steps_per_s": weak, "weak_8gpu_over_1gpu": weak / (N * T / (ms_iter * 1e-3)),
+           "note": "sequence kernels take T x (one workgroup's step latency) whatever the number of workgroups up to one per CU, "
+                   "so splitting a config's envs over more GPUs (strong scaling) leaves the iteration time nearly flat"}
+    if cfg_name == "c4":
+        out["vs_one_gpu_holding_all_8192_envs"] = ("one GPU with 8192 envs runs two 16-env tiles per CU, ~2 x the C3 iteration (~14 ms, ~75 M "
+                                                   "env-steps/s): 8 GPUs at 1024 envs each are predicted ~2.8-3 x that, NOT north_star's >= 6 x")
     return out
 
 
@@ -394,13 +510,14 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-phase", action="store_true", help="launcher mode: skip the second (strong-scaling) set of ranks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing above touched the GPU (no torch import yet),
         # every rank is a fresh process; rank 0 prints the one JSON line.
-        raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+        raise SystemExit(launch(args, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON.  Native libraries write there too (RCCL prints a version banner on stdout
     # when its first communicator comes up), so from here on fd 1 is stderr and the line goes out through the saved fd.
@@ -447,7 +564,10 @@ def main():
     value = env_steps / dt
     opt_steps = epochs * tr.num_minibatches
     reused = kind == "lstm" and cfg["layers"] == 1 and H in (64, 128) and not cfg.get("trend_k")
-    roofline = roofline_block(cfg, N, T, H, timers, dt / args.steps, epochs, reused, kind)
+    arith = {"fp16x3": "fp16x3", "bf16x6": "bf16x6"}.get(getattr(tr, "arith", "fp16x3"), "fp16x3")
+    if os.environ.get("UAV_LSTM_F32_MFMA"):
+        arith = "f32"
+    roofline = roofline_block(cfg, N, T, H, timers, dt / args.steps, epochs, reused, kind, arith)
     pol = f"LSTM h={H} x{cfg['layers']}" if kind == "lstm" else "MLP 6-256-128 (the reference's policy)"
     out = {
         "metric": f"env-steps/sec (rollout + GAE + {epochs}-epoch PPO update), {N} envs x {T} T per GPU, {pol}",
@@ -468,18 +588,10 @@ def main():
         "rollout_ms": roll_ms, "kernel_ms": {k: v["avg_ms"] for k, v in timers.items()},
         "roofline": roofline,
     }
-    if world > 1 and args.scaling == "weak":
-        # the same job shape as the 1-GPU run, split over the ranks (SURVEY 8d "strong scaling for C3").  The sequence
-        # kernels' time is T x (step latency of one workgroup) whatever the number of workgroups, so expect
-        # this to stay near the 1-GPU iteration time: it is reported, not hidden.
-        del tr
-        torch.cuda.empty_cache()
-        tr2 = build_trainer(cfg, n_strong, rank, world, dev, ops)
-        k2 = max(3, args.steps // 2)
-        dt2, roll2, _ = measure(tr2, k2, min(args.warmup, 2), world, dev, ops, dist)
-        out["strong_scaling"] = {"value": n_strong * T * world * k2 / dt2, "unit": "env-steps/s", "num_envs_per_gpu": n_strong,
-                                 "num_envs_total": n_strong * world, "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
-                                 "rollout_ms": roll2}
+    # (the strong-scaling shape is NOT timed in these processes: launch() runs it in a second set of fresh ranks; under
+    #  torchrun ask for it with --scaling strong)
+    if world == 1:
+        out["predicted_8gpu"] = predicted_8gpu(args.config, cfg, N, T, dt / args.steps * 1e3, tr.policy.num_params())
     if rehearsal:
         out["rehearsal"] = f"one-rank {args.backend} communicator, all exchanges issued (UAVPPO_FORCE_COLLECTIVES=1)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 3   /* 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 4   /* 4: uav_set_debug_flags; the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -48,7 +48,12 @@ typedef void* uav_stream;         /* hipStream_t */
 int         uav_abi_version(void);
 const char* uav_last_error(void);
 
-/* ws_bytes: scratch for deterministic two-stage reductions and split-K slabs (>= 1 MiB). */
+/* ws_bytes: scratch for deterministic two-stage reductions and split-K slabs (>= 1 MiB).
+ * A handle belongs to ONE device; a process may hold handles for several devices (per-kernel launch attributes are kept
+ * per device inside the library).  Calls through a handle must be made with that device current (torch does this) and
+ * from one thread at a time.  uav_create reads the process-level switches UAV_LSTM_F32_MFMA / UAV_LSTM_BF16X6 (initial
+ * uav_set_lstm_arith mode) and UAV_LSTM_STEP_F32 / UAV_LSTM_X_F32 (initial debug flags) from the environment, once;
+ * no entry point reads the environment afterwards. */
 int  uav_create(uav_ctx** out, int device, size_t ws_bytes);
 void uav_destroy(uav_ctx* ctx);
 
@@ -64,6 +69,12 @@ void uav_destroy(uav_ctx* ctx);
 #define UAV_ARITH_F32_MFMA 2
 int uav_set_lstm_arith(uav_ctx* ctx, int mode);
 int uav_get_lstm_arith(const uav_ctx* ctx);
+/* A/B switches of the h = 256 step path (tests / measurements only; results are bit-identical or within f32 tolerance):
+ *   STEP_F32  uav_lstm_fwd / _bwd at h = 256 take the generic exact-f32 step path instead of the fp16-split step kernels
+ *   X_F32     a wide layer input is read as f32 rows by every workgroup instead of pre-split piece planes */
+#define UAV_DEBUG_STEP_F32 1u
+#define UAV_DEBUG_X_F32    2u
+int uav_set_debug_flags(uav_ctx* ctx, unsigned flags);
 /* out[0] (f32, device) = max |x[i]| over n floats, a NaN counting as +inf: the range probe for the modes above. */
 int uav_absmax(uav_ctx* ctx, const float* x, int64_t n, float* out, uav_stream stream);
 

@@ -27,7 +27,7 @@ dist.destroy_process_group()
 
 def _launch(n, *args):
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
-            f"sys.exit(bench.spawn_ranks({n}, [sys.executable, '-c', {CHILD!r}] + {list(args)!r}, timeout=120))")
+            f"sys.exit(bench.spawn_ranks({n}, [sys.executable, '-c', {CHILD!r}] + {list(args)!r}, timeout=120)[0])")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
 
@@ -52,4 +52,59 @@ def test_bench_parent_spawns_before_importing_torch():
     top_level = [l for l in head.splitlines() if l.startswith("import ") or l.startswith("from ")]
     assert not any("torch" in l or "uavppo" in l for l in top_level), top_level
     body = src[src.index("def main():"):]
-    assert body.index("spawn_ranks(") < body.index("import torch")
+    assert body.index("launch(args") < body.index("import torch")
+
+
+def test_spawn_ranks_captures_rank0_stdout_and_times_out_a_hung_set():
+    import bench
+    rc, text = bench.spawn_ranks(2, [sys.executable, "-c", CHILD], timeout=120, capture_rank0=True)
+    assert rc == 0 and bench.last_json_line(text) == {"n_gpus": 2, "sum": 3.0}
+    hang = "import time, os\nif os.environ['RANK'] == '1':\n    time.sleep(600)\n"
+    rc, text = bench.spawn_ranks(2, [sys.executable, "-c", hang], timeout=3, capture_rank0=True)
+    assert rc == 124
+
+
+FAKE_RANK = r'''
+import json, os, sys, time
+a = sys.argv[1:]
+strong = a[a.index("--scaling") + 1] == "strong" if "--scaling" in a else False
+if strong and os.environ.get("FAKE_STRONG") == "hang":
+    time.sleep(600)
+if strong and os.environ.get("FAKE_STRONG") == "fail":
+    sys.exit(5)
+if os.environ["RANK"] == "0":
+    n = 128 if strong else 256
+    print("banner noise")
+    print(json.dumps({"value": 2.0 if strong else 1.0, "unit": "env-steps/s", "steps": 3, "ms_per_step": 1.5, "rollout_ms": 0.5,
+                      "config": {"num_envs_per_gpu": n, "num_envs_total": 2 * n}}), flush=True)
+'''
+
+
+def _fake_launch(tmp_path, monkeypatch, mode):
+    """bench.launch() with the rank command replaced by a stand-in: the launcher's own logic (two fresh rank sets, merge,
+    a failing or hanging strong phase never loses the headline line) without a GPU."""
+    import argparse
+    import bench
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(FAKE_RANK)
+    monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(fake))
+    monkeypatch.setenv("FAKE_STRONG", mode)
+    real = bench.spawn_ranks
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, cmd, **kw: real(n, cmd, **dict(kw, timeout=min(kw.get("timeout") or 5, 5))))
+    args = argparse.Namespace(gpus=2, scaling="weak", no_strong_phase=False, steps=4, warmup=1, config="c2", backend="gloo")
+    return bench.launch(args, ["--gpus", "2", "--config", "c2", "--backend", "gloo"])
+
+
+def test_launcher_runs_strong_shape_in_a_second_fresh_rank_set(tmp_path, monkeypatch, capsys):
+    assert _fake_launch(tmp_path, monkeypatch, "ok") == 0
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] == 1.0 and out["strong_scaling"]["value"] == 2.0 and out["strong_scaling"]["num_envs_total"] == 256
+
+
+def test_launcher_keeps_the_headline_when_the_strong_phase_fails_or_hangs(tmp_path, monkeypatch, capsys):
+    for mode in ("fail", "hang"):
+        assert _fake_launch(tmp_path, monkeypatch, mode) == 0
+        out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert out["value"] == 1.0 and "error" in out["strong_scaling"]

@@ -134,16 +134,12 @@ def test_lstm_generic_hidden_sizes(ops, T, N, I, H):
 
 @pytest.mark.parametrize("split", ["fp16x3", "bf16x6"])
 @pytest.mark.parametrize("N,T,H", [(64, 32, 128), (128, 16, 64), (48, 64, 128)])
-def test_split_kernels_have_f32_accuracy(ops, N, T, H, split, monkeypatch):
+def test_split_kernels_have_f32_accuracy(ops, N, T, H, split):
     """The default LSTM kernels multiply on the 16-bit matrix pipe: forward / backward with a two-piece fp16 operand split
-    and three products (common.h split2h), the weight gradients -- and everything with UAV_LSTM_BF16X6=1 -- with a
+    and three products (common.h split2h), the weight gradients -- and everything under UAV_ARITH_BF16X6 -- with a
     three-piece bf16 split and six products.  Claim: the result is an f32 computation -- against an f64 LSTM their error
-    is that of the exact-f32-MFMA kernels (UAV_LSTM_F32_MFMA=1 selects those), for forward, backward and weight
+    is that of the exact-f32-MFMA kernels (UAV_ARITH_F32_MFMA selects those), for forward, backward and weight
     gradients (shapes with full 32-row slabs)."""
-    if split == "bf16x6":
-        monkeypatch.setenv("UAV_LSTM_BF16X6", "1")
-    else:
-        monkeypatch.delenv("UAV_LSTM_BF16X6", raising=False)
     torch.manual_seed(N + T)
     I, A = 6, 6
     ref = torch.nn.LSTM(I, H, 1).double()
@@ -173,12 +169,11 @@ def test_split_kernels_have_f32_accuracy(ops, N, T, H, split, monkeypatch):
     def errs(got):
         return {k: float((got[k] - want[k].detach()).abs().max() / (want[k].detach().abs().max() + 1e-30)) for k in want}
 
-    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
-    e_x6 = errs(run())
-    monkeypatch.setenv("UAV_LSTM_F32_MFMA", "1")
-    e_f32 = errs(run())
-    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
-    monkeypatch.delenv("UAV_LSTM_BF16X6", raising=False)
+    with ops.lstm_arith(split):
+        e_x6 = errs(run())
+    with ops.lstm_arith("f32_mfma"):
+        e_f32 = errs(run())
+    assert ops.get_lstm_arith() == "fp16x3"
     for k in want:
         assert e_x6[k] < 5e-6, (k, e_x6)                                 # f32-level agreement with the f64 reference
         assert e_x6[k] <= 2.0 * e_f32[k] + 2e-7, (k, e_x6[k], e_f32[k])   # ... and no worse than the exact-f32 MFMA chain
@@ -215,14 +210,11 @@ def test_split_fp16_backward_keeps_f32_accuracy_over_40_decades(ops, H):
 
 @pytest.mark.parametrize("N,T,I,H", [(37, 21, 6, 128), (16, 9, 6, 64), (5, 1, 6, 128), (7, 6, 6, 256), (9, 12, 64, 128)])
 @pytest.mark.parametrize("f32_mfma", [False, True])
-def test_lstm_fwd_emits_heads(ops, N, T, I, H, f32_mfma, monkeypatch):
+def test_lstm_fwd_emits_heads(ops, N, T, I, H, f32_mfma):
     """uav_lstm_fwd's heads output == (y W_head^T + b_head) of model.py:44,52, whether the sequence kernel forms it
     itself (split-bf16 kernels, from the unmasked h planes: episode resets inside the sequence must not leak into it)
     or the entry point falls back to one GEMM over y (exact-f32 / wide-input / h=256 paths)."""
-    if f32_mfma:
-        monkeypatch.setenv("UAV_LSTM_F32_MFMA", "1")
-    else:
-        monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    ops.set_lstm_arith("f32_mfma" if f32_mfma else "fp16x3")
     torch.manual_seed(N * 7 + T)
     dev = DEV
     x = torch.randn(N, T, I, device=dev)
@@ -239,7 +231,7 @@ def test_lstm_fwd_emits_heads(ops, N, T, I, H, f32_mfma, monkeypatch):
     # and y itself is unchanged by asking for heads
     y2, _, _, _ = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
     assert torch.equal(y, y2)
-    monkeypatch.delenv("UAV_LSTM_F32_MFMA", raising=False)
+    ops.set_lstm_arith("fp16x3")
 
 
 def test_lstm_bwd_fused_path_fuzz_against_dy_path(ops):
@@ -389,6 +381,45 @@ def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     assert torch.equal(y[:, 0], y2_ref[:, 0]) and torch.equal(stash[:, 0], st2_ref[:, 0])
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "f32_mfma"])
+def test_h256_wide_range_modes_leave_the_fp16_step_kernels(ops, mode):
+    """The h = 256 step kernels exist in the fp16-split form only (|w| < 65504, |x| < 4096).  A caller that selects a
+    wide-range mode does so BECAUSE its operands left that range: both modes must take the generic exact-f32 step path
+    (results finite and equal to the f32 reference with a weight of 1e5 and inputs of 1e4), uav_lstm_bwd_caps must report
+    0 and the stepper must refuse -- not silently overflow to inf in the fp16 pieces."""
+    T, N, I, H = 5, 9, 8, 256
+    torch.manual_seed(3)
+    ref = torch.nn.LSTM(I, H, 1)
+    w_ih, w_hh, b_ih, b_hh = [p.detach().clone() for p in ref.parameters()]
+    w_hh[5, 7] = 1.0e5                           # far outside fp16's range (the unit saturates; everything stays finite)
+    w_ih[300, 2] = -7.0e4
+    for w in (w_ih, w_hh, b_ih, b_hh):
+        w.requires_grad_(True)
+    x = torch.randn(T, N, I)
+    x[:, :, 0] *= 1.0e4
+    x.requires_grad_(True)
+    h0 = torch.randn(N, H, requires_grad=True)
+    c0 = torch.randn(N, H, requires_grad=True)
+    y, hn, cn = po.lstm_layer_forward(x, h0, c0, w_ih, w_hh, b_ih, b_hh, None)
+    dy = torch.randn(T, N, H)
+    (y * dy).sum().backward()
+    d = lambda t: t.detach().to(DEV).contiguous()
+    xg = d(x.transpose(0, 1))
+    with ops.lstm_arith(mode):
+        assert ops.lstm_bwd_caps(DEV, I, H) == 0 and ops.lstm_bwd_caps(DEV, H, H) == 0
+        yg, hng, cng, stash = ops.lstm_fwd(xg, None, d(h0), d(c0), d(w_ih), d(w_hh), d(b_ih), d(b_hh))
+        g = ops.lstm_bwd(xg, None, stash, d(w_ih), d(w_hh), yg, d(h0), dy=d(dy.transpose(0, 1)), need_dx=True)
+        sp = ops.LstmStepper(N, I, H, DEV)
+        with pytest.raises(RuntimeError, match="fp16-split"):
+            sp.begin(d(w_ih), d(w_hh), d(b_ih), d(b_hh), d(h0), d(c0))
+    assert torch.isfinite(yg).all() and all(torch.isfinite(v).all() for v in g.values() if v is not None)
+    _close(yg.transpose(0, 1), y, 1e-5, 3e-6)
+    for k, want in (("dx", x.grad.transpose(0, 1)), ("dw_ih", w_ih.grad), ("dw_hh", w_hh.grad), ("db", b_ih.grad),
+                    ("dh0", h0.grad), ("dc0", c0.grad)):
+        _close(g[k], want, 5e-4, 5e-5)
+    assert ops.lstm_bwd_caps(DEV, H, H) != 0          # back on the default arithmetic: the fp16 step path again
+
+
 def test_lstm_stepper_refuses_other_shapes(ops):
     with pytest.raises(RuntimeError, match="not supported"):
         ops.LstmStepper(16, 6, 128, DEV)
@@ -399,7 +430,7 @@ def test_lstm_stepper_refuses_other_shapes(ops):
 def test_lstm_stepper_two_layers_through_piece_planes(ops):
     """Layer 2 of a stepped stack reads layer 1's h_t from its piece planes (`below`) instead of the f32 y rows; the
     sequence call converts its wide input to piece planes a chunk of steps at a time: both BIT-identical to each other
-    and to the f32-input kernel (UAV_LSTM_X_F32=1 is the A/B switch of the sequence driver)."""
+    and to the f32-input kernel (UAV_DEBUG_X_F32 is the A/B switch of the sequence driver)."""
     H, N, T, I = 256, 80, 19, 8
     g = torch.Generator().manual_seed(5)
     x = torch.randn(N, T, I, generator=g).to(DEV)
@@ -412,11 +443,11 @@ def test_lstm_stepper_two_layers_through_piece_planes(ops):
     # sequence: layer 1 then layer 2 (chunked piece conversion of y1)
     y1, _, _, st1 = ops.lstm_fwd(x, keep, h0[0], c0[0], *W[0])
     y2, hn2, cn2, st2 = ops.lstm_fwd(y1, keep, h0[1], c0[1], *W[1])
-    os.environ["UAV_LSTM_X_F32"] = "1"
+    ops.set_debug_flags("x_f32")
     try:
         y2f, _, _, st2f = ops.lstm_fwd(y1, keep, h0[1], c0[1], *W[1])
     finally:
-        del os.environ["UAV_LSTM_X_F32"]
+        ops.set_debug_flags()
     assert torch.equal(y2, y2f) and torch.equal(st2, st2f)
     # stepped: both layers per time step, layer 2 fed from layer 1's piece planes
     sp = [ops.LstmStepper(N, I, H, DEV), ops.LstmStepper(N, H, H, DEV)]

@@ -543,6 +543,26 @@ def test_range_guard_in_the_training_loop():
     assert tr.arith == "fp16x3"
 
 
+def test_range_guard_covers_h256():
+    """BASELINE C5's policy (h = 256 x 2, trend channels): a weight outside fp16's range switches the trainer to the wide
+    mode, where the h = 256 kernels run the generic exact-f32 step path (no stepper, no fp16 pieces); training stays
+    finite and the guard returns to the fp16 split once the weight is back in range."""
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(32, 6, "lstm", hidden=256, layers=2, device=DEV, seed=4, epochs=1, trend_k=2)
+    tr.train_iteration()
+    assert tr.arith == "fp16x3" and tr.range_events == 0
+    with torch.no_grad():
+        tr.policy.views["lstm.weight_hh_l1"][3, 3] = 9.0e4
+    tr.train_iteration()
+    assert tr.arith == "bf16x6" and tr.range_events >= 1
+    assert np.isfinite(tr.losses()).all() and torch.isfinite(tr.policy.flat).all()
+    with torch.no_grad():
+        tr.policy.views["lstm.weight_hh_l1"][3, 3] = 0.01
+    tr.train_iteration()
+    tr.train_iteration()
+    assert tr.arith == "fp16x3"
+
+
 def test_adam_publishes_max_abs_param(ops=None):
     from uavppo import ops
     n = 5000

@@ -43,7 +43,9 @@ def main():
             continue
         res[short(k)] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_read_bytes_corrected": rd, "hbm_write_bytes": wr,
                          "hbm_total_bytes": rd + wr, "launches_averaged": nf.get(k, 0)}
-    res["_meta"] = {"git_commit": os.environ.get("GIT_COMMIT"), "shape": "BASELINE C3: 4096 envs x 128 steps, LSTM h=128, 1 GPU (tools/pmc_update.py)",
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["_meta"] = {"git_commit": os.environ.get("GIT_COMMIT"), "csrc_sha": bench.csrc_digest(), "shape": "BASELINE C3: 4096 envs x 128 steps, LSTM h=128, 1 GPU (tools/pmc_update.py)",
                     "counters": "FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate rocprofv3 --pmc passes, KB -> bytes, mean per launch"}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Robustness sweep: random (N, T, H) shapes through rollout + one PPO gradient with the default (split-fp16) kernels and
-with the exact-f32 kernels (UAV_LSTM_F32_MFMA=1, read per call); the two gradients must agree to f32 noise and be finite.
+with the exact-f32 kernels (uav_set_lstm_arith(UAV_ARITH_F32_MFMA)); the two gradients must agree to f32 noise and be finite.
 (With a handful of samples the value gradient is (V_recomputed - V_rollout), pure rounding noise of whichever forward
 produced it, so the relative test gets an absolute floor of 1e-7 / sqrt(samples).)"""
 import os
@@ -22,7 +22,7 @@ def main():
         H = (64, 128)[case % 2]
         N = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 48, 100, 255, 256, 257, int(rng.randint(1, 600))]))
         T = int(rng.choice([1, 2, 7, 8, 9, 16, 31, 32, 33, 64, 100, int(rng.randint(1, 200))]))
-        os.environ.pop("UAV_LSTM_F32_MFMA", None)
+        ops.set_lstm_arith("fp16x3")
         tr = VecPPOTrainer(N, T, "lstm", hidden=H, device="cuda:0", seed=case, use_curriculum=False)
         tr.radius = 80.0
         tr.collect()
@@ -33,17 +33,14 @@ def main():
                 1.0 / n, 0.2, 0.01)
         gs = []
         for f32 in (False, True):
-            if f32:
-                os.environ["UAV_LSTM_F32_MFMA"] = "1"
-            else:
-                os.environ.pop("UAV_LSTM_F32_MFMA", None)
+            ops.set_lstm_arith("f32_mfma" if f32 else "fp16x3")
             heads = pol.heads(b["obs"], b["keep"], tr.h0, tr.c0, tr.work)
             loss = torch.zeros(4, dtype=torch.float64, device="cuda:0")
             dheads = torch.empty(n, 6, device="cuda:0")
             dbias = torch.empty(6, device="cuda:0")
             ops.ppo_loss_heads(heads, *args, loss, dheads, dbias)
             gs.append(pol.backward(dheads, tr.work, dbias).clone().double())
-        os.environ.pop("UAV_LSTM_F32_MFMA", None)
+        ops.set_lstm_arith("fp16x3")
         # the rollout's own heads / stash against the recomputed forward
         hr = tr.work["heads"].reshape(n, 6) if tr._rollout_forward_valid else None
         dn = float((gs[0] - gs[1]).norm())

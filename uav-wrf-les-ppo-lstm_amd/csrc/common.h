@@ -15,17 +15,31 @@ struct uav_ctx {
     double* pow075;    // device table pow(i, 0.75), i = 0..5000 (env_core.h)
     double* wave;      // device tables sin(0.05 x) | cos(0.07 y), x, y = 0..499 (env_core.h field_at)
     int lstm_arith;    // UAV_ARITH_*: how the LSTM sequence kernels evaluate their f32 matrix products (uav_set_lstm_arith)
+    unsigned debug;    // UAV_DEBUG_*: A/B switches of the h = 256 step path (uav_set_debug_flags)
     hipStream_t side[3];      // uav_lstm_bwd_stack: one stream per layer below the top (created on first use)
     hipEvent_t side_ev[8];    // fork / join + a small ring of per-step hand-off events per side stream
 };
 
-// arithmetic of the call in flight on this thread (set from ctx->lstm_arith by the LSTM entry points; the launch helpers
-// below them have no ctx argument).  The UAV_LSTM_BF16X6 / UAV_LSTM_F32_MFMA environment variables still force a mode.
+// arithmetic / debug switches of the call in flight on this thread (set from the handle by the LSTM entry points; the
+// launch helpers below them have no ctx argument).  No getenv on any call path: the UAV_LSTM_BF16X6 / UAV_LSTM_F32_MFMA
+// environment variables are read ONCE, by uav_create, as the handle's initial mode.
 extern thread_local int g_uav_arith;
-static inline bool uav_want_f32_mfma() { return g_uav_arith == UAV_ARITH_F32_MFMA || getenv("UAV_LSTM_F32_MFMA") != nullptr; }
-static inline bool uav_want_bf16x6() { return g_uav_arith == UAV_ARITH_BF16X6 || getenv("UAV_LSTM_BF16X6") != nullptr; }
+extern thread_local unsigned g_uav_debug;
+static inline bool uav_want_f32_mfma() { return g_uav_arith == UAV_ARITH_F32_MFMA; }
+static inline bool uav_want_bf16x6() { return g_uav_arith == UAV_ARITH_BF16X6; }
+static inline bool uav_debug(unsigned bit) { return (g_uav_debug & bit) != 0; }
+static inline void uav_enter(const struct uav_ctx* ctx);
+
+static inline void uav_enter(const uav_ctx* ctx) {
+    g_uav_arith = ctx->lstm_arith;
+    g_uav_debug = ctx->debug;
+}
 
 void uav_set_error(const char* fmt, ...);
+
+// Opt a kernel in to `bytes` of dynamic LDS.  Function attributes are PER DEVICE, so the "already done" memo is keyed by
+// (current device, kernel): a process that drives several devices through several handles gets the attribute on each.
+hipError_t uav_dyn_lds(const void* kernel, int bytes);
 
 #define UAV_CHECK_HIP(expr)                                                          \
     do {                                                                             \

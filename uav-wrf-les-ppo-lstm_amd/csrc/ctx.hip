@@ -1,9 +1,13 @@
 // ctx.hip -- handle, error string, ABI version.
 #include <stdarg.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
 thread_local int g_uav_arith = 0;
+thread_local unsigned g_uav_debug = 0;
 int env_init_tables(uav_ctx* ctx);
 
 void uav_set_error(const char* fmt, ...) {
@@ -11,6 +15,19 @@ void uav_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+hipError_t uav_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
 }
 
 extern "C" {
@@ -32,7 +49,9 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->ws_bytes = ws_bytes;
     c->pow075 = nullptr;
     c->wave = nullptr;
-    c->lstm_arith = UAV_ARITH_FP16X3;
+    // process-level override of the default arithmetic, read here once (never on a call path)
+    c->lstm_arith = getenv("UAV_LSTM_F32_MFMA") ? UAV_ARITH_F32_MFMA : (getenv("UAV_LSTM_BF16X6") ? UAV_ARITH_BF16X6 : UAV_ARITH_FP16X3);
+    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u);
     if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
         delete c;
         uav_set_error("uav_create: hipMalloc(%zu) failed", ws_bytes);
@@ -55,6 +74,12 @@ int uav_set_lstm_arith(uav_ctx* ctx, int mode) {
     return 0;
 }
 int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; }
+
+int uav_set_debug_flags(uav_ctx* ctx, unsigned flags) {
+    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32)) == 0, "uav_set_debug_flags: bad argument");
+    ctx->debug = flags;
+    return 0;
+}
 
 void uav_destroy(uav_ctx* ctx) {
     if (!ctx) return;

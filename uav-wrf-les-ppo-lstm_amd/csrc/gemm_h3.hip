@@ -302,12 +302,7 @@ int launch_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int
     const int64_t grid = 8 * G * ((ngroups + 7) / 8);
     UAV_REQUIRE(grid < (1ll << 31), "gemm_h3: grid too large");
     auto kern = gemm_h3_kernel<BN, AKC, BKC>;
-    static bool attr_set = false;                       // per instantiation
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)H3Tile<BN>::LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(kern), (int)H3Tile<BN>::LDS));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), H3Tile<BN>::LDS, st, M, N, K, A, lda, B, ldb, C, ldc, bias,
                        accumulate, kps, slabs, a_absmax, tm, tn, (int)S);
     if (S > 1) {

@@ -14,10 +14,12 @@
 //   DEFAULT  lstm_fwd_h3_kernel, lstm_bwd_h3k_kernel: the matrix products on the fp16 pipe at f32 accuracy (two-piece
 //            operand split, three products, common.h split2h; gate gradients block-scaled per env), weights-as-A
 //            orientation (a lane owns one env and four consecutive units: dwordx4 stores), stash by LDS-DMA in the backward;
-//   BF16 SPLIT lstm_fwd_x6_kernel, lstm_bwd_x6k_kernel (and its predecessor lstm_bwd_x6_kernel): the same kernels with a
-//            three-piece bf16 split and six products (no range limits, twice the matrix work); UAV_LSTM_BF16X6=1;
-//   EXACT-F32 lstm_fwd_kernel, lstm_bwd_kernel (plain dy; stacked layers), lstm_bwd_dma_kernel: v_mfma_f32_16x16x4_f32
-//            with 128 weight VGPRs per lane; selected by UAV_LSTM_F32_MFMA=1 and for the plain-dy backward.
+//   BF16 SPLIT lstm_fwd_x6_kernel, lstm_bwd_x6k_kernel: the same kernels with a three-piece bf16 split and six
+//            products (f32's exponent range: no operand limits, twice the matrix work); uav_set_lstm_arith(UAV_ARITH_BF16X6);
+//   EXACT-F32 lstm_fwd_kernel, lstm_bwd_kernel (also the plain-dy backward of stacked layers): v_mfma_f32_16x16x4_f32
+//            with 128 weight VGPRs per lane; uav_set_lstm_arith(UAV_ARITH_F32_MFMA).
+//   (Earlier generations -- an output-split bf16 backward exchanging dG through three LDS planes, an LDS-DMA form of
+//    the exact-f32 backward -- were measured, superseded and removed in round 3; their numbers are in profiles/README.md.)
 //   (A half-step stagger of waves 4-7 against 0-3 was built and measured on the exact-f32 forward: no gain,
 //    tools/stagger_probe.hip; what paced the step was the IEEE division sequence inside the activations, now v_rcp_f32.)
 //   * the K=I<=8 input projection rides along as two exact-f32 MFMA k-steps; wider inputs (stacked layers) use a
@@ -60,7 +62,7 @@ int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src,
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 // UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split ones)
-static bool f32_mfma_requested() { return uav_want_f32_mfma(); }   // read per call: tests toggle it
+static bool f32_mfma_requested() { return uav_want_f32_mfma(); }   // the handle's mode (uav_set_lstm_arith)
 static bool bf16x6_requested() { return uav_want_bf16x6(); }        // the predecessor of the fp16 split
 constexpr int TC = 32;      // time steps staged per chunk
 
@@ -950,386 +952,12 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_kernel(
     }
 }
 
-// -------------------------------------------------------------------- backward, LDS-DMA stash prefetch
-// Same math as lstm_bwd_kernel.  The per-step stash values (gates i,f,g,o + c_prev of this wave's 16
-// units x 16 env rows = 5 KB) are fetched by global_load_lds (LDS-DMA: no VGPR destination) TWO steps
-// ahead into a 2-slot per-wave ring, so the HBM latency (2-3 us under this kernel's ~5 TB/s demand) is
-// covered by two MFMA phases instead of one and 24 VGPRs of register prefetch disappear.  Each wave
-// gathers exactly what its own lanes read back, so the only ordering needed is the wave's own counted
-// s_waitcnt: vmcnt(5) = "everything but the 5 DMA ops issued last step has landed" (loads, stores and
-// LDS-DMA retire in issue order; the 5 DMA ops per step are issued unconditionally).
-template <int H>
-struct BwdDmaGeom {
-    static constexpr int S = 4 * H + 4;
-    static constexpr int TCB = 16;                               // steps of dheads/keep staged per chunk
-    static constexpr int SLOT = 5 * MT * 16;                     // floats per wave per slot: [5][16 rows][16 units]
-    static constexpr int NW = H / 16;
-    static constexpr size_t LDS = (2 * MT * S + TCB * MT * 8 + (TCB + 1) * MT) * sizeof(float);   // dynamic part
-};
-
-template <int H>
-__global__ __launch_bounds__(H * 4) void lstm_bwd_dma_kernel(
-    const float* __restrict__ keep, const float* __restrict__ stash, const float* __restrict__ w_hh,
-    const float* __restrict__ dheads, const float* __restrict__ w_head, int NH, const float* __restrict__ dhn,
-    const float* __restrict__ dcn, int N, int T, float* __restrict__ dgates, float* __restrict__ dh0,
-    float* __restrict__ dc0) {
-    using G = BwdDmaGeom<H>;
-    constexpr int S = G::S, TCB = G::TCB, SLOT = G::SLOT, NW = G::NW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* dgbuf = smem;                       // [2][MT][S]
-    float* dhbuf = dgbuf + 2 * MT * S;         // [TCB][MT][8]
-    float* kbuf = dhbuf + TCB * MT * 8;        // [TCB+1][MT]
-    // the DMA ring is its OWN __shared__ object: with everything in one array hipcc cannot prove the MFMA
-    // fragment reads of dgbuf do not alias the in-flight LDS-DMA and puts s_waitcnt vmcnt(0) in front of them
-    __shared__ __attribute__((aligned(16))) float ring[2 * NW * SLOT];   // [2 slots][NW waves][SLOT]
-
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, kq = lane >> 4;
-    const int u = 16 * w + j;
-    const int n0 = blockIdx.x * MT;
-
-    float wt[H];
-#pragma unroll
-    for (int s = 0; s < H; ++s) wt[s] = w_hh[(size_t)(kq * H + s) * H + u];
-    float whb[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) whb[a] = (4 * a + kq < NH) ? w_head[(size_t)(4 * a + kq) * H + u] : 0.f;
-
-    float dh_rec[4], dc_next[4];
-    size_t srow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = min(n0 + 4 * kq + r, N - 1);
-        dh_rec[r] = dhn ? dhn[(size_t)n * H + u] : 0.f;
-        dc_next[r] = dcn ? dcn[(size_t)n * H + u] : 0.f;
-        srow[r] = (size_t)n * T;
-    }
-    // DMA gather coordinates of this lane: env row e_d = lane/4, 4-unit group g4 = lane%4 of this wave's 16 units
-    const int e_d = lane >> 2, g4 = lane & 3;
-    const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
-    // LDS-DMA in inline asm (cdna_hip_programming.md 5.7): hipcc does not see these loads, so it neither counts
-    // them nor guards later ds_reads with vmcnt(0); their completion is ordered by the counted waits below.
-    // M0 carries the wave-uniform LDS byte address; the hardware adds lane*16.
-    typedef __attribute__((address_space(3))) float lds_f;
-    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)(ring + w * SLOT)));
-    auto issue = [&](int t, int slot) {           // 5 x 1 KiB wave-instructions: [q][row e_d][units 4*g4..]
-        const float* src = stash + (drow + t) * (6 * H) + 16 * w + 4 * g4;
-        const unsigned dst = ring_base + (unsigned)(slot * NW * SLOT * 4);
-        unsigned m0save;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(m0save)
-            : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(dst)
-            : "memory");
-    };
-    // prologue: steps T-1 and T-2 (clamped) -- always 5 + 5 ops so the counted waits below stay exact
-    issue(T - 1, (T - 1) & 1);
-    issue(T >= 2 ? T - 2 : 0, (T - 2) & 1);
-
-    int cur = 0;
-    const int nchunk = (T + TCB - 1) / TCB;
-    for (int ch = nchunk - 1; ch >= 0; --ch) {
-        const int t0 = ch * TCB, tc = min(TCB, T - t0);
-        for (int idx = threadIdx.x; idx < MT * tc * 8; idx += blockDim.x) {
-            const int e = idx / (tc * 8), rem = idx % (tc * 8), tt = rem >> 3, f = rem & 7;
-            const int n = min(n0 + e, N - 1);
-            dhbuf[(tt * MT + e) * 8 + f] = (f < NH) ? dheads[((size_t)n * T + t0 + tt) * NH + f] : 0.f;
-        }
-        for (int idx = threadIdx.x; idx < MT * tc; idx += blockDim.x) {
-            const int e = idx / tc, tt = idx % tc;
-            const int n = min(n0 + e, N - 1);
-            kbuf[tt * MT + e] = keep ? keep[(size_t)n * T + t0 + tt] : 1.f;
-        }
-        lds_barrier();
-        for (int tt = tc - 1; tt >= 0; --tt) {
-            const int t = t0 + tt;
-            float* dgw = dgbuf + cur * MT * S;
-            f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
-            {
-                const float* dr = &dhbuf[(tt * MT + j) * 8];
-                dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[kq], whb[0], dyacc, 0, 0, 0);
-                dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[4 + kq], whb[1], dyacc, 0, 0, 0);
-            }
-            // the slot of step t: issued two steps ago; only last step's 5 DMA ops may still be in flight
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            const float* sl = ring + ((t & 1) * NW + w) * SLOT;
-            float pf[4][5];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int q = 0; q < 5; ++q) pf[r][q] = sl[q * 256 + (4 * kq + r) * 16 + j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int e = 4 * kq + r;
-                const float gi = pf[r][0], gf = pf[r][1], gg = pf[r][2], go = pf[r][3], cp = pf[r][4];
-                const float dh = dyacc[r] + dh_rec[r];
-                const float c = gf * cp + gi * gg;
-                const float tch = tanhf_(c);
-                const float dc = dh * go * (1.0f - tch * tch) + dc_next[r];
-                const float dgi = dc * gg * gi * (1.0f - gi);
-                const float dgf = dc * cp * gf * (1.0f - gf);
-                const float dgg = dc * gi * (1.0f - gg * gg);
-                const float dgo = dh * tch * go * (1.0f - go);
-                const float kp = kbuf[tt * MT + e];
-                dc_next[r] = dc * gf * kp;
-                dgw[e * S + 0 * H + u] = dgi;
-                dgw[e * S + 1 * H + u] = dgf;
-                dgw[e * S + 2 * H + u] = dgg;
-                dgw[e * S + 3 * H + u] = dgo;
-                if (n0 + e < N) {
-                    float* gp = dgates + (srow[r] + t) * (4 * H);
-                    gp[u] = dgi; gp[H + u] = dgf; gp[2 * H + u] = dgg; gp[3 * H + u] = dgo;
-                }
-            }
-            // refill this slot with step t-2 (all of this wave's reads of it have returned: lgkmcnt(0))
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue(t >= 2 ? t - 2 : 0, t & 1);
-            lds_barrier();
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-            const float* drow_l = dgw + j * S + kq * H;
-#pragma unroll
-            for (int s = 0; s < H; s += 4) {
-                const float4 a = *reinterpret_cast<const float4*>(drow_l + s);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wt[s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wt[s + 1], a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wt[s + 2], a2, 0, 0, 0);
-                a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wt[s + 3], a3, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float kp = kbuf[tt * MT + 4 * kq + r];
-                dh_rec[r] = ((a0[r] + a1[r]) + (a2[r] + a3[r])) * kp;
-            }
-            cur ^= 1;
-        }
-        lds_barrier();     // kbuf / dhbuf are restaged by the next chunk
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the clamped tail DMAs before the LDS is released
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int n = n0 + 4 * kq + r;
-        if (n < N) {
-            if (dh0) dh0[(size_t)n * H + u] = dh_rec[r];
-            if (dc0) dc0[(size_t)n * H + u] = dc_next[r];
-        }
-    }
-}
-
-// ------------------------------------------------------------------- backward, split-bf16 MFMA
-// dh_{t-1}^T = W_hh^T dG_t^T on the bf16 matrix pipe at f32 accuracy (3-way split, six products; see
-// lstm_fwd_x6_kernel).  Orientation as in the forward: the weights are the A operand, so lane (j, kq) owns env j
-// and the four consecutive units uo..uo+3 -- its stash values arrive as five ds_read_b128 from the LDS-DMA ring,
-// its 16 gate gradients leave as four dwordx4 stores and are parked (split once, by their producer) as
-// ds_write_b64 in three bf16 planes [piece][env][4H + pad] that every wave reads back as B fragments.
-// All three pieces of this wave's W_hh^T slice stay in VGPRs (192 at H=128): the stash never passes through
-// registers two steps ahead, which is what makes that fit.  The planes are single-buffered (LDS also holds the
-// 80 KB ring), so a step has two barriers: planes free -> write -> planes complete -> MFMA.
-// Per step waves 0 and 1 additionally DMA the step's dheads / keep rows (96 + 16 floats) for everyone.
-template <int H>
-struct BwdX6Geom {
-    static constexpr int NW = H / 16;
-    static constexpr int NS = 4 * H / 32;                            // K = 32 slabs over the 4H gate rows
-    static constexpr int SP = 4 * H + 8;                             // padded plane row (bf16)
-    static constexpr int PLANE = MT * SP;
-    static constexpr int SLOT = 5 * MT * 16;                         // floats per wave per ring slot
-    static constexpr int SMALL = 128;                                // floats per small slot: dheads[16][6] | keep[16]
-    // the smallest weight piece of the first SPK slabs lives in a wave-private LDS slab (lane-contiguous b128):
-    // 192 weight VGPRs + the pointwise working set do not fit in 256 otherwise, and a scratch reload would put
-    // s_waitcnt vmcnt(0) in front of the counted LDS-DMA waits
-    static constexpr int SPK = (H >= 128) ? 3 : 0;
-    static constexpr int WPARK = SPK * 64 * 8;                       // bf16 elements per wave
-    static constexpr size_t LDS = (3 * PLANE + NW * WPARK) * sizeof(unsigned short) +
-                                  (2 * NW * SLOT + 2 * SMALL) * sizeof(float);
-};
-
-template <int H>
-__global__ __launch_bounds__(H * 4) void lstm_bwd_x6_kernel(
-    const float* __restrict__ keep, const float* __restrict__ stash, const float* __restrict__ w_hh,
-    const float* __restrict__ dheads, const float* __restrict__ w_head, int NH, const float* __restrict__ dhn,
-    const float* __restrict__ dcn, int N, int T, float* __restrict__ dgates, float* __restrict__ dh0,
-    float* __restrict__ dc0) {
-    using G = BwdX6Geom<H>;
-    constexpr int NS = G::NS, SP = G::SP, PLANE = G::PLANE, SLOT = G::SLOT, NW = G::NW, SMALL = G::SMALL;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SPK = G::SPK, WPARK = G::WPARK;
-    unsigned short* dgp = reinterpret_cast<unsigned short*>(smem);          // [3 pieces][MT][SP]
-    unsigned short* wpark = dgp + 3 * PLANE;                                // [NW][SPK][64 lanes][8]
-    float* ring = reinterpret_cast<float*>(wpark + NW * WPARK);             // [2 slots][NW][SLOT]
-    float* small = ring + 2 * NW * SLOT;                                    // [2 slots][SMALL]
-
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, kq = lane >> 4;
-    const int uw = 16 * w + j;                 // unit whose W_hh^T row this lane holds (A operand row)
-    const int uo = 16 * w + 4 * kq;            // first of this lane's four units; its env is j
-    const int n0 = blockIdx.x * MT;
-    const int n = min(n0 + j, N - 1);
-    const bool live = n0 + j < N;
-
-    // A fragments: lane (j, kq) holds W_hh[k = 32 s + 8 kq + e][uw], e = 0..7, as three bf16 pieces
-    bf16x8 wa[NS][2], wa2[NS - SPK];
-    bf16x8* const wpk = reinterpret_cast<bf16x8*>(wpark + w * WPARK) + lane;           // + s * 64
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        bf16x8 p2v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            __bf16 p0, p1, p2;
-            split3(w_hh[(size_t)(32 * s + 8 * kq + e) * H + uw], p0, p1, p2);
-            wa[s][0][e] = p0; wa[s][1][e] = p1; p2v[e] = p2;
-        }
-        if (s < SPK) wpk[s * 64] = p2v;
-        else wa2[s < SPK ? 0 : s - SPK] = p2v;
-    }
-    float whb[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) whb[a] = (4 * a + kq < NH) ? w_head[(size_t)(4 * a + kq) * H + uw] : 0.f;
-
-    float dh_rec[4], dc_next[4];
-    {
-        const float4 a4 = dhn ? *reinterpret_cast<const float4*>(dhn + (size_t)n * H + uo) : float4{0.f, 0.f, 0.f, 0.f};
-        const float4 c4 = dcn ? *reinterpret_cast<const float4*>(dcn + (size_t)n * H + uo) : float4{0.f, 0.f, 0.f, 0.f};
-        dh_rec[0] = a4.x; dh_rec[1] = a4.y; dh_rec[2] = a4.z; dh_rec[3] = a4.w;
-        dc_next[0] = c4.x; dc_next[1] = c4.y; dc_next[2] = c4.z; dc_next[3] = c4.w;
-    }
-    const size_t srow = (size_t)n * T;
-
-    // ---- LDS-DMA (inline asm, see lstm_bwd_dma_kernel): stash gather [q][env lane/4][units 4 (lane%4) ..]
-    typedef __attribute__((address_space(3))) float lds_f;
-    const int e_d = lane >> 2, g4 = lane & 3;
-    const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
-    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)(ring + w * SLOT)));
-    const unsigned small_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)small));
-    auto issue = [&](int t, int slot) {
-                const float* src = stash + (drow + t) * (6 * H) + 16 * w + 4 * g4;
-        const unsigned dst = ring_base + (unsigned)(slot * NW * SLOT * 4);
-        unsigned m0save;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
-            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(m0save)
-            : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(dst)
-            : "memory");
-    };
-    // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)]
-    auto issue_small = [&](int t, int slot) {
-        const int e = w * 64 + lane;                                         // element of the 128-float image
-        const float* src;
-        if (e < 16 * NH) src = dheads + ((size_t)min(n0 + e / NH, N - 1) * T + t) * NH + e % NH;
-        else if (e >= 112 && keep) src = keep + (size_t)min(n0 + e - 112, N - 1) * T + t;
-        else src = w_hh + (lane & 15);                                       // padding: any readable dwords
-        const unsigned dst = small_base + (unsigned)((slot * SMALL + w * 64) * 4);
-        unsigned m0save;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(m0save) : "v"(src), "s"(dst) : "memory");
-    };
-    const bool small_wave = w < 2;
-    issue(T - 1, (T - 1) & 1);
-    if (small_wave) issue_small(T - 1, (T - 1) & 1);
-    issue(T >= 2 ? T - 2 : 0, (T - 2) & 1);
-    if (small_wave) issue_small(T >= 2 ? T - 2 : 0, (T - 2) & 1);
-
-    for (int t = T - 1; t >= 0; --t) {
-        // slot of step t: issued two steps ago; only last step's DMA ops of this wave may still be in flight
-        if (small_wave) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        const float* sl = ring + ((t & 1) * NW + w) * SLOT + j * 16 + 4 * kq;
-        float4 pf[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) pf[q] = *reinterpret_cast<const float4*>(sl + q * 256);
-        lds_barrier();           // b2: every wave is done with the planes of step t+1; the small image of step t landed
-        const float* sm = small + (t & 1) * SMALL;
-        f32x4 dyacc = {0.f, 0.f, 0.f, 0.f};
-        {
-            const float d0 = (kq < NH) ? sm[j * NH + kq] : 0.f;
-            const float d1 = (4 + kq < NH) ? sm[j * NH + 4 + kq] : 0.f;
-            dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(whb[0], d0, dyacc, 0, 0, 0);
-            dyacc = __builtin_amdgcn_mfma_f32_16x16x4f32(whb[1], d1, dyacc, 0, 0, 0);
-        }
-        const float kp = keep ? sm[112 + j] : 1.f;                           // keep[env j][t]
-        const float gi[4] = {pf[0].x, pf[0].y, pf[0].z, pf[0].w}, gf[4] = {pf[1].x, pf[1].y, pf[1].z, pf[1].w};
-        const float gg[4] = {pf[2].x, pf[2].y, pf[2].z, pf[2].w}, go[4] = {pf[3].x, pf[3].y, pf[3].z, pf[3].w};
-        const float cp[4] = {pf[4].x, pf[4].y, pf[4].z, pf[4].w};
-        float dg[4][4];                                                      // [gate][unit r]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float dh = dyacc[r] + dh_rec[r];
-            const float c = gf[r] * cp[r] + gi[r] * gg[r];
-            const float tch = tanhf_(c);
-            const float dc = dh * go[r] * (1.0f - tch * tch) + dc_next[r];
-            dg[0][r] = dc * gg[r] * gi[r] * (1.0f - gi[r]);
-            dg[1][r] = dc * cp[r] * gf[r] * (1.0f - gf[r]);
-            dg[2][r] = dc * gi[r] * (1.0f - gg[r] * gg[r]);
-            dg[3][r] = dh * tch * go[r] * (1.0f - go[r]);
-            dc_next[r] = dc * gf[r] * kp;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned short b[3][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                __bf16 p0, p1, p2;
-                split3(dg[q][r], p0, p1, p2);
-                b[0][r] = bf_bits(p0); b[1][r] = bf_bits(p1); b[2][r] = bf_bits(p2);
-            }
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                uint2 v;
-                v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
-                v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
-                *reinterpret_cast<uint2*>(dgp + pc * PLANE + j * SP + q * H + uo) = v;
-            }
-            if (live)
-                                *reinterpret_cast<float4*>(dgates + (srow + t) * (4 * H) + q * H + uo) =
-                    float4{dg[q][0], dg[q][1], dg[q][2], dg[q][3]};
-        }
-        // refill this wave's ring slot with step t-2 (its reads of the slot have returned: lgkmcnt(0))
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue(t >= 2 ? t - 2 : 0, t & 1);
-        lds_barrier();           // b1: planes of step t complete; nobody reads the small image of step t any more
-        if (small_wave) issue_small(t >= 2 ? t - 2 : 0, t & 1);
-        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-        const unsigned short* brow = dgp + j * SP + 8 * kq;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            bf16x8 b0[3];
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) b0[pc] = *reinterpret_cast<const bf16x8*>(brow + pc * PLANE + 32 * s);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][0], b0[2], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][1], b0[1], a1, 0, 0, 0);
-            const bf16x8 w2 = (s < SPK) ? wpk[s * 64] : wa2[s < SPK ? 0 : s - SPK];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, b0[0], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][0], b0[1], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][1], b0[0], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s][0], b0[0], a1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dh_rec[r] = (a0[r] + a1[r]) * kp;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // retire the clamped tail DMAs before the LDS is released
-    if (live) {
-        if (dh0) *reinterpret_cast<float4*>(dh0 + (size_t)n * H + uo) = float4{dh_rec[0], dh_rec[1], dh_rec[2], dh_rec[3]};
-        if (dc0) *reinterpret_cast<float4*>(dc0 + (size_t)n * H + uo) = float4{dc_next[0], dc_next[1], dc_next[2], dc_next[3]};
-    }
-}
-
 // ------------------------------------------------------- backward, split-bf16 MFMA, K split over the waves
-// lstm_bwd_x6_kernel gives every wave 16 output units and the whole K = 4H of dG: each wave reads all three
-// piece planes of the step's gate gradients back from LDS (48 b128 fragments, 384 KB per step and CU -- as many
-// cycles of LDS bandwidth as the MFMAs take) behind a barrier.  With HBM taken out of the picture that kernel
-// still needs 0.52 of its 0.62 ms: it is bound by this exchange, not by memory.
+// dh_{t-1}^T = W_hh^T dG_t^T on the bf16 matrix pipe at f32 accuracy (3-way split, six products; see
+// lstm_fwd_x6_kernel), weights as the A operand: lane (j, kq) owns env j and the four consecutive units uo..uo+3.
+// Giving every wave 16 OUTPUT units and the whole K = 4H of dG (the first form built) makes each wave read all three
+// piece planes of the step's gate gradients back from LDS (48 b128 fragments, 384 KB per step and CU -- as many cycles
+// of LDS bandwidth as the MFMAs take) behind a barrier: 0.52 of 0.62 ms with HBM taken out of the picture.
 // Here the K dimension is split instead: wave w multiplies ONLY the 64 gate gradients it produced itself
 // (gates x its 16 units -- they already sit in the right lanes: the MFMA's k order is free, so lane (j, kq)
 // supplies k = (gate, unit 16w + 4kq + r) of its own env j) against W_hh[those 64 rows][all H units], and writes
@@ -1337,6 +965,9 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_x6_kernel(
 // fixed order.  LDS traffic per step drops from 384 + 48 KB to 64 + 64 KB, the gate gradients never go to LDS,
 // and the MFMAs start right after the pointwise without waiting for anybody.  The stash ring needs a single
 // slot: the refill for step t-1 is issued at the TOP of step t, right after the slot is read, a full step ahead.
+// Stash by LDS-DMA (global_load_lds: no VGPR destination): each wave gathers exactly what its own lanes read back, so
+// the only ordering needed is the wave's own counted s_waitcnt vmcnt(k) = "everything but the k ops issued last has
+// landed" (loads, stores and LDS-DMA retire in issue order; the DMA ops of a step are issued unconditionally).
 template <int H>
 struct BwdKGeom {
     static constexpr int NW = H / 16;
@@ -1404,7 +1035,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_x6k_kernel(
     }
     const size_t srow = (size_t)n * T;
 
-    // ---- LDS-DMA (inline asm, see lstm_bwd_dma_kernel): stash gather [q][env lane/4][units 4 (lane%4) ..]
+    // ---- LDS-DMA (inline asm; ordering: comment above BwdKGeom): stash gather [q][env lane/4][units 4 (lane%4) ..]
     typedef __attribute__((address_space(3))) float lds_f;
     const int e_d = lane >> 2, g4 = lane & 3;
     const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
@@ -1610,7 +1241,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_h3k_kernel(
     }
     const size_t srow = (size_t)n * T;
 
-    // ---- LDS-DMA (inline asm, see lstm_bwd_dma_kernel): stash gather [q][env lane/4][units 4 (lane%4) ..]
+    // ---- LDS-DMA (inline asm; ordering: comment above BwdKGeom): stash gather [q][env lane/4][units 4 (lane%4) ..]
     typedef __attribute__((address_space(3))) float lds_f;
     const int e_d = lane >> 2, g4 = lane & 3;
     const size_t drow = (size_t)min(n0 + e_d, N - 1) * T;
@@ -1775,12 +1406,7 @@ static int launch_bwd_h3k(const float* keep, const float* stash, const float* w_
                           const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
                           float* dh0, float* dc0, hipStream_t st) {
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_h3k_kernel<H>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdH3Geom<H>::LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_bwd_h3k_kernel<H>), (int)BwdH3Geom<H>::LDS));
     hipLaunchKernelGGL((lstm_bwd_h3k_kernel<H>), grid, block, BwdH3Geom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
                        NH, dhn, dcn, N, T, dgates, dh0, dc0);
     UAV_LAUNCH_CHECK();
@@ -1792,47 +1418,8 @@ static int launch_bwd_x6k(const float* keep, const float* stash, const float* w_
                           const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
                           float* dh0, float* dc0, hipStream_t st) {
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_x6k_kernel<H>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdKGeom<H>::LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_bwd_x6k_kernel<H>), (int)BwdKGeom<H>::LDS));
     hipLaunchKernelGGL((lstm_bwd_x6k_kernel<H>), grid, block, BwdKGeom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
-                       NH, dhn, dcn, N, T, dgates, dh0, dc0);
-    UAV_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int H>
-static int launch_bwd_x6(const float* keep, const float* stash, const float* w_hh, const float* dheads,
-                         const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
-                         float* dh0, float* dc0, hipStream_t st) {
-    const dim3 grid((N + MT - 1) / MT), block(H * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_x6_kernel<H>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdX6Geom<H>::LDS));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((lstm_bwd_x6_kernel<H>), grid, block, BwdX6Geom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
-                       NH, dhn, dcn, N, T, dgates, dh0, dc0);
-    UAV_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int H>
-static int launch_bwd_dma(const float* keep, const float* stash, const float* w_hh, const float* dheads,
-                          const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
-                          float* dh0, float* dc0, hipStream_t st) {
-    const dim3 grid((N + MT - 1) / MT), block(H * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_dma_kernel<H>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdDmaGeom<H>::LDS));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((lstm_bwd_dma_kernel<H>), grid, block, BwdDmaGeom<H>::LDS, st, keep, stash, w_hh, dheads, w_head,
                        NH, dhn, dcn, N, T, dgates, dh0, dc0);
     UAV_LAUNCH_CHECK();
     return 0;
@@ -1846,14 +1433,8 @@ static int launch_fwd(bool fuse, const float* x, const float* keep, const float*
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
     if (!f32_mfma_requested() && !bf16x6_requested()) {   // default: three fp16 piece products on the matrix pipe (f32 accuracy)
         const size_t lx = FwdH3Geom<H>::LDS;
-        static bool attr_set = false;
-        if (!attr_set) {
-            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_h3_kernel<H, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
-            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_h3_kernel<H, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
-            attr_set = true;
-        }
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_fwd_h3_kernel<H, true>), (int)lx));
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_fwd_h3_kernel<H, false>), (int)lx));
         if (fuse)
             hipLaunchKernelGGL((lstm_fwd_h3_kernel<H, true>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
                                b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, NHD, heads);
@@ -1866,14 +1447,8 @@ static int launch_fwd(bool fuse, const float* x, const float* keep, const float*
     }
     if (!f32_mfma_requested()) {         // UAV_LSTM_BF16X6=1: the six-product bf16 split
         const size_t lx = FwdX6Geom<H>::LDS;
-        static bool attr_set = false;
-        if (!attr_set) {
-            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_x6_kernel<H, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
-            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_x6_kernel<H, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lx));
-            attr_set = true;
-        }
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_fwd_x6_kernel<H, true>), (int)lx));
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_fwd_x6_kernel<H, false>), (int)lx));
         if (fuse)
             hipLaunchKernelGGL((lstm_fwd_x6_kernel<H, true>), grid, block, lx, st, x, keep, h0, c0, w_ih, w_hh, b_ih,
                                b_hh, N, T, I, y, hn, cn, stash, w_head, b_head, NHD, heads);
@@ -1900,12 +1475,7 @@ static int launch_bwd(const float* keep, const float* stash, const float* w_hh, 
                       const float* w_head, int NH, const float* dhn, const float* dcn, int N, int T, float* dgates,
                       float* dh0, float* dc0, hipStream_t st) {
     const dim3 grid((N + MT - 1) / MT), block(H * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BwdGeom<H>::LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_bwd_kernel<H>), (int)BwdGeom<H>::LDS));
     hipLaunchKernelGGL((lstm_bwd_kernel<H>), grid, block, BwdGeom<H>::LDS, st, keep, stash, w_hh, dy, dheads, w_head, NH,
                        dhn, dcn, N, T, dgates, dh0, dc0);
     UAV_LAUNCH_CHECK();
@@ -1921,30 +1491,19 @@ __global__ void add2_kernel(const float* a0, const float* a1, float* b, int n) {
 static int lstm_bwd_seq(const float* keep, const float* stash, const float* w_hh, const float* dy,
                         const float* dheads, const float* w_head, int NH, const float* dhn, const float* dcn, int N,
                         int T, int H, float* dgates, float* dh0, float* dc0, hipStream_t st) {
-    if (dheads && NH <= 7 && !f32_mfma_requested() && !bf16x6_requested() && !getenv("UAV_BWD_NSPLIT")) {   // the PPO path: split-fp16, K split over waves
+    if (dheads && NH <= 7 && !f32_mfma_requested() && !bf16x6_requested()) {   // the PPO path: split-fp16, K split over waves
         switch (H) {
             case 64: return launch_bwd_h3k<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
             case 128: return launch_bwd_h3k<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
         }
     }
-    if (dheads && NH <= 7 && !f32_mfma_requested() && !getenv("UAV_BWD_NSPLIT")) {   // UAV_LSTM_BF16X6=1: split-bf16, K split over waves
+    if (dheads && NH <= 7 && !f32_mfma_requested()) {   // UAV_ARITH_BF16X6: split-bf16 (f32's exponent range), K split over waves
         switch (H) {
             case 64: return launch_bwd_x6k<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
             case 128: return launch_bwd_x6k<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
         }
     }
-    if (dheads && NH <= 7 && !f32_mfma_requested()) {   // split-bf16, output units split over waves (dG exchanged through LDS)
-        switch (H) {
-            case 64: return launch_bwd_x6<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
-            case 128: return launch_bwd_x6<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
-        }
-    }
-    if (dheads && !getenv("UAV_BWD_NO_DMA")) {          // exact-f32 MFMA, LDS-DMA stash prefetch variant
-        switch (H) {
-            case 64: return launch_bwd_dma<64>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
-            case 128: return launch_bwd_dma<128>(keep, stash, w_hh, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
-        }
-    }
+    // exact-f32 MFMA (UAV_ARITH_F32_MFMA), plain dy (stacked layers), more than 7 heads
     switch (H) {
         case 64: return launch_bwd<64>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
         case 128: return launch_bwd<128>(keep, stash, w_hh, dy, dheads, w_head, NH, dhn, dcn, N, T, dgates, dh0, dc0, st);
@@ -1960,7 +1519,7 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
                  float* hn, float* cn, float* stash, const float* w_head, const float* b_head, int n_heads, float* heads,
                  uav_stream stream) {
     UAV_REQUIRE(ctx && x && h0 && c0 && w_ih && w_hh && b_ih && b_hh && y && hn && cn, "uav_lstm_fwd: NULL argument");
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     UAV_REQUIRE(N > 0 && T > 0 && I > 0, "uav_lstm_fwd: N=%d T=%d I=%d", N, T, I);
     UAV_REQUIRE(!heads || (w_head && b_head && n_heads > 0 && n_heads <= 8), "uav_lstm_fwd: heads needs w_head, b_head, 1..8 heads");
     hipStream_t st = as_stream(stream);
@@ -1998,14 +1557,14 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
 int uav_lstm_bwd_caps(uav_ctx* ctx, int I, int H) {
     if (!ctx) return 0;
     if (H == 64 || H == 128) return UAV_BWD_TAKES_DHEADS;            // the persistent sequence kernels
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     return lstm_generic_bwd_caps(I, H);
 }
 
 int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
                        const float* w_head, int n_heads, int N, int T, int H, uav_stream stream) {
     UAV_REQUIRE(ctx && layers, "uav_lstm_bwd_stack: NULL argument");
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd_stack: give exactly one of dy / dheads");
     UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd_stack: dheads needs w_head and 1..8 heads");
     UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd_stack: N=%d T=%d", N, T);
@@ -2018,7 +1577,7 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
                  int T, int H, float* dgates, float* dh0, float* dc0, const float* w_ih, int I, float* dx,
                  uav_stream stream) {
     UAV_REQUIRE(ctx && stash && w_hh && dgates, "uav_lstm_bwd: NULL argument");
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     UAV_REQUIRE((dy != nullptr) != (dheads != nullptr), "uav_lstm_bwd: give exactly one of dy / dheads");
     UAV_REQUIRE(!dheads || (w_head && n_heads > 0 && n_heads <= 8), "uav_lstm_bwd: dheads needs w_head and 1..8 heads");
     UAV_REQUIRE(N > 0 && T > 0, "uav_lstm_bwd: N=%d T=%d", N, T);
@@ -2036,7 +1595,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
                    int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* dw_head, float* dx,
                    uav_stream stream) {
     UAV_REQUIRE(ctx && x && h0 && y && dgates && w_ih && dw_ih && dw_hh && db, "uav_lstm_wgrad: NULL argument");
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     UAV_REQUIRE(N > 0 && T > 0 && I > 0 && H > 0, "uav_lstm_wgrad: N=%d T=%d I=%d H=%d", N, T, I, H);
     UAV_REQUIRE(!dheads || (dw_head && n_heads > 0 && n_heads <= 8), "uav_lstm_wgrad: dheads needs dw_head, 1..8 heads");
     hipStream_t st = as_stream(stream);
@@ -2057,8 +1616,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         // the bf16 split was asked for: dG is block-scaled by one power of two from its absolute maximum, which the bias
         // gradient's column-sum pass (it reads all of dG anyway) delivers; h_prev, x and W_ih are inside fp16's range
         // under the same preconditions as the sequence kernels' (include/uavppo.h, uav_set_lstm_arith).
-        const bool h3 = !uav_want_f32_mfma() && !uav_want_bf16x6() && (4 * H) % 4 == 0 &&
-                        (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
+        const bool h3 = !uav_want_f32_mfma() && !uav_want_bf16x6() && (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
         unsigned* amax = h3 ? reinterpret_cast<unsigned*>(red + (size_t)1024 * 9 * 4 * H) : nullptr;
         // a narrow input (layer 1: obs + trend, I <= 8): dW_ih = dG^T x rides on the bias gradient's pass over dG
         const bool narrow = I <= 8 && (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;

@@ -660,7 +660,12 @@ __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ 
     *reinterpret_cast<f16x8*>(o + 512) = b;
 }
 
-static bool h3_step_ok(int H) { return H == 256 && !uav_want_f32_mfma() && !getenv("UAV_LSTM_STEP_F32"); }
+// The h = 256 step kernels exist in the fp16-split form only (|w| < 65504, |x| < 4096): BOTH other modes -- exact f32 and the
+// bf16 split, which callers select precisely because operands left that range -- take the generic exact-f32 step path
+// (gemm_f32 + gen_cell_*), uav_lstm_bwd_caps reports 0 and the stepper refuses.
+static bool h3_step_ok(int H) {
+    return H == 256 && !uav_want_f32_mfma() && !uav_want_bf16x6() && !uav_debug(UAV_DEBUG_STEP_F32);
+}
 
 // fp16-split step path of uav_lstm_fwd for h = 256 (input projection included: the caller does NOT pre-fill the stash)
 int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
@@ -697,7 +702,7 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
     const int ntile = (N + 63) / 64 * 4;
     const size_t x_step = (size_t)ntile * (IP / 32) * 1024 * 2;            // bytes of one step's planes
     int TC = 0;
-    if (I == IP && I >= 64 && !getenv("UAV_LSTM_X_F32")) {
+    if (I == IP && I >= 64 && !uav_debug(UAV_DEBUG_X_F32)) {
         const size_t room = ctx->ws_bytes - need - (64u << 20);
         TC = (int)(room / x_step < 16 ? room / x_step : 16);
     }
@@ -764,7 +769,7 @@ int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const f
                            const float* b_hh, const float* h0, const float* c0, int N, int I, int H, uav_stream stream) {
     UAV_REQUIRE(ctx && state && w_ih && w_hh && b_ih && b_hh && h0 && c0, "uav_lstm_stepper_begin: NULL argument");
     UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0, "uav_lstm_stepper_begin: H = %d, I = %d not supported (H = 256, I <= 256)", H, I);
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     UAV_REQUIRE(h3_step_ok(H), "uav_lstm_stepper_begin: only the fp16-split arithmetic steps (uav_set_lstm_arith)");
     const StepperLayout L = stepper_layout(N, I);
     char* b = (char*)state;
@@ -785,7 +790,7 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
                           int I, int H, float* y, float* stash, float* hn, float* cn, uav_stream stream) {
     UAV_REQUIRE(ctx && state && x && y && stash && hn && cn, "uav_lstm_stepper_step: NULL argument");
     UAV_REQUIRE(uav_lstm_stepper_bytes(N, I, H) != 0 && T > 0 && t >= 0 && t < T, "uav_lstm_stepper_step: bad shape (N=%d T=%d t=%d I=%d H=%d)", N, T, t, I, H);
-    g_uav_arith = ctx->lstm_arith;
+    uav_enter(ctx);
     UAV_REQUIRE(h3_step_ok(H), "uav_lstm_stepper_step: only the fp16-split arithmetic steps (uav_set_lstm_arith)");
     const StepperLayout L = stepper_layout(N, I);
     char* b = (char*)state;
@@ -867,12 +872,7 @@ struct H3Bwd {
     }
 };
 static int h3_bwd_attr() {
-    static bool cell_attr = false;
-    if (!cell_attr) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)CELL_BWD_LDS));
-        cell_attr = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<256>), (int)CELL_BWD_LDS));
     return 0;
 }
 
@@ -904,6 +904,12 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
     UAV_REQUIRE((size_t)nl * need + (64u << 20) <= ctx->ws_bytes, "uav_lstm_bwd_stack: workspace too small for %d layers", nl);
     int rc;
     if ((rc = h3_bwd_attr())) return rc;
+    // every argument is checked BEFORE the side streams are forked: an error return must not leave work queued on them
+    for (int l = 0; l < nl; ++l) {
+        const uav_lstm_bwd_layer& a = layers[l];
+        UAV_REQUIRE(a.stash && a.w_hh && a.dgates, "uav_lstm_bwd_stack: layer %d: NULL stash / w_hh / dgates", l);
+        UAV_REQUIRE(l + 1 == nl || (a.w_ih && a.dx), "uav_lstm_bwd_stack: layer %d feeds the layer below: w_ih and dx are required", l);
+    }
     for (int l = 0; l + 1 < nl; ++l)
         if (!ctx->side[l]) UAV_CHECK_HIP(hipStreamCreateWithFlags(&ctx->side[l], hipStreamNonBlocking));
     for (auto& e : ctx->side_ev)
@@ -912,14 +918,23 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
     // fork: the side streams start behind everything the caller has queued
     UAV_CHECK_HIP(hipEventRecord(ctx->side_ev[0], st));
     for (int l = 1; l < nl; ++l) UAV_CHECK_HIP(hipStreamWaitEvent(str[l], ctx->side_ev[0], 0));
+    // join: the caller's stream continues behind everything queued on the side streams (also on the error paths below)
+    auto join = [&]() -> int {
+        for (int l = 1; l < nl; ++l) {
+            UAV_CHECK_HIP(hipEventRecord(ctx->side_ev[1], str[l]));
+            UAV_CHECK_HIP(hipStreamWaitEvent(st, ctx->side_ev[1], 0));
+        }
+        return 0;
+    };
     H3Bwd L[4];
     for (int l = 0; l < nl; ++l) {
         const uav_lstm_bwd_layer& a = layers[l];
-        UAV_REQUIRE(a.stash && a.w_hh && a.dgates, "uav_lstm_bwd_stack: layer %d: NULL stash / w_hh / dgates", l);
-        UAV_REQUIRE(l + 1 == nl || (a.w_ih && a.dx), "uav_lstm_bwd_stack: layer %d feeds the layer below: w_ih and dx are required", l);
         L[l] = H3Bwd{a.keep, a.stash, l == 0 ? dy : layers[l - 1].dx, l == 0 ? dheads : nullptr, l == 0 ? w_head : nullptr,
                      l == 0 ? n_heads : 0, N, T, a.dgates, a.dx};
-        if ((rc = L[l].prepare((char*)ctx->ws + ctx->ws_bytes - (size_t)(l + 1) * need, a.w_hh, a.w_ih, a.dhn, a.dcn, str[l]))) return rc;
+        if ((rc = L[l].prepare((char*)ctx->ws + ctx->ws_bytes - (size_t)(l + 1) * need, a.w_hh, a.w_ih, a.dhn, a.dcn, str[l]))) {
+            (void)join();
+            return rc;
+        }
     }
     // the wave front: at round r layer l runs its step T - 1 - (r - l); the hand-off events form a ring per boundary
     hipEvent_t* ring = ctx->side_ev + 2;                       // 6 events: two per boundary
@@ -932,11 +947,7 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
             if (l + 1 < nl) UAV_CHECK_HIP(hipEventRecord(ring[2 * l + (t & 1)], str[l]));
         }
     for (int l = 0; l < nl; ++l) L[l].finish(layers[l].dh0, layers[l].dc0, str[l]);
-    // join
-    for (int l = 1; l < nl; ++l) {
-        UAV_CHECK_HIP(hipEventRecord(ctx->side_ev[1], str[l]));
-        UAV_CHECK_HIP(hipStreamWaitEvent(st, ctx->side_ev[1], 0));
-    }
+    if ((rc = join())) return rc;
     UAV_LAUNCH_CHECK();
     return 0;
 }

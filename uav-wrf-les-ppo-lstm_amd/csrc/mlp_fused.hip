@@ -812,12 +812,7 @@ int launch_rollout_mlp(uav_ctx* ctx, void* env_state, int n_env, const uav_env_c
     UAV_REQUIRE(P.trend_k == 0, "uav_rollout: the fused MLP rollout has 6 observation features (trend_k = 0)");
     MlpRollBufs B{cur_obs, obs, act, rew, val, logp, done, flags, last_val, forced_act, noise, nan_count, info, heads};
     EnvBlob blob = env_blob_view(env_state, n_env);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_mlp_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROLL_LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&rollout_mlp_kernel), (int)ROLL_LDS));
     hipLaunchKernelGGL(rollout_mlp_kernel, dim3((n_env + MT - 1) / MT), dim3(512), ROLL_LDS, st, P, blob, n_env, horizon, iter,
                        params, B);
     UAV_LAUNCH_CHECK();
@@ -843,12 +838,7 @@ extern "C" int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* 
     float* w2t = (float*)((char*)ctx->ws + head);
     float* slabs = (float*)((char*)ctx->ws + head + w2t_bytes);
     hipLaunchKernelGGL(mlp_w2_transpose_kernel, dim3(H1 * H2 / 256), dim3(256), 0, st, params, w2t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ppo_grad_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)UPD_LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&mlp_ppo_grad_kernel), (int)UPD_LDS));
     hipLaunchKernelGGL(mlp_ppo_grad_kernel, dim3(nb), dim3(512), UPD_LDS, st, params, obs, act, logp_old, adv, ret, val_old, n,
                        inv_n, clip, ent_beta, partial, slabs, w2t);
     hipLaunchKernelGGL(mlp_slab_reduce_kernel, dim3((SLAB + 255) / 256), dim3(256), 0, st, slabs, nb, SLAB, grad);

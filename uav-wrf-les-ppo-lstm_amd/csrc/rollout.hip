@@ -525,12 +525,7 @@ template <int H>
 static int launch_rollout(const EnvParams& P, EnvBlob blob, int N, int T, uint64_t iter, const float* params,
                           const RolloutBufs& B, hipStream_t st) {
     const dim3 grid((N + RMT - 1) / RMT), block(H * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_lstm_kernel<H, 5>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)RGeom<H>::LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&rollout_lstm_kernel<H, 5>), (int)RGeom<H>::LDS));
     hipLaunchKernelGGL((rollout_lstm_kernel<H, 5>), grid, block, RGeom<H>::LDS, st, P, blob, N, T, iter, params, B);
     UAV_LAUNCH_CHECK();
     return 0;

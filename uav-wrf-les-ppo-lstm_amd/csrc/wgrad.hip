@@ -162,150 +162,6 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_kernel(
     for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
 }
 
-// ------------------------------------------------------------------------------ LDS-DMA variant
-// Same products, but every operand reaches LDS by global_load_lds (inline asm, invisible to hipcc's
-// wait insertion) TWO chunks ahead into a 3-stage ring: the register-staged version above can only
-// run one chunk (~2 us of MFMAs) ahead, which does not cover the HBM latency under load (ablation:
-// loads cost 0.17 of 0.86 ms).  Every wave issues exactly DMA_OPS (= 8) operations per chunk, so one counted
-// s_waitcnt vmcnt(8) per chunk ("my operations for chunk c have landed; those for c+1 may fly")
-// plus the workgroup barrier orders everything.  No other vector-memory operation exists in the loop.
-// Needs full chunks (rows per block and N*T multiples of 16); other shapes use the kernel above.
-// LDS images: dG rows padded (stride 4H+16, conflict-free); Hprev / Y rows are DMA-linear (stride H:
-// the 16 x ds_read_b32 B-fragment reads per k-step are 2-way conflicted, negligible beside 37 MFMAs);
-// x / dheads / keep arrive as raw [16][6] / [16] dword images; the keep mask of h_prev is applied to
-// the B fragments, the ones column (db) is a constant.
-template <int H>
-struct WGD {
-    static constexpr int NW = H / 16;
-    static constexpr int NT_ = H / 16 + 1;
-    static constexpr int NC = H + 16;
-    static constexpr int SG = 4 * H + 16;
-    static constexpr int IPR = 4 * H / 256;                       // 1-KiB DMA pieces per dG row
-    static constexpr int STAGE = KC * SG + 2 * KC * H + 128 + 128 + 64 + 64;   // dG | Hprev | Y | x | dheads | keep | dummy
-    static constexpr size_t LDS = 3 * STAGE * sizeof(float);
-    static constexpr size_t SLAB = (size_t)4 * H * NC + 16 * H;
-    static constexpr int DMA_OPS = 8;                             // per wave per chunk: 4 dG + Hprev + Y + two small
-};
-
-__device__ __forceinline__ void dma16(unsigned lds_byte, const float* g) {      // 64 lanes x 16 B -> 1 KiB at lds_byte
-    unsigned keepm0;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keepm0) : "v"(g), "s"(lds_byte) : "memory");
-}
-__device__ __forceinline__ void dma4(unsigned lds_byte, const float* g) {       // 64 lanes x 4 B -> 256 B at lds_byte
-    unsigned keepm0;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keepm0) : "v"(g), "s"(lds_byte) : "memory");
-}
-
-template <int H>
-__global__ __launch_bounds__(H * 4) void lstm_wgrad_dma_kernel(
-    const float* __restrict__ dgates, const float* __restrict__ y, const float* __restrict__ keep,
-    const float* __restrict__ h0, const float* __restrict__ x, int I, const float* __restrict__ dheads, int NH,
-    const float* __restrict__ ones64, int N, int T, int64_t rows_per_block, float* __restrict__ slabs) {
-    using G = WGD<H>;
-    constexpr int NT_ = G::NT_, SG = G::SG, IPR = G::IPR, STAGE = G::STAGE;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    typedef __attribute__((address_space(3))) float lds_f;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, kq = lane >> 4;
-    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
-    const int nchunk = (int)(rows_per_block / KC);
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)smem));
-
-    f32x4 acc[4][NT_];
-    f32x4 acch = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT_; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // stage layout (float offsets)
-    constexpr int OG = 0, OH = KC * SG, OY = OH + KC * H, OX = OY + KC * H, OD = OX + 128, OK = OD + 128, OZ = OK + 64;
-    auto issue = [&](int c) {            // exactly DMA_OPS operations per wave
-        const int cc = c < nchunk ? c : nchunk - 1;                 // clamped tail keeps the op count uniform
-        const int64_t base = r_begin + (int64_t)cc * KC;
-        const unsigned st = lds0 + (unsigned)((c % 3) * STAGE * 4);
-        // dG: 16 rows x IPR pieces; this wave takes pieces [4w, 4w+4)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = 4 * w + i, row = piece / IPR, part = piece % IPR;
-            dma16(st + (unsigned)((OG + row * SG + part * 256) * 4), dgates + (base + row) * (4 * H) + part * 256 + 4 * lane);
-        }
-        {   // Hprev and Y: H floats per row -> 1 KiB = (256/H) rows per piece, 16*H/256 = NW... pieces: one per wave
-            constexpr int RPP = 256 / H;                             // rows per 1-KiB piece (2 at H=128, 4 at H=64)
-            const int row = w * RPP + lane / (H / 4), c4 = lane % (H / 4);
-            const int64_t r = base + row;
-            const int64_t n = r / T;
-            const int t = (int)(r - n * T);
-            const float* src = (t == 0) ? (h0 + n * H) : (y + (r - 1) * H);          // h_prev = y[n][t-1] (or h0[n])
-            dma16(st + (unsigned)((OH + w * 256) * 4), src + 4 * c4);
-            dma16(st + (unsigned)((OY + w * 256) * 4), y + r * H + 4 * c4);
-        }
-        // two small 256-B pieces per wave from the list {x0, x1, dheads0, dheads1, keep, padding...}
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-            const int piece = 2 * w + k2;                            // wave-uniform
-            if (piece < 2) {
-                const int e = piece * 64 + lane;
-                dma4(st + (unsigned)((OX + piece * 64) * 4), x + base * I + (e < 16 * I ? e : 0));
-            } else if (piece < 4 && dheads) {
-                const int e = (piece - 2) * 64 + lane;
-                dma4(st + (unsigned)((OD + (piece - 2) * 64) * 4), dheads + base * NH + (e < 16 * NH ? e : 0));
-            } else if (piece == 4 && keep) {
-                dma4(st + (unsigned)(OK * 4), keep + base + (lane < KC ? lane : 0));
-            } else {
-                dma4(st + (unsigned)(OZ * 4), ones64 + lane);        // padding: keeps the op count uniform
-            }
-        }
-    };
-    issue(0);
-    issue(1);
-    for (int c = 0; c < nchunk; ++c) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // = DMA_OPS: this wave's pieces of chunk c landed
-        lds_barrier();                                             // ... and everyone else's; stage (c+2)%3 is free
-        issue(c + 2);
-        const float* st = smem + (c % 3) * STAGE;
-        const float* lg = st + OG;
-        const float* lh = st + OH;
-        const float* ly = st + OY;
-        const float* lx = st + OX;
-        const float* ld = st + OD;
-        const float* lk = st + OK;
-#pragma unroll
-        for (int s = 0; s < KC / 4; ++s) {
-            const int kr = 4 * s + kq;
-            const float kp = keep ? lk[kr] : 1.f;
-            float a[4], b[NT_];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = lg[kr * SG + 64 * w + 16 * mi + j];
-#pragma unroll
-            for (int ni = 0; ni < NT_ - 1; ++ni) b[ni] = lh[kr * H + 16 * ni + j] * kp;
-            b[NT_ - 1] = (j < I) ? lx[kr * I + j] : (j == 6 ? 1.f : 0.f);            // x columns | ones (db) | pad
-            const float ah = (dheads && j < NH) ? ld[kr * NH + j] : 0.f;
-            const float bh = ly[kr * H + 16 * w + j];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT_; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            acch = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bh, acch, 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // retire the clamped tail DMAs
-    float* slab = slabs + (size_t)blockIdx.x * G::SLAB;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT_; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                slab[(size_t)(64 * w + 16 * mi + 4 * kq + r) * G::NC + 16 * ni + j] = acc[mi][ni][r];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) slab[(size_t)4 * H * G::NC + (size_t)(4 * kq + r) * H + 16 * w + j] = acch[r];
-}
-
 // ------------------------------------------------------------------------------ split-bf16 variant
 // The same products on the bf16 matrix pipe at f32 accuracy (see lstm.hip, lstm_fwd_x6_kernel): both operands
 // are split exactly into three bf16 pieces and the six piece products with i + j <= 2 are accumulated in f32
@@ -912,12 +768,7 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
     int64_t rpb = (NTr + nb - 1) / nb;
     rpb = (rpb + KC - 1) / KC * KC;
     nb = (int)((NTr + rpb - 1) / rpb);
-    static bool attr_set = false;
-    if (!attr_set) {
-        UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_kernel<H>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
-        attr_set = true;
-    }
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_wgrad_kernel<H>), (int)G::LDS));
     float* slabs = (float*)ctx->ws;
     // split-bf16 variant: full 32-row slabs everywhere, T >= 8 (at most one sequence start per 8 rows)
     {
@@ -928,25 +779,13 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
                            (y_prev_src == ytop || ytop == nullptr) && !uav_want_f32_mfma();
         if (x6_ok) {
             using GX = WGX<H>;
-            static bool attr3 = false;
-            if (!attr3) {
-                UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_x6_kernel<H, true>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX::LDS));
-                UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_x6_kernel<H, false>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GX::LDS));
-                attr3 = true;
-            }
-            const bool h3 = !uav_want_bf16x6() && !getenv("UAV_WGRAD_BF16X6");
+            UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_wgrad_x6_kernel<H, true>), (int)GX::LDS));
+            UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_wgrad_x6_kernel<H, false>), (int)GX::LDS));
+            const bool h3 = !uav_want_bf16x6();
             if (h3) {
                 using GH = WGH<H>;
-                static bool attr4 = false;
-                if (!attr4) {
-                    UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_h3_kernel<H, true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GH::LDS));
-                    UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_h3_kernel<H, false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GH::LDS));
-                    attr4 = true;
-                }
+                UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_wgrad_h3_kernel<H, true>), (int)GH::LDS));
+                UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_wgrad_h3_kernel<H, false>), (int)GH::LDS));
                 if (dheads)
                     hipLaunchKernelGGL((lstm_wgrad_h3_kernel<H, true>), dim3(nbx), dim3(H * 4), GH::LDS, st, dgates, y_prev_src,
                                        keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
@@ -965,21 +804,7 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
             return 0;
         }
     }
-    // LDS-DMA variant: full 16-row chunks everywhere, I <= 6 dword images, at least 2 chunks per block
-    const bool dma_ok = (NTr % rpb == 0) && (rpb % KC == 0) && (rpb / KC >= 2) && I <= 6 && (!dheads || NH <= 6) &&
-                        (y_prev_src == ytop || ytop == nullptr) && !getenv("UAV_WGRAD_NO_DMA");
-    if (dma_ok) {
-        using GD = WGD<H>;
-        static bool attr2 = false;
-        if (!attr2) {
-            UAV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_wgrad_dma_kernel<H>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)GD::LDS));
-            attr2 = true;
-        }
-        const float* ones64 = reinterpret_cast<const float*>(ctx->pow075);   // any readable 256 B: source of the padding DMAs
-        hipLaunchKernelGGL((lstm_wgrad_dma_kernel<H>), dim3(nb), dim3(H * 4), GD::LDS, st, dgates, y_prev_src, keep, h0, x, I,
-                           dheads, NH, ones64, N, T, rpb, slabs);
-    } else
+    // exact-f32 MFMA (UAV_ARITH_F32_MFMA), ragged shapes the split kernels do not take
     hipLaunchKernelGGL((lstm_wgrad_kernel<H>), dim3(nb), dim3(H * 4), G::LDS, st, dgates, y_prev_src, keep, h0, x, I, ytop,
                        dheads, NH, N, T, rpb, slabs);
     hipLaunchKernelGGL((wgrad_reduce_kernel<H>), dim3((unsigned)((G::SLAB + 255) / 256)), dim3(256), 0, st, slabs, nb, I,

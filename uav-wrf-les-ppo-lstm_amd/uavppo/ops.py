@@ -232,6 +232,28 @@ def set_lstm_arith(mode, device=None):
     check(lib().uav_set_lstm_arith(Context.get(device).handle, ARITH[mode]), "uav_set_lstm_arith")
 
 
+class lstm_arith:
+    """`with ops.lstm_arith("f32_mfma"):` -- run a block on another arithmetic, then restore the handle's mode."""
+
+    def __init__(self, mode, device=None):
+        self.mode, self.device = mode, device
+
+    def __enter__(self):
+        self.prev = get_lstm_arith(self.device)
+        set_lstm_arith(self.mode, self.device)
+
+    def __exit__(self, *exc):
+        set_lstm_arith(self.prev, self.device)
+
+
+DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2}
+
+
+def set_debug_flags(*names, device=None):
+    """A/B switches of the h = 256 step path on this device's handle (include/uavppo.h, UAV_DEBUG_*); no names = none."""
+    check(lib().uav_set_debug_flags(Context.get(device).handle, sum(DEBUG_FLAGS[n] for n in names)), "uav_set_debug_flags")
+
+
 def get_lstm_arith(device=None):
     m = int(lib().uav_get_lstm_arith(Context.get(device).handle))
     return {v: k for k, v in ARITH.items()}[m]

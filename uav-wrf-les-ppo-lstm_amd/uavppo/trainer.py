@@ -9,7 +9,6 @@ statistics (train_ppo2.0.py:35-39).
 """
 from __future__ import annotations
 
-import os
 
 import numpy as np
 import torch
@@ -91,6 +90,11 @@ class VecPPOTrainer:
         self._buffers_own = False    # True between a collect() and the update() that consumes its buffers
         self.arith = "fp16x3"
         self.range_events = 0        # iterations that ran on the wide-range (bf16-split) kernels
+        # force_arith: "fp16x3" | "bf16x6" | "f32_mfma" pins the LSTM kernels' arithmetic (A/B runs, reference gradients);
+        # None = the range guard decides.  A handle that uav_create started in another mode (UAV_LSTM_F32_MFMA=1 /
+        # UAV_LSTM_BF16X6=1 in the environment: a whole-process A/B) keeps it.
+        init_mode = ops.get_lstm_arith(self.device)
+        self.force_arith = None if init_mode == "fp16x3" else init_mode
         self._flat_version = -1
         # environments of this rank: global indices [rank*N, (rank+1)*N)
         self.env_state = torch.zeros(ops.env_state_bytes(N), dtype=torch.uint8, device=d)
@@ -105,6 +109,7 @@ class VecPPOTrainer:
         self._side = torch.cuda.Stream(device=self.device) if use_curriculum else None
         self._succ_host = (torch.zeros(self.world, 4 + SUCC_CAP + 1, dtype=torch.uint8).pin_memory() if use_curriculum else None)
         self._succ_ev = torch.cuda.Event()
+        self._pack_ev = torch.cuda.Event()
         self._roll_ev = torch.cuda.Event()
         self._succ_pending = False
         self._succ_exchanged = False
@@ -150,12 +155,16 @@ class VecPPOTrainer:
     #                and counters scaled to O(1); |h| < 1), so they are not measured in the loop.  Buffers filled by a
     #                caller (update() without a preceding collect()) ARE measured, synchronously, before the update.
     def _guarded(self):
-        return self.kind == "lstm" and self.policy.hidden in (64, 128)
+        """Every LSTM policy: the h = 64 / 128 sequence kernels AND the h = 256 step kernels are fp16-split by default.
+        (At h = 256 the wide-range modes run the generic exact-f32 step path -- slow, but never silently out of range.)"""
+        return self.kind == "lstm"
 
     def _decide(self, maxima):
         ok = all(v == v and v < lim for v, lim in zip(maxima, RANGE_LIMITS))
         self.arith = "fp16x3" if ok else "bf16x6"
         self.range_events += (not ok)
+        if self.force_arith is not None:
+            self.arith = self.force_arith
         return ok
 
     def _measure_params(self):
@@ -178,6 +187,8 @@ class VecPPOTrainer:
         """Kernel arithmetic for the update about to be queued (see above); sets it on the device's handle."""
         if not self._guarded():
             return self.arith
+        if self.force_arith is not None:
+            self.arith = self.force_arith
         if not self._buffers_own:               # foreign buffers: measure everything now
             self._pmax_queue.clear()
             ops.absmax(self.policy.flat, out=self.ranges[0:1])
@@ -200,11 +211,13 @@ class VecPPOTrainer:
     def collect(self, forced_act=None, noise=None):
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
         self._rollout_forward_valid = False
-        if self._succ_pending:                 # a previous rollout's flags are still being packed on the side stream
-            torch.cuda.current_stream().wait_event(self._succ_ev)
+        if self._succ_pending:                 # a previous rollout's flags may still be read by the pack kernel on the side stream
+            torch.cuda.current_stream().wait_event(self._pack_ev)
         if self._guarded():
             self.poll_param_range()
             self._measure_params()
+            if self.force_arith is not None:
+                self.arith = self.force_arith
             ops.set_lstm_arith(self.arith, self.device)
             self._buffers_own = True
         wide = self._guarded() and self.arith != "fp16x3"      # uav_rollout exists in the fp16-split form only
@@ -233,6 +246,7 @@ class VecPPOTrainer:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(self._roll_ev)
                 self._succ_msg = pack_local_successes(self.buf["flags"])
+                self._pack_ev.record(self._side)       # the flags have been read: the next rollout may overwrite them
             self._succ_pending = True
             self._succ_exchanged = False
             if not self._coll:
@@ -243,7 +257,11 @@ class VecPPOTrainer:
         issued from update(), BEHIND the advantage-statistics all-reduce in program order: RCCL runs a rank's collectives
         in the order they were issued, and that all-reduce must not queue behind the pack kernel."""
         with torch.cuda.stream(self._side):
-            self._succ_host.copy_(exchange_successes(self._succ_msg), non_blocking=True)
+            msgs = exchange_successes(self._succ_msg)
+            if tuple(msgs.shape) != tuple(self._succ_host.shape):       # e.g. world_size > 1 without a process group
+                raise RuntimeError(f"success exchange returned {tuple(msgs.shape)}, expected {tuple(self._succ_host.shape)}: "
+                                   "is torch.distributed initialised for world_size > 1?")
+            self._succ_host.copy_(msgs, non_blocking=True)
             self._succ_ev.record(self._side)
         self._succ_exchanged = True
 
@@ -264,7 +282,7 @@ class VecPPOTrainer:
         # rollout, state kept in its piece planes, stash / y / heads written at [:, t] of the update's own arrays, so that
         # PPO epoch 0 adopts this forward pass.  Otherwise one uav_lstm_fwd call of T = 1 per layer and step.
         stepper = (self.use_stepper and self.policy.hidden == 256 and self.arith == "fp16x3" and self.num_minibatches == 1
-                   and not os.environ.get("UAV_LSTM_F32_MFMA") and not os.environ.get("UAV_LSTM_STEP_F32"))
+                   and ops.lstm_bwd_caps(self.device, self.obs_dim, 256) != 0)      # 0: the handle is not on the fp16 step path
         if stepper:
             self.policy.begin_steps(self.h, self.c)
         for t in range(self.T):
@@ -435,7 +453,11 @@ class VecPPOTrainer:
         if self.curriculum is None:
             return
         if not self._succ_pending:             # flags not produced by collect(): pack and exchange them now
-            self._succ_host.copy_(exchange_successes(pack_local_successes(self.buf["flags"])), non_blocking=True)
+            msgs = exchange_successes(pack_local_successes(self.buf["flags"]))
+            if tuple(msgs.shape) != tuple(self._succ_host.shape):
+                raise RuntimeError(f"success exchange returned {tuple(msgs.shape)}, expected {tuple(self._succ_host.shape)}: "
+                                   "is torch.distributed initialised for world_size > 1?")
+            self._succ_host.copy_(msgs, non_blocking=True)
             self._succ_ev.record()
         elif not self._succ_exchanged:         # collect() without an update() in between
             self._exchange_successes()
