@@ -26,6 +26,8 @@ class Context:
         check(lib().uav_create(C.byref(h), int(device_index), WS_BYTES), "uav_create")
         self.handle = h
         self.device = device_index
+        # the mode uav_create started the handle in (UAV_LSTM_F32_MFMA / UAV_LSTM_BF16X6 in the environment, read there once)
+        self.initial_arith = {0: "fp16x3", 1: "bf16x6", 2: "f32_mfma"}[int(lib().uav_get_lstm_arith(h))]
 
     @classmethod
     def get(cls, device=None):

@@ -93,7 +93,7 @@ class VecPPOTrainer:
         # force_arith: "fp16x3" | "bf16x6" | "f32_mfma" pins the LSTM kernels' arithmetic (A/B runs, reference gradients);
         # None = the range guard decides.  A handle that uav_create started in another mode (UAV_LSTM_F32_MFMA=1 /
         # UAV_LSTM_BF16X6=1 in the environment: a whole-process A/B) keeps it.
-        init_mode = ops.get_lstm_arith(self.device)
+        init_mode = ops.Context.get(self.device).initial_arith
         self.force_arith = None if init_mode == "fp16x3" else init_mode
         self._flat_version = -1
         # environments of this rank: global indices [rank*N, (rank+1)*N)
