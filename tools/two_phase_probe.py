@@ -10,6 +10,11 @@ events.  Variants (argv[1], comma separated) remove one suspect at a time:
     gc          gc.collect() + synchronize + barrier between the phases
     fresh       phase B only (what a fresh rank set runs)
     threads1    torch.set_num_threads(1) in every rank
+    keepA       trainer A stays alive (no del, no empty_cache)
+    noempty     del, but no torch.cuda.empty_cache()
+    samestream  trainer B takes over trainer A's side stream instead of drawing a new one from torch's pool
+    mainstream  trainer B packs / copies the success bits on the main stream (side_stream_curriculum = False)
+    sameshape   phase A with 2048 envs as well
 
     python tools/two_phase_probe.py base,gc,fresh        # launcher: spawns 2 ranks per variant
 """
@@ -34,9 +39,16 @@ def rank_main(variant):
     from uavppo import ops
     from uavppo.trainer import VecPPOTrainer
 
+    keep = {}
+
     def phase(tag, n_env, steps, warm, timers):
         tr = VecPPOTrainer(n_env, 128, "lstm", hidden=128, device=dev, seed=1234, rank=rank, world_size=world,
                            use_curriculum=(variant != "nocurr"))
+        if tag[0] == "B" and variant == "samestream":
+            tr._side = keep["side"]
+        if tag[0] == "B" and variant == "mainstream":
+            tr.side_stream_curriculum = False
+        keep["side"] = tr._side
         for _ in range(warm):
             tr.train_iteration()
         if timers:
@@ -71,9 +83,12 @@ def rank_main(variant):
         return tr
 
     if variant != "fresh":
-        tr = phase("A 4096 envs", 4096, 10, 3, variant != "notimer")
+        tr = phase("A 4096 envs", 2048 if variant == "sameshape" else 4096, 10, 3, variant != "notimer")
+        if variant == "keepA":
+            keep["A"] = tr
         del tr
-        torch.cuda.empty_cache()
+        if variant not in ("keepA", "noempty"):
+            torch.cuda.empty_cache()
         if variant == "gc":
             gc.collect()
             torch.cuda.synchronize()

@@ -27,6 +27,24 @@ DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, ent_beta=0.01, lr=3e-5, epochs=5
 RANGE_LIMITS = (0.5 * 65504.0, 0.5 * 4096.0, 0.5 * 64.0)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """ONE side stream per device and process, shared by every trainer built in it.  A trainer used to draw its own
+    stream from torch's pool; a SECOND trainer in a process (bench.py's old weak -> strong sequence) then ran its success
+    exchange on a second pool stream, and with two rank processes sharing one GPU over gloo every iteration of that second
+    trainer stalled for 50-900 ms in update() (tools/two_phase_probe.py: `base` 58-245 ms per C3 iteration against 9.6 ms
+    in fresh processes; `samestream` -- the second trainer reusing the first one's stream -- 10.7 ms; `nocurr` and
+    `mainstream`, which never touch a side stream, 9.0 / 9.8 ms; dropping the first trainer, gc, empty_cache, kernel
+    timers and the torch thread count made no difference).  Streams are a per-process resource: keep exactly one."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class VecPPOTrainer:
     def __init__(self, num_envs, horizon, policy="lstm", hidden=128, layers=1, variant="v2.0", device="cuda",
                  seed=1234, gae_mode="reference_exact", num_minibatches=1, bank=None, bank_sources=None,
@@ -106,7 +124,7 @@ class VecPPOTrainer:
         # the curriculum's success bits leave on a side stream right behind the rollout and land in pinned host memory
         # while the update runs: the iteration's one host sync (update_curriculum) then waits for a copy that finished
         # milliseconds ago instead of draining the main stream
-        self._side = torch.cuda.Stream(device=self.device) if use_curriculum else None
+        self._side = _side_stream(self.device) if use_curriculum else None
         self._succ_host = (torch.zeros(self.world, 4 + SUCC_CAP + 1, dtype=torch.uint8).pin_memory() if use_curriculum else None)
         self._succ_ev = torch.cuda.Event()
         self._pack_ev = torch.cuda.Event()
