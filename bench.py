@@ -71,6 +71,11 @@ def spawn_ranks(n, cmd, extra_env=None, timeout=None, capture_rank0=False):
     env = dict(os.environ)
     env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    if "--backend" in cmd and cmd[cmd.index("--backend") + 1] == "gloo":
+        # gloo = the rehearsal of several ranks SHARING one GPU: each process then gets two hardware queues instead of
+        # HIP's default four.  With the default, two C5 ranks oversubscribed the GPU's queue slots and every dependent
+        # launch waited a scheduling quantum (49.8 s per iteration against 0.46 s: DESIGN.md 6, gpurun_out/b2_c5_*).
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
     env.update(WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_WORLD_SIZE=str(n))
     procs = []
     out0 = tempfile.TemporaryFile() if capture_rank0 else None

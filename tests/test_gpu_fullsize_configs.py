@@ -39,7 +39,7 @@ def test_c2_whole_iteration_matches_oracle():
     ora = pr.ProceduralVecEnv(N, seed, "v2.0", radius=120.0)
     obs0 = ora.reset()
     p = cpu_params(tr.policy)
-    adam = po.AdamState(p)
+    adam = po.AdamState(p, lr=3e-4)
     h0, c0 = tr.h.cpu().clone(), tr.c.cpu().clone()
     tr.collect()
     b = {k: v.cpu().numpy() for k, v in tr.buf.items()}
