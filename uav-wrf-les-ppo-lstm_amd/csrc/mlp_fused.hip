@@ -459,7 +459,8 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob b
 //   ACC1 [3][16][256] (dg1, dbe1, db1)   ACC2 [3][16][128] (dg2, dbe2, db2)   DH [MS][8] dheads
 constexpr int UNC = 2;                  // column tiles per workgroup step: 32 samples
 constexpr int UMS = MT * UNC;
-constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 3 * MT * H1 + 3 * MT * H2 + UMS * 8;
+constexpr int LS_STRIDE = 10;             // doubles per loss lane: policy / value / entropy / NaN sums + 6 head-bias sums
+constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 3 * MT * H1 + 3 * MT * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2;
 constexpr size_t UPD_LDS = (size_t)UPD_FLOATS * sizeof(float);
 constexpr int SLAB = NPARAM;            // one gradient slab per workgroup, flat parameter layout
 
@@ -474,6 +475,13 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     float* ACC1 = smem + Tiles<NC>::FLOATS;
     float* ACC2 = ACC1 + 3 * MT * H1;
     float* DH = ACC2 + 3 * MT * H2;
+    // the loss lanes' running sums live in LDS, not in registers: only wave 0 touches them, once per tile, but as registers
+    // they were live in EVERY wave across the whole tile loop (14 VGPRs of a kernel that spills)
+    double* LS = reinterpret_cast<double*>(DH + MS * 8);
+    // W1 [256][8] (columns 6, 7 zero) and the head weights [8][128] (rows 6, 7 zero): their per-lane MFMA fragments are
+    // re-read from here where they are used instead of living in 10 VGPRs across the whole tile loop
+    float* W1L = reinterpret_cast<float*>(LS + MS * LS_STRIDE);
+    float* WHL = W1L + H1 * 8;
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -491,18 +499,8 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         L.prm[3 * H1 + 2 * H2 + i] = params[O_BE2 + i];
     }
     for (int i = threadIdx.x; i < 3 * MT * H1 + 3 * MT * H2; i += 512) ACC1[i] = 0.f;
-    float w1a[2][2], wh[4], whT[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int k = 4 * s + kq;
-            w1a[t][s] = k < IN ? params[O_W1 + (32 * w + 16 * t + j) * IN + k] : 0.f;
-        }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) wh[s] = j < NH ? params[O_WH + j * H2 + 16 * w + 4 * s + kq] : 0.f;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) whT[s] = (4 * s + kq) < NH ? params[O_WH + (4 * s + kq) * H2 + 16 * w + j] : 0.f;
+    for (int i = threadIdx.x; i < H1 * 8; i += 512) W1L[i] = (i & 7) < IN ? params[O_W1 + (i >> 3) * IN + (i & 7)] : 0.f;
+    for (int i = threadIdx.x; i < 8 * H2; i += 512) WHL[i] = (i / H2) < NH ? params[O_WH + i] : 0.f;
     // W2 is NOT held in registers: the 64 + 64 VGPRs of its two orientations beside the 64 of the dW2 accumulators spill
     // (measured: 85 VGPRs to scratch).  Both orientations are streamed from L2 instead -- 256 KB per 32 samples and CU,
     // dwordx4 per lane thanks to the permuted k order -- W2 row-major for the forward, its transpose (w2t, made once per
@@ -516,10 +514,7 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) dW2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     dW1[0] = dW1[1] = dWh = f32x4{0.f, 0.f, 0.f, 0.f};
-    LossAcc lacc{0.0, 0.0, 0.0, 0.0};
-    float s_db[NH];
-#pragma unroll
-    for (int k = 0; k < NH; ++k) s_db[k] = 0.f;
+    for (int i = threadIdx.x; i < MS * LS_STRIDE; i += 512) LS[i] = 0.0;
 
     const int64_t ntile = (Bn + MS - 1) / MS;
     M_PROF_DECL;
@@ -541,13 +536,25 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         // ---- forward
         f32x4 xh1[NC][2], xh2[NC];
         float r1[NC], r2[NC];
-        layer1<NC>(L, w1a, w, j, kq, xh1, r1);
+        {
+            float w1a[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) w1a[t][s] = W1L[(32 * w + 16 * t + j) * 8 + 4 * s + kq];
+            layer1<NC>(L, w1a, w, j, kq, xh1, r1);
+        }
         lds_barrier();
         M_PROF_MARK(1);
         layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
         lds_barrier();
         M_PROF_MARK(2);
-        heads_fwd<NC>(L, wh, bh, w, lane);
+        {
+            float wh[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wh[s] = j < 8 ? WHL[j * H2 + 16 * w + 4 * s + kq] : 0.f;
+            heads_fwd<NC>(L, wh, bh, w, lane);
+        }
         M_PROF_MARK(3);
         // ---- loss + d(total)/d(heads) for the tile's samples (lanes 0..MS-1 of wave 0)
         if (w == 0) {
@@ -561,10 +568,14 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                     float z[NA];
 #pragma unroll
                     for (int a = 0; a < NA; ++a) z[a] = L.HD[lane * 8 + a];
+                    double* ls = LS + lane * LS_STRIDE;
+                    LossAcc lacc{ls[0], ls[1], ls[2], ls[3]};
                     dV = ppo_sample<NA>(z, L.HD[lane * 8 + NA], a_s, lpo, Ad, Rt, vo, inv_n, clip, beta, lacc, dz);
+                    ls[0] = lacc.pl; ls[1] = lacc.vl; ls[2] = lacc.en; ls[3] = lacc.nan;
+                    // head-bias gradient sums: f32 running sums as before (kept as f32 VALUES in the f64 slots)
 #pragma unroll
-                    for (int a = 0; a < NA; ++a) s_db[a] += dz[a];
-                    s_db[NA] += dV;
+                    for (int a = 0; a < NA; ++a) ls[4 + a] = (double)((float)ls[4 + a] + dz[a]);
+                    ls[4 + NA] = (double)((float)ls[4 + NA] + dV);
                 }
 #pragma unroll
                 for (int a = 0; a < NA; ++a) DH[lane * 8 + a] = dz[a];
@@ -590,6 +601,7 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
             double p1[NC], p2[NC];
             f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = sg, sz = sg;
             float* a2p = ACC2 + j * H2 + u;
+            const float whT[2] = {WHL[kq * H2 + 16 * w + j], WHL[(4 + kq) * H2 + 16 * w + j]};
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 f32x4 da2 = {0.f, 0.f, 0.f, 0.f};
@@ -760,19 +772,13 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     }
     if (w == 0) {
         // loss sums and the head-bias gradient: the loss lanes park their partial sums, lane 0 adds them in lane order
-        if (lane < MS) {
-            double* pr = L.red + lane * 10;
-            pr[0] = lacc.pl; pr[1] = lacc.vl; pr[2] = lacc.en; pr[3] = lacc.nan;
-#pragma unroll
-            for (int k = 0; k < NH; ++k) pr[4 + k] = (double)s_db[k];
-        }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             double* pp = loss_partial + (size_t)LOSS_PSTRIDE * blockIdx.x;
             for (int k = 0; k < 4 + NH; ++k) {
                 double t = 0.0;
-                for (int sj = 0; sj < MS; ++sj) t += L.red[sj * 10 + k];
+                for (int sj = 0; sj < MS; ++sj) t += LS[sj * LS_STRIDE + k];
                 pp[k] = t;
                 if (k >= 4) slab[O_BH + k - 4] = (float)t;
             }
