@@ -87,6 +87,17 @@ __device__ __forceinline__ f32x4 ld4(const float* p) {
 __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cast<float4*>(p) = float4{v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// sum over the 16 lanes of a row (the 16 samples lane & 15 = 0..15 that share lane >> 4): four DPP adds -- xor 1, xor 2,
+// half-row mirror, row mirror -- every lane ends with the same total (a + b == b + a bitwise at every stage)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ f32x4 row16_sum(f32x4 v) { return f32x4{row16_sum(v[0]), row16_sum(v[1]), row16_sum(v[2]), row16_sum(v[3])}; }
+
 // sum over the four lanes that hold the same sample (lane & 15) of a wave
 __device__ __forceinline__ double quad_sum(double v) {
     v += __shfl_xor(v, 16, 64);
@@ -455,12 +466,14 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob b
 }
 
 // ==================================================================================================== update
-// LDS of the update kernel: the tiles + the per-(sample lane, unit) accumulators of the LayerNorm / bias gradients
-//   ACC1 [3][16][256] (dg1, dbe1, db1)   ACC2 [3][16][128] (dg2, dbe2, db2)   DH [MS][8] dheads
+// LDS of the update kernel: the tiles + the per-unit accumulators of the LayerNorm / bias gradients
+//   ACC1 [2][256] (dg1, dbe1)   ACC2 [3][128] (dg2, dbe2, db2)   DH [MS][8] dheads
+// (each tile's contribution is summed over its 16 sample lanes by row16_sum first; db1 rides on the dW1 product as a
+//  ones column of X.  Round 2 kept one slot per (sample lane, unit): 74 KB of LDS and 18 LDS read-modify-writes per tile.)
 constexpr int UNC = 2;                  // column tiles per workgroup step: 32 samples
 constexpr int UMS = MT * UNC;
 constexpr int LS_STRIDE = 10;             // doubles per loss lane: policy / value / entropy / NaN sums + 6 head-bias sums
-constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 3 * MT * H1 + 3 * MT * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2;
+constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 2 * H1 + 3 * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2 + UMS * AS1 + UMS * AS2;
 constexpr size_t UPD_LDS = (size_t)UPD_FLOATS * sizeof(float);
 constexpr int SLAB = NPARAM;            // one gradient slab per workgroup, flat parameter layout
 
@@ -473,8 +486,8 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Tiles<NC> L(smem);
     float* ACC1 = smem + Tiles<NC>::FLOATS;
-    float* ACC2 = ACC1 + 3 * MT * H1;
-    float* DH = ACC2 + 3 * MT * H2;
+    float* ACC2 = ACC1 + 2 * H1;
+    float* DH = ACC2 + 3 * H2;
     // the loss lanes' running sums live in LDS, not in registers: only wave 0 touches them, once per tile, but as registers
     // they were live in EVERY wave across the whole tile loop (14 VGPRs of a kernel that spills)
     double* LS = reinterpret_cast<double*>(DH + MS * 8);
@@ -482,6 +495,9 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     // re-read from here where they are used instead of living in 10 VGPRs across the whole tile loop
     float* W1L = reinterpret_cast<float*>(LS + MS * LS_STRIDE);
     float* WHL = W1L + H1 * 8;
+    // xhat of both LayerNorms, parked between the forward and the backward of a tile (24 VGPRs of a kernel that spilled)
+    float* XH1 = WHL + 8 * H2;
+    float* XH2 = XH1 + MS * AS1;
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -498,7 +514,7 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         L.prm[3 * H1 + H2 + i] = params[O_G2 + i];
         L.prm[3 * H1 + 2 * H2 + i] = params[O_BE2 + i];
     }
-    for (int i = threadIdx.x; i < 3 * MT * H1 + 3 * MT * H2; i += 512) ACC1[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * H1 + 3 * H2; i += 512) ACC1[i] = 0.f;
     for (int i = threadIdx.x; i < H1 * 8; i += 512) W1L[i] = (i & 7) < IN ? params[O_W1 + (i >> 3) * IN + (i & 7)] : 0.f;
     for (int i = threadIdx.x; i < 8 * H2; i += 512) WHL[i] = (i / H2) < NH ? params[O_WH + i] : 0.f;
     // W2 is NOT held in registers: the 64 + 64 VGPRs of its two orientations beside the 64 of the dW2 accumulators spill
@@ -523,7 +539,9 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         // ---- stage the tile's observations; the loss lanes fetch their per-sample scalars early
         if (threadIdx.x < MS * 8) {
             const int sj = threadIdx.x >> 3, f = threadIdx.x & 7;
-            L.X[threadIdx.x] = (f < IN && s0 + sj < Bn) ? obs[(s0 + sj) * IN + f] : 0.f;
+            // column 6 = 1: W1 has no column 6 (the forward multiplies it by zero), and dW1 = dz1^T X then carries
+            // db1 = dz1^T 1 in its seventh column for free
+            L.X[threadIdx.x] = (s0 + sj < Bn) ? (f < IN ? obs[(s0 + sj) * IN + f] : (f == IN ? 1.f : 0.f)) : 0.f;
         }
         int a_s = 0;
         float lpo = 0.f, Ad = 0.f, Rt = 0.f, vo = 0.f;
@@ -534,19 +552,28 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         lds_barrier();
         M_PROF_MARK(0);
         // ---- forward
-        f32x4 xh1[NC][2], xh2[NC];
         float r1[NC], r2[NC];
         {
+            f32x4 xh1[NC][2];
             float w1a[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) w1a[t][s] = W1L[(32 * w + 16 * t + j) * 8 + 4 * s + kq];
             layer1<NC>(L, w1a, w, j, kq, xh1, r1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) st4(XH1 + (16 * c + j) * AS1 + 32 * w + 16 * t + 4 * kq, xh1[c][t]);
         }
         lds_barrier();
         M_PROF_MARK(1);
-        layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
+        {
+            f32x4 xh2[NC];
+            layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) st4(XH2 + (16 * c + j) * AS2 + 16 * w + 4 * kq, xh2[c]);
+        }
         lds_barrier();
         M_PROF_MARK(2);
         {
@@ -598,29 +625,40 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
             const int u = 16 * w + 4 * kq;
             const f32x4 g = ld4(L.prm + 3 * H1 + H2 + u), be = ld4(L.prm + 3 * H1 + 2 * H2 + u);
             f32x4 dxh[NC];
+            // per-lane partial sums in f32 (4 terms, fixed order), widened to f64 only for the cross-lane / cross-wave sum:
+            // the reference's own LayerNorm backward accumulates in f32; 48 f64 conversions and FMAs per tile and lane
+            // here and in LayerNorm 1 were a quarter of these phases' issue time
             double p1[NC], p2[NC];
             f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = sg, sz = sg;
-            float* a2p = ACC2 + j * H2 + u;
+            float* a2p = ACC2 + u;
             const float whT[2] = {WHL[kq * H2 + 16 * w + j], WHL[(4 + kq) * H2 + 16 * w + j]};
+            f32x4 xh2[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xh2[c] = ld4(XH2 + (16 * c + j) * AS2 + u);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 f32x4 da2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) da2 = mfma4(whT[s], DH[(16 * c + j) * 8 + 4 * s + kq], da2);
-                p1[c] = 0.0;
-                p2[c] = 0.0;
+                float q1 = 0.f, q2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float dy = (xh2[c][r] * g[r] + be[r] > 0.f) ? da2[r] : 0.f;
                     sg[r] += dy * xh2[c][r];
                     sb[r] += dy;
                     dxh[c][r] = dy * g[r];
-                    p1[c] += (double)dxh[c][r];
-                    p2[c] += (double)dxh[c][r] * (double)xh2[c][r];
+                    q1 += dxh[c][r];
+                    q2 += dxh[c][r] * xh2[c][r];
                 }
+                p1[c] = (double)q1;
+                p2[c] = (double)q2;
             }
-            st4(a2p, ld4(a2p) + sg);                         // dg2, dbe2: this lane's own (sample lane, unit) slots
-            st4(a2p + MT * H2, ld4(a2p + MT * H2) + sb);
+            sg = row16_sum(sg);                              // dg2, dbe2: summed over the tile's 16 sample lanes, then ONE lane per
+            sb = row16_sum(sb);                              // kq group adds them to the per-unit accumulators
+            if (j == 0) {
+                st4(a2p, ld4(a2p) + sg);
+                st4(a2p + H2, ld4(a2p + H2) + sb);
+            }
             double S1[NC], S2[NC];
             ln_exchange<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dWh reads of A2 are done
 #pragma unroll
@@ -631,7 +669,8 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                 st4(L.A2 + (16 * c + j) * AS2 + u, dz2[c]);  // dz2 replaces a2
                 sz = sz + dz2[c];
             }
-            st4(a2p + 2 * MT * H2, ld4(a2p + 2 * MT * H2) + sz);
+            sz = row16_sum(sz);
+            if (j == 0) st4(a2p + 2 * H2, ld4(a2p + 2 * H2) + sz);
         }
         lds_barrier();                                       // dz2 visible
         M_PROF_MARK(5);
@@ -685,9 +724,15 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         // ---- LayerNorm 1 + ReLU backward
         {
             f32x4 dxh[NC][2];                                // da1 becomes dxhat in place
-            double p1[NC], p2[NC];
+            f32x4 xh1[NC][2];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) p1[c] = p2[c] = 0.0;
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xh1[c][t] = ld4(XH1 + (16 * c + j) * AS1 + 32 * w + 16 * t + 4 * kq);
+            double p1[NC], p2[NC];
+            float q1[NC], q2[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) q1[c] = q2[c] = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int u = 32 * w + 16 * t + 4 * kq;
@@ -701,30 +746,32 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                         sg[r] += dy * xh1[c][t][r];
                         sb[r] += dy;
                         dxh[c][t][r] = dy * g[r];
-                        p1[c] += (double)dxh[c][t][r];
-                        p2[c] += (double)dxh[c][t][r] * (double)xh1[c][t][r];
+                        q1[c] += dxh[c][t][r];
+                        q2[c] += dxh[c][t][r] * xh1[c][t][r];
                     }
-                float* a1p = ACC1 + j * H1 + u;              // dg1, dbe1: this lane's own (sample lane, unit) slots
-                st4(a1p, ld4(a1p) + sg);
-                st4(a1p + MT * H1, ld4(a1p + MT * H1) + sb);
+                sg = row16_sum(sg);
+                sb = row16_sum(sb);
+                if (j == 0) {
+                    float* a1p = ACC1 + u;                   // dg1, dbe1
+                    st4(a1p, ld4(a1p) + sg);
+                    st4(a1p + H1, ld4(a1p + H1) + sb);
+                }
             }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { p1[c] = (double)q1[c]; p2[c] = (double)q2[c]; }
             double S1[NC], S2[NC];
             ln_exchange<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dW2 reads of A1 are done
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int u = 32 * w + 16 * t + 4 * kq;
-                f32x4 sz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     const float m1 = (float)(S1[c] * (1.0 / H1)), m2 = (float)(S2[c] * (1.0 / H1));
                     f32x4 dz1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dz1[r] = r1[c] * (dxh[c][t][r] - m1 - xh1[c][t][r] * m2);
-                    st4(L.A1 + (16 * c + j) * AS1 + u, dz1);  // dz1 replaces a1
-                    sz = sz + dz1;
+                    st4(L.A1 + (16 * c + j) * AS1 + u, dz1);  // dz1 replaces a1 (db1 = its column sums: the dW1 product below)
                 }
-                float* a1p = ACC1 + j * H1 + u + 2 * MT * H1;
-                st4(a1p, ld4(a1p) + sz);
             }
         }
         lds_barrier();                                       // dz1 visible
@@ -747,7 +794,10 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
+        {
             if (j < IN) slab[O_W1 + (32 * w + 16 * t + 4 * kq + r) * IN + j] = dW1[t][r];
+            else if (j == IN) slab[O_B1 + 32 * w + 16 * t + 4 * kq + r] = dW1[t][r];       // the ones column: db1
+        }
 #pragma unroll
     for (int tj = 0; tj < 16; ++tj)
 #pragma unroll
@@ -755,20 +805,12 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (4 * kq + r < NH) slab[O_WH + (4 * kq + r) * H2 + 16 * w + j] = dWh[r];
-    // per-unit sums over the 16 sample lanes, fixed order
-    for (int i = threadIdx.x; i < 3 * H1; i += 512) {
-        const int q = i / H1, u = i % H1;
-        float s = 0.f;
-#pragma unroll
-        for (int sj = 0; sj < MT; ++sj) s += ACC1[(q * MT + sj) * H1 + u];
-        slab[(q == 0 ? O_G1 : (q == 1 ? O_BE1 : O_B1)) + u] = s;
-    }
+    // LayerNorm / bias gradients from the per-unit accumulators
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * H1; i += 512) slab[(i < H1 ? O_G1 : O_BE1) + (i % H1)] = ACC1[i];
     for (int i = threadIdx.x; i < 3 * H2; i += 512) {
         const int q = i / H2, u = i % H2;
-        float s = 0.f;
-#pragma unroll
-        for (int sj = 0; sj < MT; ++sj) s += ACC2[(q * MT + sj) * H2 + u];
-        slab[(q == 0 ? O_G2 : (q == 1 ? O_BE2 : O_B2)) + u] = s;
+        slab[(q == 0 ? O_G2 : (q == 1 ? O_BE2 : O_B2)) + u] = ACC2[i];
     }
     if (w == 0) {
         // loss sums and the head-bias gradient: the loss lanes park their partial sums, lane 0 adds them in lane order
