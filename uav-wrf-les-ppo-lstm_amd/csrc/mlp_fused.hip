@@ -45,6 +45,8 @@ constexpr int IN = 6, H1 = 256, H2 = 128, NA = 5, NH = 6;
 constexpr int NWAVE = 8;
 constexpr int AS1 = 260, AS2 = 132;     // row strides (floats) of the a1 / a2 tiles: float4-aligned rows
 constexpr int WS2 = 260;                // row stride of the rollout's LDS image of wave 0's W2 rows (float4-aligned)
+constexpr int RS1 = H1 + 8;             // row stride (halves) of the a1 piece planes: conflict-free ds_read_b128
+constexpr int RS2 = H2 + 8;             // row stride (halves) of the dz2 piece planes
 constexpr float LN_EPS_F = 1e-5f;
 constexpr float R_EPS = 1.1920928955078125e-07f;
 
@@ -68,7 +70,8 @@ struct Tiles {
     double* red;     // [2][8 waves][MS] per-wave partial sums of the LayerNorm reductions
     f32x4* HP;       // [8 waves][NC][32] partial head tiles (K split over the waves; rows 0..7 = lanes with kq < 2)
     float* HD;       // [MS][8]   heads: logits | value
-    static constexpr int FLOATS = 3 * H1 + 3 * H2 + MS * 8 + MS * AS1 + MS * AS2 + 2 * (2 * NWAVE * MS) + NWAVE * NC * 32 * 4 + MS * 8;
+    unsigned short* P1;   // [2 pieces][MS][RS1] a1 as two fp16 planes (the B operand of the split layer-2 product)
+    static constexpr int FLOATS = 3 * H1 + 3 * H2 + MS * 8 + MS * AS1 + MS * AS2 + 2 * (2 * NWAVE * MS) + NWAVE * NC * 32 * 4 + MS * 8 + MS * RS1;
     __device__ __forceinline__ explicit Tiles(float* base) {
         prm = base;
         X = prm + 3 * H1 + 3 * H2;
@@ -77,6 +80,7 @@ struct Tiles {
         red = reinterpret_cast<double*>(A2 + MS * AS2);
         HP = reinterpret_cast<f32x4*>(red + 2 * NWAVE * MS);
         HD = reinterpret_cast<float*>(HP + NWAVE * NC * 32);
+        P1 = reinterpret_cast<unsigned short*>(HD + MS * 8);
     }
 };
 
@@ -136,7 +140,8 @@ __device__ __forceinline__ void ln_exchange(const Tiles<NC>& L, int w, int j, in
 // z1 -> LN1 -> a1 (to LDS).  Lane (j = lane & 15, kq = lane >> 4) of wave w holds units 32 w + 16 t + 4 kq + r, t < 2,
 // r < 4 of samples 16 c + j.  Leaves xhat1 / rstd1 for the backward.  One barrier inside (ln_exchange); the caller's
 // barrier after it publishes A1.
-template <int NC>
+// MODE: 0 = a1 as f32 rows (A1), 1 = a1 as two fp16 piece planes (P1), 2 = both.
+template <int NC, int MODE = 0>
 __device__ __forceinline__ void layer1(const Tiles<NC>& L, const float (&w1a)[2][2], int w, int j, int kq, f32x4 (&xh)[NC][2],
                                        float (&rstd)[NC]) {
     f32x4 z[NC][2];
@@ -180,7 +185,23 @@ __device__ __forceinline__ void layer1(const Tiles<NC>& L, const float (&w1a)[2]
                 const float pre = xh[c][t][r] * g[r] + be[r];
                 a[r] = pre < 0.f ? 0.f : pre;                // NaN propagates like torch.relu
             }
-            st4(L.A1 + (16 * c + j) * AS1 + u, a);
+            if (MODE != 1) st4(L.A1 + (16 * c + j) * AS1 + u, a);
+            if (MODE != 0) {
+                unsigned short b[2][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 p0, p1;
+                    split2h(a[r], p0, p1);
+                    b[0][r] = h_bits(p0); b[1][r] = h_bits(p1);
+                }
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    uint2 v;
+                    v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+                    v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+                    *reinterpret_cast<uint2*>(L.P1 + (pc * (MT * NC) + 16 * c + j) * RS1 + u) = v;
+                }
+            }
         }
     }
 }
@@ -252,6 +273,79 @@ __device__ __forceinline__ void layer2(const Tiles<NC>& L, WA&& wa4, int w, int 
     }
 }
 
+// The same layer on the fp16 matrix pipe at f32 accuracy (common.h split2h: two fp16 pieces per operand, three products per
+// K = 32 slab into a main and a cross accumulator): 8 slabs x 3 x 16 cycles instead of 64 k-steps x 32.  wa8(s, piece) =
+// the A fragment W2[16 w + (lane & 15)][32 s + 8 kq .. + 7] as fp16 piece `piece`; B fragments from the a1 piece planes.
+// Operand ranges: |W2| < 65504 and a1 <= sqrt(255) |g1| + |be1| < 65504, i.e. max |param| < 2048 (the caller's guard).
+template <int NC, class WA>
+__device__ __forceinline__ void layer2_h3(const Tiles<NC>& L, WA&& wa8, int w, int j, int kq, f32x4 (&xh)[NC], float (&rstd)[NC]) {
+    constexpr int MS = MT * NC;
+    const int u = 16 * w + 4 * kq;
+    f32x4 acc[NC], acl[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        acc[c] = ld4(L.prm + 3 * H1 + u);                    // b2
+        acl[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned short* brow = L.P1 + j * RS1 + 8 * kq;
+    // two slabs of weight fragments in flight ahead of the MFMAs that use them (L2 latency in the update kernel)
+    f16x8 wq[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { wq[0][i][0] = wa8(i, 0); wq[0][i][1] = wa8(i, 1); }
+#pragma unroll
+    for (int ch = 0; ch < H1 / 64; ++ch) {
+        if (ch + 1 < H1 / 64) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { wq[(ch + 1) & 1][i][0] = wa8(2 * (ch + 1) + i, 0); wq[(ch + 1) & 1][i][1] = wa8(2 * (ch + 1) + i, 1); }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = 2 * ch + i;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(brow + (16 * c) * RS1 + 32 * s);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(brow + (MS + 16 * c) * RS1 + 32 * s);
+                acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ch & 1][i][1], b0, acl[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ch & 1][i][0], b0, acc[c], 0, 0, 0);
+                acl[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[ch & 1][i][0], b1, acl[c], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = acc[c] + acl[c] * H3_LO;
+    double s1[NC], q1[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        s1[c] = 0.0;
+        q1[c] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1[c] += (double)acc[c][r];
+            q1[c] += (double)acc[c][r] * (double)acc[c][r];
+        }
+    }
+    double S[NC], Q[NC];
+    ln_exchange<NC>(L, w, j, kq, s1, q1, S, Q);
+    const f32x4 g = ld4(L.prm + 3 * H1 + H2 + u), be = ld4(L.prm + 3 * H1 + 2 * H2 + u);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double mean = S[c] * (1.0 / H2);
+        double var = Q[c] * (1.0 / H2) - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float mf = (float)mean;
+        rstd[c] = 1.0f / sqrtf((float)var + LN_EPS_F);
+        f32x4 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xh[c][r] = (acc[c][r] - mf) * rstd[c];
+            const float pre = xh[c][r] * g[r] + be[r];
+            a[r] = pre < 0.f ? 0.f : pre;
+        }
+        st4(L.A2 + (16 * c + j) * AS2 + u, a);
+    }
+}
+
 // heads = Wh a2 + bh with K = 128 split over the 8 waves (16 each); wave 0 adds the partial tiles in a fixed order and
 // leaves heads[sample][0..5] in HD.  wh[s] = Wh[lane & 15][16 w + 4 s + kq] (0 for rows >= 6).  Barrier inside.
 template <int NC>
@@ -289,6 +383,9 @@ struct MlpRollBufs {
 
 constexpr size_t ROLL_LDS = (size_t)(Tiles<1>::FLOATS + 16 * WS2) * sizeof(float);
 
+// H3: the 256 x 128 layer on the fp16 matrix pipe (layer2_h3) -- the update kernel of the same arithmetic runs the same
+// code, so the rollout's log-probabilities stay bit-identical to the update's first forward pass.
+template <bool H3>
 __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob blob, int N, int T, uint64_t iter,
                                                             const float* __restrict__ params, MlpRollBufs B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -316,7 +413,19 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob b
         L.prm[3 * H1 + H2 + i] = params[O_G2 + i];
         L.prm[3 * H1 + 2 * H2 + i] = params[O_BE2 + i];
     }
-    for (int i = threadIdx.x; i < 16 * H1; i += 512) W2i[(i >> 8) * WS2 + (i & 255)] = params[O_W2 + i];
+    unsigned short* W2p = reinterpret_cast<unsigned short*>(W2i);   // H3: rows 0..15 as piece fragments [8 slabs][2][64 lanes][8]
+    if (H3) {
+        for (int i = threadIdx.x; i < 16 * H1; i += 512) {
+            const int row = i >> 8, k = i & 255, sl = k >> 5, q8 = (k >> 3) & 3, e = k & 7;
+            _Float16 p0, p1;
+            split2h(params[O_W2 + i], p0, p1);
+            unsigned short* d = W2p + ((sl * 2) * 64 + q8 * 16 + row) * 8 + e;
+            d[0] = h_bits(p0);
+            d[64 * 8] = h_bits(p1);
+        }
+    } else {
+        for (int i = threadIdx.x; i < 16 * H1; i += 512) W2i[(i >> 8) * WS2 + (i & 255)] = params[O_W2 + i];
+    }
     float w1a[2][2], wh[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -342,15 +451,32 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob b
     const int steps = T + (B.last_val ? 1 : 0);              // one extra value-only pass for V(s_T)
     if (w != 0) {
         // ------------------------------------------------------------------ waves 1..7: their rows of W2 in registers
-        f32x4 wA[H1 / 16];
+        f32x4 wA[H3 ? 1 : H1 / 16];
+        f16x8 wP[H3 ? H1 / 32 : 1][2];
+        if (H3) {
 #pragma unroll
-        for (int s = 0; s < H1 / 16; ++s) wA[s] = ld4(params + O_W2 + (16 * w + j) * H1 + 16 * s + 4 * kq);
+            for (int sl = 0; sl < H1 / 32; ++sl) {
+                const float* src = params + O_W2 + (16 * w + j) * H1 + 32 * sl + 8 * kq;
+                const f32x4 v0 = ld4(src), v1 = ld4(src + 4);
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 p0, p1;
+                    split2h(v[e], p0, p1);
+                    wP[sl][0][e] = p0; wP[sl][1][e] = p1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < H1 / 16; ++s) wA[s] = ld4(params + O_W2 + (16 * w + j) * H1 + 16 * s + 4 * kq);
+        }
         for (int t = 0; t < steps; ++t) {
             f32x4 xh1[1][2], xh2[1];
             float r1[1], r2[1];
-            layer1<1>(L, w1a, w, j, kq, xh1, r1);
+            layer1<1, H3 ? 1 : 0>(L, w1a, w, j, kq, xh1, r1);
             lds_barrier();                                   // a1 visible
-            layer2<1>(L, [&](int s) { return wA[s]; }, w, j, kq, xh2, r2);
+            if constexpr (H3) layer2_h3<1>(L, [&](int sl, int pc) { return wP[sl][pc]; }, w, j, kq, xh2, r2);
+            else layer2<1>(L, [&](int s) { return wA[s]; }, w, j, kq, xh2, r2);
             lds_barrier();                                   // a2 visible
             heads_fwd<1>(L, wh, bh, w, lane);
             lds_barrier();                                   // wave 0 has stepped the environments: next observations visible
@@ -361,9 +487,11 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob b
             const bool value_only = (t == T);
             f32x4 xh1[1][2], xh2[1];
             float r1[1], r2[1];
-            layer1<1>(L, w1a, w, j, kq, xh1, r1);
+            layer1<1, H3 ? 1 : 0>(L, w1a, w, j, kq, xh1, r1);
             lds_barrier();                                       // a1 visible
-            layer2<1>(L, [&](int s) { return ld4(w2row + 16 * s); }, w, j, kq, xh2, r2);
+            if constexpr (H3) layer2_h3<1>(L, [&](int sl, int pc) { return *reinterpret_cast<const f16x8*>(W2p + ((sl * 2 + pc) * 64 + lane) * 8); },
+                                           w, j, kq, xh2, r2);
+            else layer2<1>(L, [&](int s) { return ld4(w2row + 16 * s); }, w, j, kq, xh2, r2);
             lds_barrier();                                       // a2 visible
             heads_fwd<1>(L, wh, bh, w, lane);
             if (w == 0) {
@@ -473,10 +601,15 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob b
 constexpr int UNC = 2;                  // column tiles per workgroup step: 32 samples
 constexpr int UMS = MT * UNC;
 constexpr int LS_STRIDE = 10;             // doubles per loss lane: policy / value / entropy / NaN sums + 6 head-bias sums
-constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 2 * H1 + 3 * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2 + UMS * AS1 + UMS * AS2;
+// + (H3) P2 [2 pieces][MS][RS2] dz2 as scaled fp16 planes, MX [8 waves][MS] per-sample maxima for their scale
+constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 2 * H1 + 3 * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2 + UMS * RS2 + NWAVE * UMS;
 constexpr size_t UPD_LDS = (size_t)UPD_FLOATS * sizeof(float);
 constexpr int SLAB = NPARAM;            // one gradient slab per workgroup, flat parameter layout
 
+// H3: the two K = 256 / K = 128 products (layer 2 forward, da1 = W2^T dz2) on the fp16 matrix pipe at f32 accuracy; `w2t`
+// is then the pre-split weights in MFMA fragment order (mlp_w2_pieces_kernel) instead of the f32 transpose.  dW2 (K = the
+// tile's 32 samples) stays on exact-f32 MFMA: its operands would need a second, transposed set of piece planes.
+template <bool H3>
 __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     const float* __restrict__ params, const float* __restrict__ obs, const int32_t* __restrict__ act,
     const float* __restrict__ logp_old, const float* __restrict__ adv, const float* __restrict__ ret,
@@ -495,9 +628,8 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     // re-read from here where they are used instead of living in 10 VGPRs across the whole tile loop
     float* W1L = reinterpret_cast<float*>(LS + MS * LS_STRIDE);
     float* WHL = W1L + H1 * 8;
-    // xhat of both LayerNorms, parked between the forward and the backward of a tile (24 VGPRs of a kernel that spilled)
-    float* XH1 = WHL + 8 * H2;
-    float* XH2 = XH1 + MS * AS1;
+    unsigned short* P2 = reinterpret_cast<unsigned short*>(WHL + 8 * H2);
+    float* MX = reinterpret_cast<float*>(P2 + 2 * MS * RS2);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -524,6 +656,10 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     const float* wfw = params + O_W2 + (16 * w + j) * H1 + 4 * kq;           // forward:  W2[16 w + j][16 s + 4 kq ..]
     const float* wbw0 = w2t + (32 * w + j) * H2 + 4 * kq;                    // backward: W2^T[32 w + 16 t + j][16 s + 4 kq ..]
     const float* wbw1 = wbw0 + 16 * H2;
+    // H3: fragment-ordered pieces.  forward: [row tile w][8 slabs][2 pieces][64 lanes][8]; backward (after the 64 K halves of
+    // the forward set): [row tile 2 w + t][4 slabs][2][64][8]
+    const unsigned short* w2f = reinterpret_cast<const unsigned short*>(w2t) + (size_t)w * 8 * 2 * 512 + lane * 8;
+    const unsigned short* w2b = reinterpret_cast<const unsigned short*>(w2t) + (size_t)H1 * H2 * 2 + (size_t)(2 * w) * 4 * 2 * 512 + lane * 8;
     const float* bh = params + O_BH;
 
     f32x4 dW2[16], dW1[2], dWh;
@@ -552,28 +688,20 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         lds_barrier();
         M_PROF_MARK(0);
         // ---- forward
+        f32x4 xh1[NC][2], xh2[NC];
         float r1[NC], r2[NC];
         {
-            f32x4 xh1[NC][2];
             float w1a[2][2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) w1a[t][s] = W1L[(32 * w + 16 * t + j) * 8 + 4 * s + kq];
-            layer1<NC>(L, w1a, w, j, kq, xh1, r1);
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) st4(XH1 + (16 * c + j) * AS1 + 32 * w + 16 * t + 4 * kq, xh1[c][t]);
+            layer1<NC, H3 ? 2 : 0>(L, w1a, w, j, kq, xh1, r1);
         }
         lds_barrier();
         M_PROF_MARK(1);
-        {
-            f32x4 xh2[NC];
-            layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) st4(XH2 + (16 * c + j) * AS2 + 16 * w + 4 * kq, xh2[c]);
-        }
+        if constexpr (H3) layer2_h3<NC>(L, [&](int sl, int pc) { return *reinterpret_cast<const f16x8*>(w2f + (sl * 2 + pc) * 512); }, w, j, kq, xh2, r2);
+        else layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
         lds_barrier();
         M_PROF_MARK(2);
         {
@@ -621,6 +749,9 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         }
         // ---- LayerNorm 2 + ReLU backward (mlp.hip: ln_relu_bwd_kernel's arithmetic)
         f32x4 dz2[NC];
+        float isc2[NC];                                      // H3: inverse fp16 scale of samples 16 c + j
+#pragma unroll
+        for (int c = 0; c < NC; ++c) isc2[c] = 1.f;
         {
             const int u = 16 * w + 4 * kq;
             const f32x4 g = ld4(L.prm + 3 * H1 + H2 + u), be = ld4(L.prm + 3 * H1 + 2 * H2 + u);
@@ -632,15 +763,12 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
             f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = sg, sz = sg;
             float* a2p = ACC2 + u;
             const float whT[2] = {WHL[kq * H2 + 16 * w + j], WHL[(4 + kq) * H2 + 16 * w + j]};
-            f32x4 xh2[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) xh2[c] = ld4(XH2 + (16 * c + j) * AS2 + u);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 f32x4 da2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) da2 = mfma4(whT[s], DH[(16 * c + j) * 8 + 4 * s + kq], da2);
-                float q1 = 0.f, q2 = 0.f;
+                float q1 = 0.f, q2 = 0.f, mx = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float dy = (xh2[c][r] * g[r] + be[r] > 0.f) ? da2[r] : 0.f;
@@ -649,9 +777,15 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                     dxh[c][r] = dy * g[r];
                     q1 += dxh[c][r];
                     q2 += dxh[c][r] * xh2[c][r];
+                    mx = fmaxf(mx, fabsf(dxh[c][r]));
                 }
                 p1[c] = (double)q1;
                 p2[c] = (double)q2;
+                if (H3) {        // this wave's max |dxhat| of sample 16 c + j, for the sample's fp16 scale (below)
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    if (kq == 0) MX[w * MS + 16 * c + j] = mx;
+                }
             }
             sg = row16_sum(sg);                              // dg2, dbe2: summed over the tile's 16 sample lanes, then ONE lane per
             sb = row16_sum(sb);                              // kq group adds them to the per-unit accumulators
@@ -668,6 +802,37 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                 for (int r = 0; r < 4; ++r) dz2[c][r] = r2[c] * (dxh[c][r] - m1 - xh2[c][r] * m2);
                 st4(L.A2 + (16 * c + j) * AS2 + u, dz2[c]);  // dz2 replaces a2
                 sz = sz + dz2[c];
+                if (H3) {
+                    // The sample's dz2 row as two fp16 planes for da1 = W2^T dz2.  Gradients span dozens of binades, fp16
+                    // five bits of exponent: the row is scaled by the power of two that puts a BOUND on its largest
+                    // magnitude -- |dz2| <= rstd (max |dxhat| + |m1| + sqrt(127) |m2|), identical in every wave -- into
+                    // [2^13, 2^14), and the sample's column of da1 is scaled back exactly.
+                    float M = MX[16 * c + j];
+#pragma unroll
+                    for (int i = 1; i < NWAVE; ++i) M = fmaxf(M, MX[i * MS + 16 * c + j]);
+                    const float bound = r2[c] * (M + fabsf(m1) + 11.3f * fabsf(m2));
+                    int e = 0;
+                    if (bound > 0.f && bound < 3.0e38f) {
+                        e = 13 - (int)((__float_as_uint(bound) >> 23) & 0xff) + 127;
+                        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+                    }
+                    const float sc = __uint_as_float((unsigned)(127 + e) << 23);
+                    isc2[c] = __uint_as_float((unsigned)(127 - e) << 23);
+                    unsigned short b[2][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        _Float16 p0, p1;
+                        split2h(dz2[c][r] * sc, p0, p1);
+                        b[0][r] = h_bits(p0); b[1][r] = h_bits(p1);
+                    }
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        uint2 v;
+                        v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+                        v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+                        *reinterpret_cast<uint2*>(P2 + (pc * MS + 16 * c + j) * RS2 + u) = v;
+                    }
+                }
             }
             sz = row16_sum(sz);
             if (j == 0) st4(a2p + 2 * H2, ld4(a2p + 2 * H2) + sz);
@@ -690,7 +855,42 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         f32x4 da1[NC][2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) da1[c][0] = da1[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
+        if constexpr (H3) {
+            // da1^T tile (row tiles 2 w, 2 w + 1 of the 256 units) = W2^T pieces x the scaled dz2 planes, K = 128 in 4 slabs
+            const unsigned short* brow = P2 + j * RS2 + 8 * kq;
+            f32x4 acl[NC][2];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acl[c][0] = acl[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f16x8 wq[2][2][2];                               // [buffer][row tile][piece]: one slab ahead
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { wq[0][t][0] = *reinterpret_cast<const f16x8*>(w2b + (t * 4) * 1024); wq[0][t][1] = *reinterpret_cast<const f16x8*>(w2b + (t * 4) * 1024 + 512); }
+#pragma unroll
+            for (int sl = 0; sl < H2 / 32; ++sl) {
+                if (sl + 1 < H2 / 32) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        wq[(sl + 1) & 1][t][0] = *reinterpret_cast<const f16x8*>(w2b + (t * 4 + sl + 1) * 1024);
+                        wq[(sl + 1) & 1][t][1] = *reinterpret_cast<const f16x8*>(w2b + (t * 4 + sl + 1) * 1024 + 512);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const f16x8 b0 = *reinterpret_cast<const f16x8*>(brow + (16 * c) * RS2 + 32 * sl);
+                    const f16x8 b1 = *reinterpret_cast<const f16x8*>(brow + (MS + 16 * c) * RS2 + 32 * sl);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acl[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[sl & 1][t][1], b0, acl[c][t], 0, 0, 0);
+                        da1[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[sl & 1][t][0], b0, da1[c][t], 0, 0, 0);
+                        acl[c][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[sl & 1][t][0], b1, acl[c][t], 0, 0, 0);
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) da1[c][t] = (da1[c][t] + acl[c][t] * H3_LO) * isc2[c];
+        } else {
             const float* brow = L.A2 + j * AS2 + 4 * kq;
             f32x4 wq[2][2][2];                               // [buffer][slab in chunk][row tile]: two slabs ahead
 #pragma unroll
@@ -724,11 +924,6 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         // ---- LayerNorm 1 + ReLU backward
         {
             f32x4 dxh[NC][2];                                // da1 becomes dxhat in place
-            f32x4 xh1[NC][2];
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) xh1[c][t] = ld4(XH1 + (16 * c + j) * AS1 + 32 * w + 16 * t + 4 * kq);
             double p1[NC], p2[NC];
             float q1[NC], q2[NC];
 #pragma unroll
@@ -834,6 +1029,32 @@ __global__ __launch_bounds__(256) void mlp_w2_transpose_kernel(const float* __re
     if (i < H1 * H2) w2t[i] = params[O_W2 + (i % H2) * H1 + i / H2];
 }
 
+// H3: both orientations of W2 as fp16 piece fragments (once per gradient call): forward set [8 row tiles][8 slabs][2][64][8],
+// element (i, kq, e) of fragment (w, s) = W2[16 w + i][32 s + 8 kq + e]; backward set [16 row tiles][4 slabs][2][64][8],
+// element = W2[32 s + 8 kq + e][16 rt + i].
+__global__ __launch_bounds__(256) void mlp_w2_pieces_kernel(const float* __restrict__ params, unsigned short* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;           // over 2 x H1 * H2 elements
+    if (i >= 2 * H1 * H2) return;
+    const bool bwd = i >= H1 * H2;
+    const int q = bwd ? i - H1 * H2 : i;
+    const int e = q & 7, lane = (q >> 3) & 63, row = lane & 15, kq = lane >> 4;
+    float v;
+    size_t o;
+    if (!bwd) {
+        const int sl = (q >> 9) & 7, wt = q >> 12;
+        v = params[O_W2 + (16 * wt + row) * H1 + 32 * sl + 8 * kq + e];
+        o = ((size_t)(wt * 8 + sl) * 2) * 512 + lane * 8 + e;
+    } else {
+        const int sl = (q >> 9) & 3, rt = q >> 11;
+        v = params[O_W2 + (32 * sl + 8 * kq + e) * H1 + 16 * rt + row];
+        o = (size_t)H1 * H2 * 2 + ((size_t)(rt * 4 + sl) * 2) * 512 + lane * 8 + e;
+    }
+    _Float16 p0, p1;
+    split2h(v, p0, p1);
+    out[o] = h_bits(p0);
+    out[o + 512] = h_bits(p1);
+}
+
 // grad[i] = sum over the workgroups' slabs, 8 independent partial sums in a fixed association (deterministic)
 __global__ __launch_bounds__(256) void mlp_slab_reduce_kernel(const float* __restrict__ slabs, int nb, int n, float* __restrict__ out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -860,9 +1081,17 @@ int launch_rollout_mlp(uav_ctx* ctx, void* env_state, int n_env, const uav_env_c
     UAV_REQUIRE(P.trend_k == 0, "uav_rollout: the fused MLP rollout has 6 observation features (trend_k = 0)");
     MlpRollBufs B{cur_obs, obs, act, rew, val, logp, done, flags, last_val, forced_act, noise, nan_count, info, heads};
     EnvBlob blob = env_blob_view(env_state, n_env);
-    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&rollout_mlp_kernel), (int)ROLL_LDS));
-    hipLaunchKernelGGL(rollout_mlp_kernel, dim3((n_env + MT - 1) / MT), dim3(512), ROLL_LDS, st, P, blob, n_env, horizon, iter,
-                       params, B);
+    // the handle's arithmetic (uav_set_lstm_arith): FP16X3 = the 256 x 128 layer on the fp16 matrix pipe (max |param| < 2048);
+    // anything else = exact-f32 MFMA
+    if (ctx->lstm_arith == UAV_ARITH_FP16X3) {
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&rollout_mlp_kernel<true>), (int)ROLL_LDS));
+        hipLaunchKernelGGL(rollout_mlp_kernel<true>, dim3((n_env + MT - 1) / MT), dim3(512), ROLL_LDS, st, P, blob, n_env, horizon,
+                           iter, params, B);
+    } else {
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&rollout_mlp_kernel<false>), (int)ROLL_LDS));
+        hipLaunchKernelGGL(rollout_mlp_kernel<false>, dim3((n_env + MT - 1) / MT), dim3(512), ROLL_LDS, st, P, blob, n_env, horizon,
+                           iter, params, B);
+    }
     UAV_LAUNCH_CHECK();
     return 0;
 }
@@ -880,15 +1109,23 @@ extern "C" int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* 
     const int64_t ntile = (n + UMS - 1) / UMS;
     int nb = ctx->num_cu;
     if (nb > ntile) nb = (int)ntile;
-    const size_t head = 65536, w2t_bytes = (size_t)H1 * H2 * sizeof(float);      // loss partials | W2^T | slabs
+    const bool h3 = ctx->lstm_arith == UAV_ARITH_FP16X3;       // the handle's arithmetic (uav_set_lstm_arith); else exact-f32 MFMA
+    const size_t head = 65536, w2t_bytes = (size_t)H1 * H2 * sizeof(float) * 2;  // loss partials | W2^T or both piece sets | slabs
     UAV_REQUIRE(ctx->ws_bytes >= head + w2t_bytes + (size_t)nb * SLAB * sizeof(float), "uav_mlp_ppo_grad: workspace too small");
     double* partial = (double*)ctx->ws;
     float* w2t = (float*)((char*)ctx->ws + head);
     float* slabs = (float*)((char*)ctx->ws + head + w2t_bytes);
-    hipLaunchKernelGGL(mlp_w2_transpose_kernel, dim3(H1 * H2 / 256), dim3(256), 0, st, params, w2t);
-    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&mlp_ppo_grad_kernel), (int)UPD_LDS));
-    hipLaunchKernelGGL(mlp_ppo_grad_kernel, dim3(nb), dim3(512), UPD_LDS, st, params, obs, act, logp_old, adv, ret, val_old, n,
-                       inv_n, clip, ent_beta, partial, slabs, w2t);
+    if (h3) {
+        hipLaunchKernelGGL(mlp_w2_pieces_kernel, dim3(2 * H1 * H2 / 256), dim3(256), 0, st, params, reinterpret_cast<unsigned short*>(w2t));
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&mlp_ppo_grad_kernel<true>), (int)UPD_LDS));
+        hipLaunchKernelGGL(mlp_ppo_grad_kernel<true>, dim3(nb), dim3(512), UPD_LDS, st, params, obs, act, logp_old, adv, ret, val_old,
+                           n, inv_n, clip, ent_beta, partial, slabs, w2t);
+    } else {
+        hipLaunchKernelGGL(mlp_w2_transpose_kernel, dim3(H1 * H2 / 256), dim3(256), 0, st, params, w2t);
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&mlp_ppo_grad_kernel<false>), (int)UPD_LDS));
+        hipLaunchKernelGGL(mlp_ppo_grad_kernel<false>, dim3(nb), dim3(512), UPD_LDS, st, params, obs, act, logp_old, adv, ret, val_old,
+                           n, inv_n, clip, ent_beta, partial, slabs, w2t);
+    }
     hipLaunchKernelGGL(mlp_slab_reduce_kernel, dim3((SLAB + 255) / 256), dim3(256), 0, st, slabs, nb, SLAB, grad);
     UAV_LAUNCH_CHECK();
     return launch_loss_final(partial, nb, NH, loss_sums, nullptr, st);
