@@ -103,9 +103,36 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ f32x4 row16_sum(f32x4 v) { return f32x4{row16_sum(v[0]), row16_sum(v[1]), row16_sum(v[2]), row16_sum(v[3])}; }
 
 // sum over the four lanes that hold the same sample (lane & 15) of a wave
+// (the two gfx950 row-swap instructions instead of ds_bpermute: v_permlane16_swap / v_permlane32_swap hand every lane its
+//  xor-16 / xor-32 partner's dword without touching LDS; a + b == b + a bitwise, so the four lanes agree)
+__device__ __forceinline__ float quad_sum(float v) {
+    {
+        const auto s = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        v = __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+    }
+    {
+        const auto s = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        v = __builtin_bit_cast(float, (unsigned)s[0]) + __builtin_bit_cast(float, (unsigned)s[1]);
+    }
+    return v;
+}
 __device__ __forceinline__ double quad_sum(double v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        const double x = __builtin_bit_cast(double, (unsigned long long)(unsigned)lo[0] | ((unsigned long long)(unsigned)hi[0] << 32));
+        const double y = __builtin_bit_cast(double, (unsigned long long)(unsigned)lo[1] | ((unsigned long long)(unsigned)hi[1] << 32));
+        v = x + y;
+    }
+    {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        const double x = __builtin_bit_cast(double, (unsigned long long)(unsigned)lo[0] | ((unsigned long long)(unsigned)hi[0] << 32));
+        const double y = __builtin_bit_cast(double, (unsigned long long)(unsigned)lo[1] | ((unsigned long long)(unsigned)hi[1] << 32));
+        v = x + y;
+    }
     return v;
 }
 
@@ -132,6 +159,34 @@ __device__ __forceinline__ void ln_exchange(const Tiles<NC>& L, int w, int j, in
         for (int i = 0; i < NWAVE; ++i) {
             A[c] += L.red[i * MS + 16 * c + j];
             B[c] += L.red[(NWAVE + i) * MS + 16 * c + j];
+        }
+    }
+}
+
+// The same exchange in f32 for the LayerNorm BACKWARD sums (mean of dxhat, mean of dxhat * xhat): they enter the result
+// linearly, so there is no cancellation to protect and the reference's own backward accumulates them in f32.
+template <int NC>
+__device__ __forceinline__ void ln_exchange_f32(const Tiles<NC>& L, int w, int j, int kq, const float (&a)[NC], const float (&b)[NC],
+                                                float (&A)[NC], float (&B)[NC]) {
+    constexpr int MS = MT * NC;
+    float* red = reinterpret_cast<float*>(L.red);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float ta = quad_sum(a[c]), tb = quad_sum(b[c]);
+        if (kq == 0) {
+            red[w * MS + 16 * c + j] = ta;
+            red[(NWAVE + w) * MS + 16 * c + j] = tb;
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        A[c] = 0.f;
+        B[c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) {
+            A[c] += red[i * MS + 16 * c + j];
+            B[c] += red[(NWAVE + i) * MS + 16 * c + j];
         }
     }
 }
@@ -700,8 +755,16 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         }
         lds_barrier();
         M_PROF_MARK(1);
-        if constexpr (H3) layer2_h3<NC>(L, [&](int sl, int pc) { return *reinterpret_cast<const f16x8*>(w2f + (sl * 2 + pc) * 512); }, w, j, kq, xh2, r2);
-        else layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
+        if constexpr (H3) {
+            // ONE address register pair, advanced 4 KB per two-slab chunk, the four fragments of a chunk at immediate offsets:
+            // sixteen separate 64-bit addresses (what the compiler makes of w2f + constant) are sixteen spilled pairs
+            const unsigned short* pw = w2f;
+            asm volatile("" : "+v"(pw));
+            layer2_h3<NC>(L, [&](int sl, int pc) {
+                if (sl > 0 && (sl & 1) == 0 && pc == 0) { pw += 2048; asm volatile("" : "+v"(pw)); }
+                return *reinterpret_cast<const f16x8*>(pw + ((sl & 1) * 2 + pc) * 512);
+            }, w, j, kq, xh2, r2);
+        } else layer2<NC>(L, [&](int s) { return ld4(wfw + 16 * s); }, w, j, kq, xh2, r2);
         lds_barrier();
         M_PROF_MARK(2);
         {
@@ -759,7 +822,7 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
             // per-lane partial sums in f32 (4 terms, fixed order), widened to f64 only for the cross-lane / cross-wave sum:
             // the reference's own LayerNorm backward accumulates in f32; 48 f64 conversions and FMAs per tile and lane
             // here and in LayerNorm 1 were a quarter of these phases' issue time
-            double p1[NC], p2[NC];
+            float p1[NC], p2[NC];
             f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = sg, sz = sg;
             float* a2p = ACC2 + u;
             const float whT[2] = {WHL[kq * H2 + 16 * w + j], WHL[(4 + kq) * H2 + 16 * w + j]};
@@ -779,11 +842,15 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                     q2 += dxh[c][r] * xh2[c][r];
                     mx = fmaxf(mx, fabsf(dxh[c][r]));
                 }
-                p1[c] = (double)q1;
-                p2[c] = (double)q2;
+                p1[c] = q1;
+                p2[c] = q2;
                 if (H3) {        // this wave's max |dxhat| of sample 16 c + j, for the sample's fp16 scale (below)
-                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    {
+                        const auto s16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+                        mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+                        const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+                        mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+                    }
                     if (kq == 0) MX[w * MS + 16 * c + j] = mx;
                 }
             }
@@ -793,11 +860,11 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                 st4(a2p, ld4(a2p) + sg);
                 st4(a2p + H2, ld4(a2p + H2) + sb);
             }
-            double S1[NC], S2[NC];
-            ln_exchange<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dWh reads of A2 are done
+            float S1[NC], S2[NC];
+            ln_exchange_f32<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dWh reads of A2 are done
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const float m1 = (float)(S1[c] * (1.0 / H2)), m2 = (float)(S2[c] * (1.0 / H2));
+                const float m1 = S1[c] * (1.0f / H2), m2 = S2[c] * (1.0f / H2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dz2[c][r] = r2[c] * (dxh[c][r] - m1 - xh2[c][r] * m2);
                 st4(L.A2 + (16 * c + j) * AS2 + u, dz2[c]);  // dz2 replaces a2
@@ -862,16 +929,18 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
 #pragma unroll
             for (int c = 0; c < NC; ++c) acl[c][0] = acl[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             f16x8 wq[2][2][2];                               // [buffer][row tile][piece]: one slab ahead
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { wq[0][t][0] = *reinterpret_cast<const f16x8*>(w2b + (t * 4) * 1024); wq[0][t][1] = *reinterpret_cast<const f16x8*>(w2b + (t * 4) * 1024 + 512); }
+            const unsigned short* pb0 = w2b;                 // one address pair per row tile, advanced 2 KB per slab
+            const unsigned short* pb1 = w2b + 4 * 1024;
+            asm volatile("" : "+v"(pb0), "+v"(pb1));
+            wq[0][0][0] = *reinterpret_cast<const f16x8*>(pb0); wq[0][0][1] = *reinterpret_cast<const f16x8*>(pb0 + 512);
+            wq[0][1][0] = *reinterpret_cast<const f16x8*>(pb1); wq[0][1][1] = *reinterpret_cast<const f16x8*>(pb1 + 512);
 #pragma unroll
             for (int sl = 0; sl < H2 / 32; ++sl) {
                 if (sl + 1 < H2 / 32) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        wq[(sl + 1) & 1][t][0] = *reinterpret_cast<const f16x8*>(w2b + (t * 4 + sl + 1) * 1024);
-                        wq[(sl + 1) & 1][t][1] = *reinterpret_cast<const f16x8*>(w2b + (t * 4 + sl + 1) * 1024 + 512);
-                    }
+                    pb0 += 1024; pb1 += 1024;
+                    asm volatile("" : "+v"(pb0), "+v"(pb1));
+                    wq[(sl + 1) & 1][0][0] = *reinterpret_cast<const f16x8*>(pb0); wq[(sl + 1) & 1][0][1] = *reinterpret_cast<const f16x8*>(pb0 + 512);
+                    wq[(sl + 1) & 1][1][0] = *reinterpret_cast<const f16x8*>(pb1); wq[(sl + 1) & 1][1][1] = *reinterpret_cast<const f16x8*>(pb1 + 512);
                 }
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
@@ -924,7 +993,6 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
         // ---- LayerNorm 1 + ReLU backward
         {
             f32x4 dxh[NC][2];                                // da1 becomes dxhat in place
-            double p1[NC], p2[NC];
             float q1[NC], q2[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) q1[c] = q2[c] = 0.f;
@@ -952,16 +1020,14 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                     st4(a1p + H1, ld4(a1p + H1) + sb);
                 }
             }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { p1[c] = (double)q1[c]; p2[c] = (double)q2[c]; }
-            double S1[NC], S2[NC];
-            ln_exchange<NC>(L, w, j, kq, p1, p2, S1, S2);    // barrier inside: every wave's dW2 reads of A1 are done
+            float S1[NC], S2[NC];
+            ln_exchange_f32<NC>(L, w, j, kq, q1, q2, S1, S2);    // barrier inside: every wave's dW2 reads of A1 are done
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int u = 32 * w + 16 * t + 4 * kq;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const float m1 = (float)(S1[c] * (1.0 / H1)), m2 = (float)(S2[c] * (1.0 / H1));
+                    const float m1 = S1[c] * (1.0f / H1), m2 = S2[c] * (1.0f / H1);
                     f32x4 dz1;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dz1[r] = r1[c] * (dxh[c][t][r] - m1 - xh1[c][t][r] * m2);
