@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 4   /* 4: uav_set_debug_flags; the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 4   /* 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -236,7 +236,12 @@ int uav_mlp_bwd(uav_ctx* ctx, const float* params, const float* x, float* stash,
  * 44 algorithmic bytes per sample.  obs [n][6], act i32 [n], logp_old / adv / ret / val_old f32 [n]; inv_n = 1 / (global
  * sample count); loss_sums f64[4] as uav_ppo_loss; grad: flat f32 gradient in the layout of `params` (overwritten;
  * includes the head biases).  The fused kernel is specialised for the reference's sizes (in 6, 256, 128, 5 actions); other
- * sizes take uav_mlp_fwd + uav_ppo_loss + uav_mlp_bwd. */
+ * sizes take uav_mlp_fwd + uav_ppo_loss + uav_mlp_bwd.
+ * Arithmetic: the handle's mode (uav_set_lstm_arith) also governs this kernel and uav_rollout's policy_kind 0.  FP16X3
+ * (default): the 256 x 128 layer and its transpose product da1 = W2^T dz2 as three fp16 piece products per f32 product
+ * (f32 results; dz2 block-scaled per sample by a power of two); needs max |param| < 2048, so that W2 and the layer's input
+ * a1 <= sqrt(255) |g1| + |be1| stay inside fp16's range.  Any other mode: every product on exact-f32 MFMA, no range
+ * limit.  The Python trainer measures max |param| (uav_clip_adam's pmax_out) and switches by itself. */
 int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* obs, const int32_t* act, const float* logp_old,
                      const float* adv, const float* ret, const float* val_old, int64_t n, int in_dim, int h1, int h2,
                      int n_act, float inv_n, float clip, float ent_beta, double* loss_sums, float* grad,

@@ -563,6 +563,40 @@ def test_range_guard_covers_h256():
     assert tr.arith == "fp16x3"
 
 
+def test_range_guard_covers_the_fused_mlp():
+    """The fused MLP kernels run the 256 x 128 layer on the fp16 split (max |param| < 2048).  A LayerNorm gain of 3000
+    pushes the layer's input past fp16's range: the trainer must switch the handle to the exact-f32 form of the same
+    kernels by itself, and the update must still match the f32 oracle; in range it stays on the split."""
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    N, T = 12, 20
+    for big in (True, False):
+        tr = VecPPOTrainer(N, T, "mlp", device=DEV, seed=5, use_curriculum=False, epochs=1)
+        if big:
+            with torch.no_grad():
+                tr.policy.views["feature.1.weight"][7] = 3000.0
+        d, last_val = _fill_synthetic(tr, N, T, 0, 0, seed=3)
+        p = cpu_params(tr.policy)
+        adam = po.AdamState(p)
+        tr.record = True
+        tr.update()
+        assert (tr.arith != "fp16x3") == big and (tr.range_events == 1) == big
+        assert (ops.get_lstm_arith(DEV) != "fp16x3") == big
+        adv = po.gae_reference_exact(d["rew"], d["val"], d["done"])
+        adv, ret = po.normalise(adv, d["val"])
+        leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+        probs, value, _ = po.mlp_forward(leaf, torch.from_numpy(d["obs"]).reshape(N * T, 6))
+        total, pl, vl, ent = po.ppo_losses(probs, value, torch.from_numpy(d["act"]).reshape(-1), torch.from_numpy(d["logp"]).reshape(-1),
+                                           adv, ret, torch.from_numpy(d["val"]).reshape(-1))
+        total.backward()
+        gn = po.clip_grads({k: leaf[k].grad for k in p})
+        s = tr.log[0][0].cpu().numpy()
+        assert np.isfinite(s).all()
+        assert np.allclose(s[:3] / (N * T), [float(pl), float(vl), float(ent)], rtol=3e-4, atol=3e-6)
+        assert np.isclose(tr.log[0][1].item(), gn, rtol=3e-3)
+    ops.set_lstm_arith("fp16x3")
+
+
 def test_adam_publishes_max_abs_param(ops=None):
     from uavppo import ops
     n = 5000

@@ -25,6 +25,9 @@ DEFAULTS = dict(gamma=0.99, lam=0.95, clip=0.2, ent_beta=0.01, lr=3e-5, epochs=5
 # trainer switches to the bf16-split kernels at HALF of each limit; parameters move by at most lr per optimiser step, so a
 # weight maximum read one iteration late still has that margin.
 RANGE_LIMITS = (0.5 * 65504.0, 0.5 * 4096.0, 0.5 * 64.0)
+# the fused MLP kernels run their 256 x 128 products on the same fp16 split: its operand a1 = relu(LayerNorm) is bounded by
+# sqrt(255) |g1| + |be1|, so max |param| < 2048 keeps it inside fp16's range (include/uavppo.h, uav_mlp_ppo_grad); half of it:
+MLP_RANGE_LIMITS = (0.5 * 2048.0, float("inf"), float("inf"))
 
 
 _SIDE_STREAMS = {}
@@ -174,11 +177,12 @@ class VecPPOTrainer:
     #                caller (update() without a preceding collect()) ARE measured, synchronously, before the update.
     def _guarded(self):
         """Every LSTM policy: the h = 64 / 128 sequence kernels AND the h = 256 step kernels are fp16-split by default.
-        (At h = 256 the wide-range modes run the generic exact-f32 step path -- slow, but never silently out of range.)"""
-        return self.kind == "lstm"
+        (At h = 256 the wide-range modes run the generic exact-f32 step path -- slow, but never silently out of range.)
+        The fused MLP kernels likewise (their wide-range mode is the exact-f32 MFMA form of the same kernels)."""
+        return self.kind == "lstm" or self.fused_mlp
 
     def _decide(self, maxima):
-        ok = all(v == v and v < lim for v, lim in zip(maxima, RANGE_LIMITS))
+        ok = all(v == v and v < lim for v, lim in zip(maxima, RANGE_LIMITS if self.kind == "lstm" else MLP_RANGE_LIMITS))
         self.arith = "fp16x3" if ok else "bf16x6"
         self.range_events += (not ok)
         if self.force_arith is not None:
@@ -210,8 +214,9 @@ class VecPPOTrainer:
         if not self._buffers_own:               # foreign buffers: measure everything now
             self._pmax_queue.clear()
             ops.absmax(self.policy.flat, out=self.ranges[0:1])
-            ops.absmax(self.buf["obs"], out=self.ranges[1:2])
-            ops.absmax(self.h0, out=self.ranges[2:3])
+            if self.kind == "lstm":
+                ops.absmax(self.buf["obs"], out=self.ranges[1:2])
+                ops.absmax(self.h0, out=self.ranges[2:3])
             self._flat_version = self.policy.flat._version
             self._decide(self.ranges.tolist())
         else:
