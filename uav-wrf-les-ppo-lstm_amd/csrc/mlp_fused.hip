@@ -102,6 +102,34 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 __device__ __forceinline__ f32x4 row16_sum(f32x4 v) { return f32x4{row16_sum(v[0]), row16_sum(v[1]), row16_sum(v[2]), row16_sum(v[3])}; }
 
+// max over all 64 lanes of a wave (DPP within the rows of 16, then the two row swaps); every lane gets the result
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true)));
+    const auto s16 = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+    const auto s32 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+}
+
+// Transposed LDS read (gfx950 ds_read_b64_tr_b16): an MFMA 16x16x32 fragment -- 8 consecutive K per lane -- from a plane
+// stored [K rows][16+ columns of halves] with row stride `rs` halves: lane (i = lane & 15, kq) gets rows 8 kq .. 8 kq + 7 of
+// column i.  Lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of each 4-row block.
+// EXEC must be all ones (the gather crosses lanes): only called from uniform code.
+__device__ __forceinline__ f16x8 tr_frag(const unsigned short* plane, int rs, int lane) {
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    typedef __attribute__((address_space(3))) v4s lds_v4s;
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned short* a = plane + (8 * kq + (li >> 2)) * rs + 4 * (li & 3);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)a);
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(a + 4 * rs));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    const v8s r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, r);
+}
+
 // sum over the four lanes that hold the same sample (lane & 15) of a wave
 // (the two gfx950 row-swap instructions instead of ds_bpermute: v_permlane16_swap / v_permlane32_swap hand every lane its
 //  xor-16 / xor-32 partner's dword without touching LDS; a + b == b + a bitwise, so the four lanes agree)
@@ -657,7 +685,7 @@ constexpr int UNC = 2;                  // column tiles per workgroup step: 32 s
 constexpr int UMS = MT * UNC;
 constexpr int LS_STRIDE = 10;             // doubles per loss lane: policy / value / entropy / NaN sums + 6 head-bias sums
 // + (H3) P2 [2 pieces][MS][RS2] dz2 as scaled fp16 planes, MX [8 waves][MS] per-sample maxima for their scale
-constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 2 * H1 + 3 * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2 + UMS * RS2 + NWAVE * UMS;
+constexpr int UPD_FLOATS = Tiles<UNC>::FLOATS + 2 * H1 + 3 * H2 + UMS * 8 + 2 * UMS * LS_STRIDE + H1 * 8 + 8 * H2 + UMS * RS2 + NWAVE * UMS + UMS * RS2;
 constexpr size_t UPD_LDS = (size_t)UPD_FLOATS * sizeof(float);
 constexpr int SLAB = NPARAM;            // one gradient slab per workgroup, flat parameter layout
 
@@ -685,6 +713,9 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     float* WHL = W1L + H1 * 8;
     unsigned short* P2 = reinterpret_cast<unsigned short*>(WHL + 8 * H2);
     float* MX = reinterpret_cast<float*>(P2 + 2 * MS * RS2);
+    // dz2 once more for dW2 = dz2^T a1 (K = the tile's samples, so the scale must not depend on the sample): plane 0 =
+    // fp16(x), plane 1 = fp16(x - plane 0) with x = dz2 * 2^e_run, e_run the WAVE's running power of two (below)
+    unsigned short* P2w = reinterpret_cast<unsigned short*>(MX + NWAVE * MS);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -723,6 +754,10 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
     dW1[0] = dW1[1] = dWh = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x; i < MS * LS_STRIDE; i += 512) LS[i] = 0.0;
 
+    // H3: the dW2 accumulators of this wave hold dW2 * 2^e_run: dz2 rows of this wave's 16 units enter the fp16 product
+    // scaled by a power of two that puts the largest magnitude seen SO FAR in [2^13, 2^14); when a tile brings a larger one
+    // the exponent drops and the accumulators are rescaled (exact)
+    int e_run = 100;
     const int64_t ntile = (Bn + MS - 1) / MS;
     M_PROF_DECL;
     for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -751,7 +786,7 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) w1a[t][s] = W1L[(32 * w + 16 * t + j) * 8 + 4 * s + kq];
-            layer1<NC, H3 ? 2 : 0>(L, w1a, w, j, kq, xh1, r1);
+            layer1<NC, H3 ? 1 : 0>(L, w1a, w, j, kq, xh1, r1);
         }
         lds_barrier();
         M_PROF_MARK(1);
@@ -867,7 +902,7 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
                 const float m1 = S1[c] * (1.0f / H2), m2 = S2[c] * (1.0f / H2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dz2[c][r] = r2[c] * (dxh[c][r] - m1 - xh2[c][r] * m2);
-                st4(L.A2 + (16 * c + j) * AS2 + u, dz2[c]);  // dz2 replaces a2
+                if (!H3) st4(L.A2 + (16 * c + j) * AS2 + u, dz2[c]);  // dz2 replaces a2 (the f32 dW2 product reads it)
                 sz = sz + dz2[c];
                 if (H3) {
                     // The sample's dz2 row as two fp16 planes for da1 = W2^T dz2.  Gradients span dozens of binades, fp16
@@ -903,11 +938,68 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
             }
             sz = row16_sum(sz);
             if (j == 0) st4(a2p + 2 * H2, ld4(a2p + 2 * H2) + sz);
+            if constexpr (H3) {
+                float m = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(dz2[c][r]));
+                m = wave_max(m);
+                int e = 100;
+                if (m > 0.f && m < 3.0e38f) {
+                    e = 13 - (int)((__float_as_uint(m) >> 23) & 0xff) + 127;
+                    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+                }
+                if (e < e_run) {                             // wave-uniform: a larger magnitude than any tile before
+                    if (e_run < 100) {
+#pragma unroll
+                        for (int tj = 0; tj < 16; ++tj)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) dW2[tj][r] = __builtin_amdgcn_ldexpf(dW2[tj][r], e - e_run);
+                    }
+                    e_run = e;
+                }
+                const float sc = __builtin_amdgcn_ldexpf(1.0f, e_run);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    unsigned short b[2][4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = dz2[c][r] * sc;
+                        const _Float16 p0 = (_Float16)x;
+                        const _Float16 p1 = (_Float16)(x - (float)p0);
+                        b[0][r] = h_bits(p0); b[1][r] = h_bits(p1);
+                    }
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        uint2 v;
+                        v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+                        v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+                        *reinterpret_cast<uint2*>(P2w + (pc * MS + 16 * c + j) * RS2 + u) = v;
+                    }
+                }
+            }
         }
         lds_barrier();                                       // dz2 visible
         M_PROF_MARK(5);
         // ---- dW2 += dz2^T a1 (row tile w, all 16 column tiles; K = the tile's samples), da1 = W2^T dz2
-        {
+        if constexpr (H3) {
+            // one K = 32 slab (the tile's samples): A = this wave's 16 dz2 rows from P2w, B = a1 from the SAME planes layer 2
+            // read row-wise, both through the transposing LDS read.  a b = A0 q0 + 2^-11 A0 q1 + r q0 (+ O(2^-22)) with
+            // A0 = fp16(x), r = fp16(x - A0), q0 / q1 = split2h(a1): ONE accumulator, the 2^-11 folded into an operand.
+            const f16x8 a0 = tr_frag(P2w + 16 * w, RS2, lane);
+            const f16x8 ar = tr_frag(P2w + MS * RS2 + 16 * w, RS2, lane);
+            const f16x8 a0s = a0 * (_Float16)(1.0f / 2048.0f);
+#pragma unroll
+            for (int tj = 0; tj < 16; ++tj) {
+                const f16x8 q0 = tr_frag(L.P1 + 16 * tj, RS1, lane);
+                const f16x8 q1 = tr_frag(L.P1 + MS * RS1 + 16 * tj, RS1, lane);
+                dW2[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, q0, dW2[tj], 0, 0, 0);
+                dW2[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0s, q1, dW2[tj], 0, 0, 0);
+                dW2[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ar, q0, dW2[tj], 0, 0, 0);
+                if ((tj & 3) == 3) asm volatile("" ::: "memory");
+            }
+        } else {
             float af[MS / 4];
 #pragma unroll
             for (int s = 0; s < MS / 4; ++s) af[s] = L.A2[(4 * s + kq) * AS2 + 16 * w + j];
@@ -1062,7 +1154,8 @@ __global__ __launch_bounds__(512) void mlp_ppo_grad_kernel(
 #pragma unroll
     for (int tj = 0; tj < 16; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[O_W2 + (16 * w + 4 * kq + r) * H1 + 16 * tj + j] = dW2[tj][r];
+        for (int r = 0; r < 4; ++r)
+            slab[O_W2 + (16 * w + 4 * kq + r) * H1 + 16 * tj + j] = H3 ? __builtin_amdgcn_ldexpf(dW2[tj][r], -e_run) : dW2[tj][r];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (4 * kq + r < NH) slab[O_WH + (4 * kq + r) * H2 + 16 * w + j] = dWh[r];
