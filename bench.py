@@ -46,8 +46,11 @@ PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: exact-f32 MFMA = the f32 vector rate
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA ~2.5 PFLOP/s
 NHEADS = 6                       # 5 logits + value
-# the reference's MLP policy: products of the fused gradient / rollout kernels and the pipe they execute on
-MLP_EXEC_MULT, MLP_EXEC_PEAK = 1, PEAK_F32_MFMA_TFLOPS      # exact-f32 MFMA (v_mfma_f32_16x16x4_f32)
+# the reference's MLP policy (6-256-128-6): flops per sample of one forward pass, by the pipe that executes them in the fused
+# kernels: the 256 x 128 layer (and, in the update, its two transposed products) as three fp16 piece products per f32 product,
+# the two small layers on exact-f32 MFMA
+MLP_F32_FWD = 2 * (6 * 256 + 128 * 6)
+MLP_H3_FWD = 2 * 256 * 128
 # algorithmic bytes per env-step: rollout write 44, GAE 20 (12 read + 8 written), update 44 read per epoch
 ALG_ROLLOUT_B, ALG_GAE_B, ALG_UPDATE_B = 44, 20, 44
 
@@ -378,8 +381,14 @@ def load_traffic(tag_glob="r0*_hbm_traffic_pmc.json"):
 
 def binding_roof(bytes_moved, executed_flops, sec, flop_peak_tflops):
     """The roof that actually binds: the larger of (bytes moved / 8 TB/s) and (EXECUTED matrix flops / the peak of the
-    pipe they run on).  Returns the top-level roofline fields."""
+    pipe they run on).  executed_flops may be a list of (flops, peak TFLOP/s) pairs for work spread over two pipes: the
+    matrix-pipe fraction is then the sum of the times each part needs at its own peak, and `peak` the blended rate.
+    Returns the top-level roofline fields."""
     hbm = bytes_moved / sec / 1e9
+    if isinstance(executed_flops, (list, tuple)):
+        total = sum(f for f, _ in executed_flops)
+        t_peak = sum(f / (pk * 1e12) for f, pk in executed_flops)
+        executed_flops, flop_peak_tflops = total, total / t_peak / 1e12
     mf = executed_flops / sec / 1e12
     if hbm / PEAK_HBM_GBPS >= mf / flop_peak_tflops:
         return {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBPS}
@@ -439,7 +448,7 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
     else:
         fwd_fl = 2 * (I * 256 + 256 * 128 + 128 * NHEADS)
         impl_it = units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)     # the fused MLP kernels keep everything else on chip
-        it_mult, it_peak = MLP_EXEC_MULT, MLP_EXEC_PEAK
+        it_mult, it_peak = 1, PEAK_F32_MFMA_TFLOPS
     alg_it = units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)
     fl_it = units * fwd_fl * (1 + 3 * epochs)
     pm = None
@@ -448,15 +457,27 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
             return sum(v["hbm_total_bytes"] for k, v in traffic.items() if k.startswith(prefix))
         pm = tb("rollout_lstm_kernel") + (epochs - (1 if reused_fwd else 0)) * tb("lstm_fwd_h3_kernel") \
             + epochs * (tb("lstm_bwd_h3k_kernel") + tb("lstm_wgrad_h3_kernel") + tb("ppo_loss_kernel") + tb("wgrad_reduce_kernel"))
-    whole = binding_roof(pm if pm else impl_it, it_mult * fl_it, dt_iter, it_peak)
+    if kind == "lstm":
+        exec_it = it_mult * fl_it
+    elif arith == "fp16x3":      # rollout: one forward; per epoch: forward + twice that backward (dW1's input gradient is not formed)
+        exec_it = [(units * (MLP_F32_FWD * (1 + 3 * epochs) - epochs * 2 * 6 * 256), PEAK_F32_MFMA_TFLOPS),
+                   (units * 3 * MLP_H3_FWD * (1 + 3 * epochs), PEAK_F16_MFMA_TFLOPS)]
+    else:
+        exec_it = fl_it
+    whole = binding_roof(pm if pm else impl_it, exec_it, dt_iter, it_peak)
     whole.update({"bytes_basis": "pmc (big kernels)" if pm else "formula", "bytes_per_iteration": pm if pm else impl_it,
                   "algorithmic_bytes": alg_it, "algorithmic_GBps": alg_it / dt_iter / 1e9,
                   "frac_hbm_algorithmic": alg_it / dt_iter / 1e9 / PEAK_HBM_GBPS,
                   "implementation_bytes_formula": impl_it, "implementation_over_algorithmic": impl_it / alg_it,
                   "implementation_GBps": impl_it / dt_iter / 1e9,
                   "algorithmic_f32_tflops": fl_it / dt_iter / 1e12, "frac_f32_mfma_peak": fl_it / dt_iter / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                  "executed_tflops": it_mult * fl_it / dt_iter / 1e12, "executed_pipe_peak_tflops": it_peak,
-                  "frac_executed_pipe": it_mult * fl_it / dt_iter / 1e12 / it_peak})
+                  "executed_tflops": (sum(f for f, _ in exec_it) if isinstance(exec_it, list) else exec_it) / dt_iter / 1e12})
+    if isinstance(exec_it, list):
+        whole["executed_by_pipe"] = [{"tflops": f / dt_iter / 1e12, "peak_tflops": pk, "frac": f / dt_iter / 1e12 / pk} for f, pk in exec_it]
+        whole["frac_executed_pipe"] = sum(f / (pk * 1e12) for f, pk in exec_it) / dt_iter
+    else:
+        whole["executed_pipe_peak_tflops"] = it_peak
+        whole["frac_executed_pipe"] = exec_it / dt_iter / 1e12 / it_peak
     if pm:
         whole["pmc_bytes_big_kernels"] = pm
         whole["pmc_over_algorithmic"] = pm / alg_it

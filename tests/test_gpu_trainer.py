@@ -664,6 +664,51 @@ def test_fused_mlp_gradient_matches_oracle_and_layered_path(n):
     assert np.allclose(sums.cpu().numpy(), s2.cpu().numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize("pattern", ["growing", "shrinking", "spiky"])
+def test_fused_mlp_split_gradient_over_a_wide_dynamic_range(pattern):
+    """The fp16-split products of uav_mlp_ppo_grad against an f64 autograd of the same network, next to the exact-f32 form
+    of the same kernel (uav_set_lstm_arith): sample gradients spanning 30 decades -- growing along the batch (every tile
+    lowers the dW2 wave scale and rescales the accumulators), shrinking (late tiles far below the running scale), and a
+    few huge samples among tiny ones (per-sample dz2 scale of the da1 product).  The split kernels must be as close to f64
+    as the exact-f32 ones (to a factor 2 + f32 noise), tensor by tensor."""
+    from uavppo import ops
+    from uavppo.policy import MLPActorCritic
+    n = 4096
+    pol = MLPActorCritic(6, 5, device=DEV, seed=11)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(2)
+        for k in ("feature.1.weight", "feature.4.weight"):
+            pol.views[k].copy_(1 + 0.3 * torch.randn(pol.views[k].shape, generator=g))
+        pol.views["head.weight"].mul_(20.0)
+    rng = np.random.RandomState(5)
+    obs = rng.rand(n, 6).astype(np.float32)
+    act = rng.randint(0, 5, n).astype(np.int32)
+    lp = (np.log(0.2) + 0.3 * rng.randn(n)).astype(np.float32)
+    vo = rng.randn(n).astype(np.float32)
+    expo = {"growing": np.linspace(-20, 10, n), "shrinking": np.linspace(10, -20, n),
+            "spiky": np.where(rng.rand(n) < 0.01, 8.0, -12.0)}[pattern]
+    mag = (10.0 ** expo).astype(np.float32)
+    adv = (rng.randn(n) * mag).astype(np.float32)
+    ret = (vo + rng.randn(n) * mag).astype(np.float32)          # value-loss gradients of the same spread
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    leaf = {k: v.detach().cpu().double().requires_grad_(True) for k, v in pol.named_views().items()}
+    probs, value, _ = po.mlp_forward(leaf, torch.from_numpy(obs).double())
+    total, _, _, _ = po.ppo_losses(probs, value, torch.from_numpy(act), torch.from_numpy(lp).double(), torch.from_numpy(adv).double(),
+                                   torch.from_numpy(ret).double(), torch.from_numpy(vo).double())
+    total.backward()
+    errs = {}
+    for mode in ("fp16x3", "f32_mfma"):
+        with ops.lstm_arith(mode):
+            sums = torch.zeros(4, dtype=torch.float64, device=DEV)
+            ops.mlp_ppo_grad(pol.flat, d(obs), d(act), d(lp), d(adv), d(ret), d(vo), 1.0 / n, 0.2, 0.01, sums, pol.grad)
+            got = {k: v.detach().cpu().double().clone() for k, v in pol.named_grads().items()}
+        assert all(torch.isfinite(v).all() for v in got.values()), mode
+        errs[mode] = {k: ((got[k] - leaf[k].grad).abs().max() / (leaf[k].grad.abs().max() + 1e-300)).item() for k in leaf}
+    for k in leaf:
+        assert errs["fp16x3"][k] < 2e-5, (pattern, k, errs["fp16x3"][k])
+        assert errs["fp16x3"][k] <= 2.0 * errs["f32_mfma"][k] + 3e-7, (pattern, k, errs["fp16x3"][k], errs["f32_mfma"][k])
+
+
 @pytest.mark.parametrize("N,T", [(5, 40), (37, 70)])
 def test_fused_mlp_rollout_matches_oracle_simulation(N, T):
     """uav_rollout policy_kind 0 (the reference's policy, train_ppo2.0.py:157-198 for N envs) vs a step-by-step oracle
