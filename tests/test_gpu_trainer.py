@@ -689,7 +689,9 @@ def test_fused_mlp_split_gradient_over_a_wide_dynamic_range(pattern):
             "spiky": np.where(rng.rand(n) < 0.01, 8.0, -12.0)}[pattern]
     mag = (10.0 ** expo).astype(np.float32)
     adv = (rng.randn(n) * mag).astype(np.float32)
-    ret = (vo + rng.randn(n) * mag).astype(np.float32)          # value-loss gradients of the same spread
+    # value-loss gradients of the same spread on the small side; capped at 1e2, because for |ret| >> |V| the two branches of
+    # max((V - R)^2, (Vclip - R)^2) TIE in f32 and not in f64 -- a property of the f32 loss, not of the kernels
+    ret = (vo + rng.randn(n) * np.minimum(mag, 1e2)).astype(np.float32)
     d = lambda a: torch.from_numpy(a).to(DEV)
     leaf = {k: v.detach().cpu().double().requires_grad_(True) for k, v in pol.named_views().items()}
     probs, value, _ = po.mlp_forward(leaf, torch.from_numpy(obs).double())
