@@ -14,6 +14,7 @@ struct uav_ctx {
     size_t ws_bytes;
     double* pow075;    // device table pow(i, 0.75), i = 0..5000 (env_core.h)
     double* wave;      // device tables sin(0.05 x) | cos(0.07 y), x, y = 0..499 (env_core.h field_at)
+    double* ftab;      // device tables of the table-driven f64 log / cos-sin / exp (env_core.h ft_*)
     int lstm_arith;    // UAV_ARITH_*: how the LSTM sequence kernels evaluate their f32 matrix products (uav_set_lstm_arith)
     unsigned debug;    // UAV_DEBUG_*: A/B switches of the h = 256 step path (uav_set_debug_flags)
     hipStream_t side[3];      // uav_lstm_bwd_stack: one stream per layer below the top (created on first use)

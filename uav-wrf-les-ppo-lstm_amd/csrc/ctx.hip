@@ -49,6 +49,7 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->ws_bytes = ws_bytes;
     c->pow075 = nullptr;
     c->wave = nullptr;
+    c->ftab = nullptr;
     // process-level override of the default arithmetic, read here once (never on a call path)
     c->lstm_arith = getenv("UAV_LSTM_F32_MFMA") ? UAV_ARITH_F32_MFMA : (getenv("UAV_LSTM_BF16X6") ? UAV_ARITH_BF16X6 : UAV_ARITH_FP16X3);
     c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u);
@@ -61,6 +62,7 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
         (void)hipFree(c->ws);
         (void)hipFree(c->pow075);
         (void)hipFree(c->wave);
+        (void)hipFree(c->ftab);
         delete c;
         return 1;
     }
@@ -90,6 +92,7 @@ void uav_destroy(uav_ctx* ctx) {
     (void)hipFree(ctx->ws);
     (void)hipFree(ctx->pow075);
     (void)hipFree(ctx->wave);
+    (void)hipFree(ctx->ftab);
     delete ctx;
 }
 

@@ -19,6 +19,21 @@ int env_init_tables(uav_ctx* ctx) {
     }
     UAV_CHECK_HIP(hipMalloc(&ctx->wave, sizeof(double) * 2 * GRID));
     UAV_CHECK_HIP(hipMemcpy(ctx->wave, wv.data(), sizeof(double) * 2 * GRID, hipMemcpyHostToDevice));
+    // tables of the f64 log / cos-sin / exp of env_core.h (ft_*), host libm
+    std::vector<double> ft(FT_N);
+    for (int i = 0; i < FT_LOG_N; ++i) ft[FT_LOG + i] = log1p((double)i / FT_LOG_N);
+    for (int i = 0; i < FT_CS_N; ++i) {
+        const double a = 6.283185307179586477 * (double)i / FT_CS_N;
+        ft[FT_CS + 2 * i] = cos(a);
+        ft[FT_CS + 2 * i + 1] = sin(a);
+    }
+    ft[FT_CS] = 1.0; ft[FT_CS + 1] = 0.0;                                       // exact at the quarter turns
+    ft[FT_CS + 2 * (FT_CS_N / 4)] = 0.0; ft[FT_CS + 2 * (FT_CS_N / 4) + 1] = 1.0;
+    ft[FT_CS + 2 * (FT_CS_N / 2)] = -1.0; ft[FT_CS + 2 * (FT_CS_N / 2) + 1] = 0.0;
+    ft[FT_CS + 2 * (3 * FT_CS_N / 4)] = 0.0; ft[FT_CS + 2 * (3 * FT_CS_N / 4) + 1] = -1.0;
+    for (int j = 0; j < FT_EXP_N; ++j) ft[FT_EXP + j] = exp2((double)j / FT_EXP_N);
+    UAV_CHECK_HIP(hipMalloc(&ctx->ftab, sizeof(double) * FT_N));
+    UAV_CHECK_HIP(hipMemcpy(ctx->ftab, ft.data(), sizeof(double) * FT_N, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -50,6 +65,9 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
     P.bank_src = cfg->bank_src;
     P.pow075 = ctx->pow075;
     P.wave = ctx->wave;
+    P.pow_near = nullptr;
+    P.pow_near_n = 0;
+    P.ftab = ctx->ftab;
     return 0;
 }
 

@@ -25,7 +25,72 @@ struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived c
     const double* bank_src;   // [F][2]
     const double* pow075;     // [POW_TABLE_N] host-libm pow(i, 0.75)
     const double* wave;       // [2][GRID] host-libm sin(0.05 x) | cos(0.07 y) of environment.py:58
+    const double* pow_near;   // optional copy of pow075[0 .. pow_near_n) in faster memory (the fused rollouts' LDS), else NULL
+    int pow_near_n;
+    const double* ftab;       // [FT_N] host-libm tables of the f64 log / cos-sin / exp below (global, or the rollouts' LDS copy)
 };
+
+// ---- f64 log, cos/sin and exp for the procedural field and the Box-Muller normals, table-driven.  The arguments are not
+// arbitrary doubles: log is needed of a 24-bit integer, cos/sin of a 24-bit fraction of a turn, exp of -d^2 / 2 sigma^2 in
+// [-300, 0].  A table entry (host libm, correctly rounded) + a few polynomial terms of a remainder below 2^-12 / 2 pi / 1024 /
+// ln 2 / 128 gives the value to ~3e-16 -- libm accuracy, the oracle's numpy calls agree to 1e-15 -- in a third of the
+// instructions of the general-purpose routines, which sat on the chain of the wave that paces the fused rollouts.
+constexpr int FT_LOG = 0, FT_LOG_N = 4096;            // log(1 + i / 4096)
+constexpr int FT_CS = FT_LOG + FT_LOG_N, FT_CS_N = 1024;   // cos, sin (2 pi i / 1024), interleaved
+constexpr int FT_EXP = FT_CS + 2 * FT_CS_N, FT_EXP_N = 64;   // 2^(j / 64)
+constexpr int FT_N = FT_EXP + FT_EXP_N;
+
+__device__ __forceinline__ double ft_rcp(double x) {   // 1 / x to f64 accuracy for normal x: hardware seed + two Newton steps
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+}
+// -ln(k / 2^24) for an integer 1 <= k <= 2^24 (= -ln u1 of the Box-Muller radius).  Near u1 = 1 the difference of two logs
+// would cancel (absolute error 2e-15 against a value of 6e-8): there, k > 2^24 - 4096, the series of -log1p(-t), t < 2^-12.
+__device__ __forceinline__ double ft_neglog_u24(uint32_t k, const double* __restrict__ ft) {
+    const int e = 31 - __builtin_clz(k);
+    const uint32_t m = k << (24 - e);                  // [2^24, 2^25): k = 2^(e - 24) m
+    const uint32_t i = (m >> 12) & 0xfffu, lo = m & 0xfffu;
+    const double d = (double)lo * ft_rcp((double)(m - lo));      // k = 2^e (1 + i / 4096)(1 + d), d < 2^-12
+    const double l1p = d * (1.0 - d * (0.5 - d * (1.0 / 3.0 - d * 0.25)));
+    const double far = ((double)(24 - e) * 0.6931471805599453094 - ft[FT_LOG + i]) - l1p;
+    const double t = (double)(16777216u - k) * (1.0 / 16777216.0);
+    const double near = t * (1.0 + t * (0.5 + t * (1.0 / 3.0 + t * 0.25)));
+    return (16777216u - k) < 4096u ? near : far;
+}
+// cos and sin of 2 pi m / 2^24 for a 24-bit m
+__device__ __forceinline__ void ft_sincos_u24(uint32_t m, const double* __restrict__ ft, double& sn, double& cs) {
+    const uint32_t idx = m >> 14, rem = m & 0x3fffu;
+    const double C = ft[FT_CS + 2 * idx], S = ft[FT_CS + 2 * idx + 1];
+    const double d = (double)rem * (6.283185307179586477 / 16777216.0), d2 = d * d;
+    const double cd = 1.0 - d2 * (0.5 - d2 * (1.0 / 24.0 - d2 * (1.0 / 720.0)));
+    const double sd = d * (1.0 - d2 * (1.0 / 6.0 - d2 * (1.0 / 120.0)));
+    cs = C * cd - S * sd;
+    sn = S * cd + C * sd;
+}
+// exp(x) for -700 < x <= 0
+__device__ __forceinline__ double ft_exp_neg(double x, const double* __restrict__ ft) {
+    const double n = rint(x * 92.332482616893656877);                          // 64 / ln 2
+    const double r = (x - n * 0.010830424695996044) - n * 2.5310172166650877e-13;       // ln 2 / 64 = hi (35 bits: n hi is exact) + lo
+    const int ni = (int)n;
+    const double p = 1.0 + r * (1.0 + r * (0.5 + r * (1.0 / 6.0 + r * (1.0 / 24.0 + r * (1.0 / 120.0)))));
+    return __builtin_amdgcn_ldexp(ft[FT_EXP + (ni & 63)] * p, ni >> 6);
+}
+
+// The two small tables an env step reads AFTER its action is known -- pow(visit count, 0.75) and the ripple factors of the
+// cell -- copied into LDS by the fused rollout kernels: from L2 each was a dependent ~700-cycle load on the chain of the
+// wave that paces the step.
+constexpr int ENV_POW_NEAR = 1024;                    // covers every visit count of a 1000-step episode
+constexpr int ENV_LDS_TABLE_DOUBLES = ENV_POW_NEAR + 2 * 500 + FT_N;
+__device__ __forceinline__ void env_tables_to_lds(EnvParams& P, double* tab, int tid, int nthreads) {
+    for (int i = tid; i < ENV_POW_NEAR; i += nthreads) tab[i] = P.pow075[i];
+    for (int i = tid; i < 2 * 500; i += nthreads) tab[ENV_POW_NEAR + i] = P.wave[i];
+    for (int i = tid; i < FT_N; i += nthreads) tab[ENV_POW_NEAR + 2 * 500 + i] = P.ftab[i];
+    P.pow_near = tab;
+    P.pow_near_n = ENV_POW_NEAR;
+    P.wave = tab + ENV_POW_NEAR;
+    P.ftab = tab + ENV_POW_NEAR + 2 * 500;
+}
 
 struct EnvState {             // registers of one env
     float px, py;             // agent_pos (f32 after the first step; (0,0) at reset)
@@ -81,15 +146,13 @@ constexpr int POW_TABLE_N = 5001;      // table pointer travels in EnvParams (ow
 // two standard normals from one Philox block: Box-Muller in f64 on 24-bit uniforms, u1 in (0,1], u2 in [0,1):
 // z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = ... sin(2 pi u2).  oracle/procedural_oracle.py restates exactly this from the
 // same draws (numpy f64), so the procedural mode is pinned to libm accuracy (1e-15), not statistically.
-__device__ __forceinline__ double bm_radius(uint32_t a) {
-    const double u1 = ((double)(a >> 8) + 1.0) * (1.0 / 16777216.0);      // (0,1]
-    return sqrt(-2.0 * log(u1));
+__device__ __forceinline__ double bm_radius(uint32_t a, const double* __restrict__ ft) {
+    return sqrt(2.0 * ft_neglog_u24((a >> 8) + 1u, ft));          // u1 = k / 2^24 in (0,1], k = (a >> 8) + 1
 }
-__device__ __forceinline__ void normal2(const Philox4& r, double& z0, double& z1) {
-    const double rad = bm_radius(r.x);
-    const double u2 = (double)(r.y >> 8) * (1.0 / 16777216.0);            // [0,1)
+__device__ __forceinline__ void normal2(const Philox4& r, const double* __restrict__ ft, double& z0, double& z1) {
+    const double rad = bm_radius(r.x, ft);
     double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
+    ft_sincos_u24(r.y >> 8, ft, sn, cs);                                  // u2 = (r.y >> 8) / 2^24 in [0,1)
     z0 = rad * cs;
     z1 = rad * sn;
 }
@@ -107,13 +170,15 @@ __device__ __forceinline__ void field_at(const EnvParams& P, int env_global, con
     // procedural: |N(0,1)| and U[0,1) of this (env, episode, cell) from the counter RNG, then the reference's formula in
     // f64 with its own operation order (environment.py:52-61); sin(0.05 x), cos(0.07 y) from the host-libm tables
     const Philox4 r = philox4x32_10(P.seed, (uint32_t)(x * GRID + y), (uint32_t)env_global, (uint32_t)s.episode, RNG_FIELD);
-    const double g = bm_radius(r.x) * cospi(2.0 * ((double)(r.y >> 8) * (1.0 / 16777216.0)));
+    double gs, gc;
+    ft_sincos_u24(r.y >> 8, P.ftab, gs, gc);
+    const double g = bm_radius(r.x, P.ftab) * gc;
     const double u = (double)r.w * (1.0 / 4294967296.0);
     const double wave = (0.3 * P.wave[x]) * P.wave[GRID + y];
     tke = 3.0 * ((fabs(g) + wave) + 0.2 * u);                                       // :56-60
     const double dx = (double)x - s.sx, dy = (double)y - s.sy;
     const double dist = sqrt(dx * dx + dy * dy);                                    // :53
-    const double base = 100.0 * exp(-(dist * dist) / P.two_sigma2);                 // :54 (V2.1 :56)
+    const double base = 100.0 * ft_exp_neg(-(dist * dist) / P.two_sigma2, P.ftab);  // :54 (V2.1 :56)
     const double c = base + tke;
     conc = c < 0.0 ? 0.0 : (c > 100.0 ? 100.0 : c);                                  // :61
 }
@@ -221,7 +286,7 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
     vis[vi] = (unsigned short)vc;                                     // :129-130
 
     env_obs(P, s, vis, out.obs);                                      // :133,136 (f32-position cell)
-    const double den = P.pow075[vc < POW_TABLE_N ? vc : POW_TABLE_N - 1] + 1.0;
+    const double den = (vc < P.pow_near_n ? P.pow_near[vc] : P.pow075[vc < POW_TABLE_N ? vc : POW_TABLE_N - 1]) + 1.0;
     const float conc_r = 2.0f * out.obs[2];                           // f32, :140
     const float tke_p = 0.4f * out.obs[3];                            // f32, :143
     double explore, total;
@@ -252,5 +317,5 @@ __device__ __forceinline__ void env_step_core(const EnvParams& P, int env_global
 // noise of (env, episode, step) from the counter RNG
 __device__ __forceinline__ void env_step_noise(const EnvParams& P, int env_global, const EnvState& s, double& z0, double& z1) {
     const Philox4 r = philox4x32_10(P.seed, (uint32_t)s.steps, (uint32_t)env_global, (uint32_t)s.episode, RNG_STEP);
-    normal2(r, z0, z1);
+    normal2(r, P.ftab, z0, z1);
 }

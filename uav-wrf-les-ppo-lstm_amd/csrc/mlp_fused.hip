@@ -469,13 +469,16 @@ constexpr size_t ROLL_LDS = (size_t)(Tiles<1>::FLOATS + 16 * WS2) * sizeof(float
 // H3: the 256 x 128 layer on the fp16 matrix pipe (layer2_h3) -- the update kernel of the same arithmetic runs the same
 // code, so the rollout's log-probabilities stay bit-identical to the update's first forward pass.
 template <bool H3>
-__global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P, EnvBlob blob, int N, int T, uint64_t iter,
+__global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P_arg, EnvBlob blob, int N, int T, uint64_t iter,
                                                             const float* __restrict__ params, MlpRollBufs B) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Tiles<1> L(smem);
     float* W2i = smem + Tiles<1>::FLOATS;                        // [16][WS2] rows 0..15 of W2: wave 0 (the env role) keeps no weight VGPRs
     __shared__ unsigned short vis[MT * NVIS];
     __shared__ EnvState es_s[MT];
+    __shared__ double env_tab[ENV_LDS_TABLE_DOUBLES];            // pow(vc, 0.75) | ripple factors (env_core.h)
+    EnvParams P = P_arg;
+    env_tables_to_lds(P, env_tab, threadIdx.x, 512);
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

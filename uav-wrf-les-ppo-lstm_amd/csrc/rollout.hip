@@ -79,7 +79,7 @@ struct RolloutBufs {
 // register file to itself; the two roles run separate, barrier-matched time loops, which keeps the other waves' 128
 // weight VGPRs out of wave 0's live set.
 template <int H, int NA>
-__global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlob blob, int N, int T,
+__global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P_arg, EnvBlob blob, int N, int T,
                                                                         uint64_t iter, const float* __restrict__ params,
                                                                         RolloutBufs B) {
     using G = RGeom<H>;
@@ -98,6 +98,9 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P, EnvBlo
     __shared__ EnvState es_s[RMT];
     __shared__ float trs[4 * RMT * 8];                            // the step's transition, parked by wave 0, stored by the last gate wave
     __shared__ __attribute__((aligned(16))) f32x4 acc0[4 * 64];  // wave 0's next-step accumulators, computed by the gate waves
+    __shared__ double env_tab[ENV_LDS_TABLE_DOUBLES];            // pow(vc, 0.75) | ripple factors (env_core.h)
+    EnvParams P = P_arg;
+    env_tables_to_lds(P, env_tab, threadIdx.x, H * 4);
 
     const float* w_ih = params;
     const float* w_hh = w_ih + 4 * H * I;
