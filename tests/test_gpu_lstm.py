@@ -497,3 +497,35 @@ def test_lstm_bwd_stack_three_layers_equals_per_layer_calls(ops):
         assert torch.equal(s["dgates"], ref_dg[l]), l
         if l > 0:
             assert torch.equal(s["dx"], ref_dx[l]), l
+
+
+def test_lstm_bwd_stack_rejects_a_bad_layer_before_queueing_work(ops):
+    """A layer that feeds the one below without w_ih / dx is an argument error: uav_lstm_bwd_stack must return it BEFORE forking
+    its side streams (all layers are validated first), leave nothing queued, and the next valid call must give the same bits
+    as a fresh one.  Also: the debug-flag setter refuses unknown bits."""
+    H, N, T = 256, 32, 5
+    g = torch.Generator().manual_seed(3)
+    mk = lambda *shape: (torch.randn(*shape, generator=g) * 0.1).to(DEV)
+    x = mk(N, T, H)
+    W = [(mk(4 * H, H), mk(4 * H, H), mk(4 * H), mk(4 * H)) for _ in range(2)]
+    y0, _, _, st0 = ops.lstm_fwd(x, None, mk(N, H), mk(N, H), *W[0])
+    y1, _, _, st1 = ops.lstm_fwd(y0, None, mk(N, H), mk(N, H), *W[1])
+    dy = (torch.randn(N, T, H, generator=g) * 1e-4).to(DEV)
+
+    def specs(bad):
+        return [{"stash": st1, "w_hh": W[1][1], "w_ih": None if bad else W[1][0], "dgates": torch.zeros(N, T, 4 * H, device=DEV),
+                 "dx": None if bad else torch.zeros(N, T, H, device=DEV)},
+                {"stash": st0, "w_hh": W[0][1], "w_ih": None, "dgates": torch.zeros(N, T, 4 * H, device=DEV), "dx": None}]
+    good = specs(False)
+    ops.lstm_bwd_stack(good, None, dy=dy)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="w_ih and dx are required"):
+        ops.lstm_bwd_stack(specs(True), None, dy=dy)
+    again = specs(False)
+    ops.lstm_bwd_stack(again, None, dy=dy)
+    torch.cuda.synchronize()
+    for a, b in zip(good, again):
+        assert torch.equal(a["dgates"], b["dgates"])
+    from uavppo import _lib
+    assert _lib.lib().uav_set_debug_flags(ops.Context.get(DEV).handle, 64) != 0
+    ops.set_debug_flags()
