@@ -241,7 +241,9 @@ int uav_mlp_bwd(uav_ctx* ctx, const float* params, const float* x, float* stash,
  * (default): the 256 x 128 layer and its transpose product da1 = W2^T dz2 as three fp16 piece products per f32 product
  * (f32 results; dz2 block-scaled per sample by a power of two); needs max |param| < 2048, so that W2 and the layer's input
  * a1 <= sqrt(255) |g1| + |be1| stay inside fp16's range.  Any other mode: every product on exact-f32 MFMA, no range
- * limit.  The Python trainer measures max |param| (uav_clip_adam's pmax_out) and switches by itself. */
+ * limit.  The Python trainer measures max |param| (uav_clip_adam's pmax_out) and switches by itself.  Keep ONE mode between
+ * a uav_rollout(policy_kind 0) and the uav_mlp_ppo_grad calls that consume its log-probabilities: both run the same forward
+ * code in the same arithmetic, which is what makes the first epoch's probability ratio exactly 1. */
 int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* obs, const int32_t* act, const float* logp_old,
                      const float* adv, const float* ret, const float* val_old, int64_t n, int in_dim, int h1, int h2,
                      int n_act, float inv_n, float clip, float ent_beta, double* loss_sums, float* grad,
