@@ -23,6 +23,8 @@ def main():
         N = 1024
         tr = VecPPOTrainer(N, T, "lstm", hidden=256, layers=2, trend_k=2, variant="v2.1", device="cuda:0", seed=1, lr=lr,
                            num_minibatches=mb, use_curriculum=True)
+    elif len(sys.argv) > 4 and sys.argv[4] == "mlp":      # the reference's own policy through the fused MLP kernels
+        tr = VecPPOTrainer(N, T, "mlp", device="cuda:0", seed=1, lr=lr, num_minibatches=mb, use_curriculum=True)
     else:
         tr = VecPPOTrainer(N, T, "lstm", hidden=128, device="cuda:0", seed=1, lr=lr, num_minibatches=mb, use_curriculum=True)
     t0 = time.perf_counter()
