@@ -62,6 +62,44 @@ def test_methane_env_procedural_fields_consistent():
     assert env.conc_field[int(sx), int(sy)] > 90          # Gaussian peak at the source
 
 
+def test_methane_env_procedural_equals_oracle():
+    """The reference-shaped single environment (MethaneEnv().reset() / .step(a) -> obs, reward, done, info) in its default,
+    procedural mode against oracle/procedural_oracle.py with the same seed: observations bit for bit, rewards and the five
+    info parts to 1e-6, done flags, source position, and the whole conc_field / tke_field the training script reads
+    (train_ppo2.0.py:170-173,203), across episode ends and an explicit mid-episode reset()."""
+    from environment import MethaneEnv
+    from oracle import procedural_oracle as pr
+    seed = 987654
+    env = MethaneEnv("v2.0", seed=seed)
+    ora = pr.ProceduralVecEnv(1, seed, "v2.0")
+    ora.reset()
+    # MethaneEnv() resets once in its constructor (environment.py:39) and the script resets again before the first step
+    # (train_ppo2.0.py:139): as in the reference, the second reset starts a NEW episode (here: the counter RNG's episode 1)
+    ora.episode[0] += 1
+    assert np.array_equal(env.reset(), ora._begin(0))
+    env.current_radius = 220.0
+    ora.set_curriculum(220.0, 0.6)
+    rng = np.random.RandomState(0)
+    ended = 0
+    keys = ("concentration_reward", "explore_reward", "move_penalty", "tke_penalty", "boundary_penalty")
+    for t in range(240):
+        a = int(rng.choice([1, 3])) if t % 5 else int(rng.randint(0, 5))
+        o_ref, r_ref, d_ref, s_ref, info_ref, term_ref = ora.step(np.array([a]))
+        o, r, d, info = env.step(a)
+        assert np.array_equal(o, term_ref[0]), t
+        assert abs(r - r_ref[0]) <= 1e-6 and d == bool(d_ref[0]), t
+        assert np.allclose([info[k] for k in keys], info_ref[0], rtol=0, atol=1e-6), t
+        if d:
+            ended += 1
+            assert np.array_equal(env.reset(), o_ref[0]), t           # the auto-started next episode
+            src = ora.envs[0].source
+            assert np.array_equal(env.source_pos, src)
+            if ended == 1:                                                # the table the script indexes: cell for cell
+                want_src, conc, tke = pr.full_field(seed, 0, int(ora.episode[0]), 500 / 16)
+                assert np.abs(env.conc_field - conc).max() <= 1e-11 and np.abs(env.tke_field - tke).max() <= 1e-11
+    assert ended >= 2
+
+
 def test_actor_critic_module_surface(golden):
     from model import PPOActorCritic
     g = golden("policy_update.npz")
