@@ -711,6 +711,35 @@ def test_fused_mlp_split_gradient_over_a_wide_dynamic_range(pattern):
         assert errs["fp16x3"][k] <= 2.0 * errs["f32_mfma"][k] + 3e-7, (pattern, k, errs["fp16x3"][k], errs["f32_mfma"][k])
 
 
+def test_fused_mlp_split_kernels_at_the_edge_of_their_operand_range():
+    """include/uavppo.h: the fp16-split form of uav_mlp_ppo_grad needs max |param| < 2048 (a1 <= sqrt(255) |g1| + |be1| < 65504).
+    With a LayerNorm-1 gain of 2000 and a weight of W2 at 2000 -- just inside -- it must still agree with the exact-f32 form
+    of the same kernel (the trainer's guard switches at half the limit; the kernel's own limit is what is checked here)."""
+    from uavppo import ops
+    from uavppo.policy import MLPActorCritic
+    n = 2048
+    pol = MLPActorCritic(6, 5, device=DEV, seed=4)
+    with torch.no_grad():
+        pol.views["feature.1.weight"][11] = 2000.0
+        pol.views["feature.1.weight"][200] = -1500.0
+        pol.views["feature.3.weight"][5, 9] = 2000.0
+    rng = np.random.RandomState(9)
+    d = lambda a: torch.from_numpy(a).to(DEV)
+    obs, act = rng.rand(n, 6).astype(np.float32), rng.randint(0, 5, n).astype(np.int32)
+    adv, ret, vo = (rng.randn(n).astype(np.float32) for _ in range(3))
+    lp = (np.log(0.2) + 0.3 * rng.randn(n)).astype(np.float32)
+    out = {}
+    for mode in ("fp16x3", "f32_mfma"):
+        with ops.lstm_arith(mode):
+            sums = torch.zeros(4, dtype=torch.float64, device=DEV)
+            ops.mlp_ppo_grad(pol.flat, d(obs), d(act), d(lp), d(adv), d(ret), d(vo), 1.0 / n, 0.2, 0.01, sums, pol.grad)
+            out[mode] = (pol.grad.clone(), sums.clone())
+    g3, gf = out["fp16x3"][0].double(), out["f32_mfma"][0].double()
+    assert torch.isfinite(g3).all() and torch.isfinite(gf).all()
+    assert ((g3 - gf).norm() / gf.norm()).item() < 2e-5
+    assert torch.allclose(out["fp16x3"][1], out["f32_mfma"][1], rtol=1e-5, atol=1e-9)
+
+
 @pytest.mark.parametrize("N,T", [(5, 40), (37, 70)])
 def test_fused_mlp_rollout_matches_oracle_simulation(N, T):
     """uav_rollout policy_kind 0 (the reference's policy, train_ppo2.0.py:157-198 for N envs) vs a step-by-step oracle
