@@ -311,7 +311,8 @@ int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* lay
  * Range note: the default kernels of uav_lstm_fwd / _bwd / _wgrad / uav_rollout evaluate their matrix products as fp16
  * piece products at f32 accuracy (csrc/common.h, split2h); they assume |w| < 65504 for the recurrent and head weights and,
  * in the I <= 6 weight-gradient kernel, |x| < 4096 and |h0| < 64 (observations and hidden states are O(1)).  UAV_ARITH_BF16X6 (uav_set_lstm_arith) selects bf16 piece products
- * (f32's exponent range, twice the matrix work), UAV_LSTM_F32_MFMA=1 the exact-f32 MFMA kernels. */
+ * (f32's exponent range, twice the matrix work), UAV_ARITH_F32_MFMA the exact-f32 MFMA kernels; at H = 256 both take the
+ * generic exact-f32 step path (the fp16-split step kernels have no wide-range twin). */
 int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* y,
                    const float* stash, const float* dgates, const float* w_ih, const float* dheads,
                    int n_heads, int N, int T, int I, int H, float* dw_ih, float* dw_hh, float* db,
