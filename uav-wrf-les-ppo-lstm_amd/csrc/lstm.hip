@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_x6k_kernel(
             "s_mov_b32 m0, %0"
             : "=&s"(m0save)
             : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(ring_base)
-            : "memory");
+            : "memory", "scc");
     };
     // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)].
     // The lane's element of step 0 and its per-step stride are fixed: only `+ t * stride` is left in the loop
@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_h3k_kernel(
             "s_mov_b32 m0, %0"
             : "=&s"(m0save)
             : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(ring_base)
-            : "memory");
+            : "memory", "scc");
     };
     // waves 0 / 1: one 256-B piece each of the step's small image  [dheads(16 envs x NH, env-major) | keep(16)].
     // The lane's element of step 0 and its per-step stride are fixed: only `+ t * stride` is left in the loop
