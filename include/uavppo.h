@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 4   /* 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 5   /* 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -380,6 +380,20 @@ int uav_rollout(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg
                 float* val, float* logp, float* done, uint8_t* flags, float* keep, float* last_val,
                 const int32_t* forced_act, const double* noise, int32_t* nan_count,
                 float* stash, float* y_out, float* info, float* heads, uav_stream stream);
+
+/* The tail of step t of a step-wise rollout as ONE launch (train_ppo2.0.py:165-198 after the recurrent layers): policy heads of
+ * the top layer (heads[:, t] = y_t W_head^T + b_head, the sums of uav_gemm_f32's few-column kernel bit for bit; y = row t of a
+ * [n][T][hidden] array given as the pointer to y[0][t] and its row stride y_stride floats, likewise heads / heads_stride),
+ * uav_policy_sample_at's draw (same key: seed, counter = iteration << 32 | t, index_offset + env), uav_env_step's step with
+ * auto-reset (cfg, noise [n][2] or NULL, as there), uav_store_transition's columns (keep [n] in / out), and the observation
+ * step t + 1 starts from: cur_obs [n][obs_dim] and, while t + 1 < T, obs_seq[:, t + 1] of the [n][T][obs_dim] array.
+ * Replaces five launches that all sit on the step's dependency chain; results identical to calling them one by one. */
+int uav_rollout_tail(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg /*host*/, const float* y, int64_t y_stride,
+                     int hidden, const float* w_head, const float* b_head, int n_act, float* heads, int64_t heads_stride, int T,
+                     int t, uint64_t seed, uint64_t counter, int64_t index_offset, const int32_t* forced_act, const double* noise,
+                     int32_t* act_out, float* cur_obs, float* obs_seq, float* keep, int32_t* act_buf, float* val_buf,
+                     float* logp_buf, float* keep_buf, float* rew_buf, float* done_buf, uint8_t* flags_buf, int32_t* nan_count,
+                     uav_stream stream);
 
 #ifdef __cplusplus
 }

@@ -448,6 +448,32 @@ def test_stepper_rollout_equals_per_call_rollout_and_is_adopted():
         assert torch.equal(a.policy.flat, b.policy.flat), it
 
 
+def test_fused_rollout_tail_equals_the_five_launches():
+    """uav_rollout_tail (heads + action draw + env step + PPOBuffer.store + next observation of a step as ONE launch) against
+    the five launches it replaces (uav_gemm_f32's few-column kernel, uav_policy_sample_at, uav_env_step, uav_store_transition,
+    the observation copy): every buffer, the heads, the carried state and the env blobs BIT-identical -- free-running, with
+    injected step noise, and with forced actions; episodes end and restart inside the horizon (radius 200)."""
+    from uavppo.trainer import VecPPOTrainer
+    mk = lambda: VecPPOTrainer(70, 12, "lstm", hidden=256, layers=2, variant="v2.1", device=DEV, seed=11, trend_k=2, epochs=1,
+                               use_curriculum=False)
+    a, b = mk(), mk()
+    a.radius = b.radius = 200.0
+    assert a.use_fused_tail
+    b.use_fused_tail = False
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for it, (fa, nz) in enumerate(((None, None), (None, torch.randn(70, 12, 2, generator=g, dtype=torch.float64).to(DEV)),
+                                   (torch.randint(0, 5, (70, 12), generator=g, dtype=torch.int32).to(DEV), None), (None, None))):
+        a.collect(forced_act=fa, noise=nz); b.collect(forced_act=fa, noise=nz)
+        for k in ("obs", "act", "rew", "val", "logp", "done", "keep", "flags"):
+            assert torch.equal(a.buf[k], b.buf[k]), (it, k)
+        assert torch.equal(a.work["heads"], b.work["heads"]), it
+        assert torch.equal(a.cur_obs, b.cur_obs) and torch.equal(a.h, b.h) and torch.equal(a.c, b.c), it
+        assert torch.equal(a.env_state, b.env_state), it
+        assert a.buf["done"].sum() > 0 or it == 0
+        a.iteration += 1; b.iteration += 1
+    assert int(a.nan_count.item()) == int(b.nan_count.item()) == 0
+
+
 def test_pipelined_stack_backward_equals_layer_by_layer():
     """uav_lstm_bwd_stack (the layers' BPTTs pipelined on internal streams, the layer below one step behind the one above)
     runs the kernels of one uav_lstm_bwd per layer: after two iterations (4 optimiser steps) the parameters are BIT-identical."""

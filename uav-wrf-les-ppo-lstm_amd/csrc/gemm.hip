@@ -8,6 +8,7 @@
 // NN / NT / TN one kernel; split-K (grid.z) writes slabs to the context workspace and a second
 // kernel reduces them in a fixed order (deterministic, no float atomics).
 #include "common.h"
+#include "rows_dot_core.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -237,45 +238,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // No MFMA tile pays here (a 64 x 64 tile would compute 58 unused columns and needs split-K + a reduce launch to fill the
 // chip: 18.6 us per call at 4096 x 6 x 256); one WAVE per row instead: lane l holds 4 (or 8) consecutive k of the row and
 // of every W row (registers), NO butterfly sums.  HBM-bound on A for long M (the time-batched heads of uav_lstm_fwd).
-template <int NO, int KQ>     // KQ = float4 chunks per lane (K <= 256 KQ)
+template <int NO, int KQ>     // KQ = float4 chunks per lane (K <= 256 KQ); arithmetic: rows_dot_core.h
 __global__ __launch_bounds__(256) void rows_dot_kernel(int64_t M, int K, const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw, int n_out, float* __restrict__ C,
                                                        int64_t ldc, const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63;
-    float4 wv[NO][KQ];
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) {
-            const int k = 4 * (lane + 64 * q);
-            wv[o][q] = (o < n_out && k < K) ? *reinterpret_cast<const float4*>(W + o * ldw + k) : float4{0.f, 0.f, 0.f, 0.f};
-        }
+    RowsDot<NO, KQ> rd;
+    rd.load_w(W, ldw, n_out, K, lane);
     const float bv = (bias && lane < n_out) ? bias[lane] : 0.f;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
     // four rows per trip: their loads are in flight together (a long M is a stream from HBM, one row per trip would run
     // at the memory latency)
     for (int64_t m0 = wave * 4; m0 < M; m0 += nwave * 4) {
-        float4 av[4][KQ];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-                const int k = 4 * (lane + 64 * q);
-                av[r][q] = (m0 + r < M && k < K) ? *reinterpret_cast<const float4*>(A + (m0 + r) * lda + k) : float4{0.f, 0.f, 0.f, 0.f};
-            }
+        float out[4][NO];
+        rd.rows4(A, lda, m0, M, K, lane, out);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float mine = 0.f;
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                float p = 0.f;
-#pragma unroll
-                for (int q = 0; q < KQ; ++q)
-                    p += (av[r][q].x * wv[o][q].x + av[r][q].y * wv[o][q].y) + (av[r][q].z * wv[o][q].z + av[r][q].w * wv[o][q].w);
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) p += __shfl_xor(p, d, 64);
-                if (lane == o) mine = p;
-            }
+            for (int o = 0; o < NO; ++o)
+                if (lane == o) mine = out[r][o];
             if (m0 + r < M && lane < n_out) C[(m0 + r) * ldc + lane] = mine + bv;
         }
     }

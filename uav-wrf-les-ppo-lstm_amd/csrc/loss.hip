@@ -182,42 +182,13 @@ __global__ __launch_bounds__(256) void policy_sample_kernel(
     float z[A], p[A];
 #pragma unroll
     for (int k = 0; k < A; ++k) z[k] = logits[i * stride + k];
-    softmax_row<A>(z, p);
-    float psum = 0.f;
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < A; ++k) {
-        psum += p[k];
-        bad |= (p[k] != p[k]);
-    }
+    bool bad;
+    float qa;
+    const int a = sample_categorical<A>(z, p, u ? &u[i] : nullptr, seed, counter, index_offset + i, forced ? &forced[i] : nullptr, qa, bad);
     if (bad) atomicAdd(nan_count, 1);
-    int a;
-    if (forced) {
-        a = forced[i];
-    } else {
-        float uu;
-        if (u) uu = u[i];
-        else {
-            // the fused rollout's key (rollout.hip): (seed; step-in-rollout, GLOBAL env index, iteration), so a job
-            // draws the same actions however its envs are sharded over ranks and whichever rollout path runs it
-            const Philox4 r = philox4x32_10(seed, (uint32_t)counter, (uint32_t)(index_offset + i), (uint32_t)(counter >> 32), RNG_ACTION);
-            uu = u01_f32(r.x);
-        }
-        // inverse-CDF draw over the normalised probabilities (torch.multinomial semantics)
-        float cdf = 0.f;
-        a = A - 1;
-        const float target = uu * psum;
+    if (probs_out) {
 #pragma unroll
-        for (int k = 0; k < A; ++k) {
-            cdf += p[k];
-            if (target < cdf) { a = k; break; }
-        }
-    }
-    float qa = 0.f;
-#pragma unroll
-    for (int k = 0; k < A; ++k) {
-        if (probs_out) probs_out[i * A + k] = p[k];
-        if (k == a) qa = p[k] / psum;
+        for (int k = 0; k < A; ++k) probs_out[i * A + k] = p[k];
     }
     act_out[i] = a;
     const float lp = logf(fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS));

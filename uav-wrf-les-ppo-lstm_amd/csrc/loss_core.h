@@ -2,6 +2,7 @@
 // loss kernels (loss.hip) and the fused MLP update (mlp_fused.hip), so every path rounds alike.
 #pragma once
 #include "common.h"
+#include "philox.h"
 
 constexpr float F32_EPS = 1.1920928955078125e-07f;
 
@@ -18,6 +19,47 @@ __device__ __forceinline__ void softmax_row(const float* z, float* p) {
     }
 #pragma unroll
     for (int k = 0; k < A; ++k) p[k] = p[k] / s;
+}
+
+// One Categorical(probs) draw from logits z[A] (train_ppo2.0.py:171-173; torch.multinomial's inverse-CDF semantics over the
+// normalised probabilities): p[] = softmax(z), the action (forced, from a given uniform, or from the counter RNG keyed
+// (seed; step-in-rollout, GLOBAL env index, iteration) like the fused rollout kernels, so a job draws the same actions however
+// its envs are sharded over ranks and whichever rollout path runs it), qa = its normalised probability, bad = a NaN probability.
+template <int A>
+__device__ __forceinline__ int sample_categorical(const float* z, float* p, const float* u, uint64_t seed, uint64_t counter,
+                                                  int64_t env_global, const int32_t* forced, float& qa, bool& bad) {
+    softmax_row<A>(z, p);
+    float psum = 0.f;
+    bad = false;
+#pragma unroll
+    for (int k = 0; k < A; ++k) {
+        psum += p[k];
+        bad |= (p[k] != p[k]);
+    }
+    int a;
+    if (forced) {
+        a = *forced;
+    } else {
+        float uu;
+        if (u) uu = *u;
+        else {
+            const Philox4 r = philox4x32_10(seed, (uint32_t)counter, (uint32_t)env_global, (uint32_t)(counter >> 32), RNG_ACTION);
+            uu = u01_f32(r.x);
+        }
+        float cdf = 0.f;
+        a = A - 1;
+        const float target = uu * psum;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            cdf += p[k];
+            if (target < cdf) { a = k; break; }
+        }
+    }
+    qa = 0.f;
+#pragma unroll
+    for (int k = 0; k < A; ++k)
+        if (k == a) qa = p[k] / psum;
+    return a;
 }
 
 constexpr int LOSS_BLOCKS = 1024;

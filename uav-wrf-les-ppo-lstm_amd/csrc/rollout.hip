@@ -19,6 +19,8 @@
 // Procedural fields make the whole rollout HBM-write-only apart from the policy parameters:
 // 44 B per env-step (obs 24, act 4, rew 4, val 4, logp 4, done 4) + 5 B (keep, flags).
 #include "env_core.h"
+#include "loss_core.h"
+#include "rows_dot_core.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -530,6 +532,121 @@ static int launch_rollout(const EnvParams& P, EnvBlob blob, int N, int T, uint64
     const dim3 grid((N + RMT - 1) / RMT), block(H * 4);
     UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&rollout_lstm_kernel<H, 5>), (int)RGeom<H>::LDS));
     hipLaunchKernelGGL((rollout_lstm_kernel<H, 5>), grid, block, RGeom<H>::LDS, st, P, blob, N, T, iter, params, B);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the tail of ONE step of a step-wise rollout (policies the fused rollout kernels do not cover: stacked layers, h = 256)
+// as one launch: policy heads of the top layer's y_t, action sample, environment step, PPOBuffer.store, next observation into
+// the sequence array -- five launches (rows-dot GEMM 14.3 us, uav_policy_sample_at 4.3, uav_env_step 8.6, uav_store_transition
+// 2.9, a copy 3.4 at 4096 envs, each mostly launch and memory latency) that all sit on the step's dependency chain.
+// A wave takes four envs: the heads as rows_dot_kernel forms them (rows_dot_core.h: the same sums, so heads[:, t] is bit for
+// bit uav_gemm_f32's), then lanes 0..3 each carry one env through uav_policy_sample_at's draw (loss_core.h) and
+// env_step_kernel's body (env_core.h).  4096 envs = 1024 waves = one per SIMD.
+template <int A>
+__global__ __launch_bounds__(256) void rollout_tail_kernel(
+    EnvParams P, EnvBlob b, int n, const float* __restrict__ y, int64_t ldy, int K, const float* __restrict__ w_head,
+    const float* __restrict__ b_head, float* __restrict__ heads, int64_t ldh, int T, int t, uint64_t seed, uint64_t counter,
+    int64_t index_offset, const int32_t* __restrict__ forced, const double* __restrict__ noise, int32_t* __restrict__ act_out,
+    float* __restrict__ cur_obs, float* __restrict__ obs_seq, float* __restrict__ keep, int32_t* __restrict__ act_buf,
+    float* __restrict__ val_buf, float* __restrict__ logp_buf, float* __restrict__ keep_buf, float* __restrict__ rew_buf,
+    float* __restrict__ done_buf, uint8_t* __restrict__ flags_buf, int32_t* __restrict__ nan_count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (m0 >= n) return;
+    RowsDot<8, 1> rd;
+    rd.load_w(w_head, K, A + 1, K, lane);
+    float out[4][8];
+    rd.rows4(y, ldy, m0, n, K, lane, out);
+    float z[A + 1];
+#pragma unroll
+    for (int o = 0; o <= A; ++o) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (lane == r) v = out[r][o];
+        z[o] = v + b_head[o];
+    }
+    const int64_t i64 = m0 + lane;
+    if (lane >= 4 || i64 >= n) return;
+    const int i = (int)i64;
+#pragma unroll
+    for (int o = 0; o <= A; ++o) heads[i64 * ldh + o] = z[o];
+    // ---- uav_policy_sample_at
+    float p[A], qa;
+    bool bad;
+    int a = sample_categorical<A>(z, p, nullptr, seed, counter, index_offset + i, forced ? &forced[i] : nullptr, qa, bad);
+    if (bad) atomicAdd(nan_count, 1);
+    const int64_t col = i64 * T + t;
+    act_out[i] = a;
+    act_buf[col] = a;
+    logp_buf[col] = logf(fminf(fmaxf(qa, F32_EPS), 1.0f - F32_EPS));
+    val_buf[col] = z[A];
+    // ---- uav_env_step (env_step_kernel's body)
+    EnvState s = env_load(b, i);
+    unsigned short* vis = b.visited + (size_t)i * NVIS;
+    const int eg = P.env_offset + i;
+    double z0, z1;
+    if (noise) { z0 = noise[2 * (size_t)i]; z1 = noise[2 * (size_t)i + 1]; }
+    else env_step_noise(P, eg, s, z0, z1);
+    a = a < 0 ? 0 : (a > 4 ? 4 : a);
+    StepOut o;
+    double tx, ty;
+    env_step_wind(s, z0, z1, tx, ty);
+    env_step_core(P, eg, s, vis, a, tx, ty, o);
+    const float d = o.done ? 1.f : 0.f;
+    const uint8_t fl = (uint8_t)((o.done ? 1 : 0) | (o.reached ? 2 : 0));
+    const float rw = (float)o.reward;
+    if (o.done) {                                   // the reset of train_ppo2.0.py:139
+        s.episode += 1;
+        env_begin_episode(P, eg, s, vis);
+        env_obs(P, s, vis, o.obs);
+    }
+    env_store(b, i, s);
+    // ---- uav_store_transition, and the observation step t + 1 starts from
+    keep_buf[col] = keep[i];
+    rew_buf[col] = rw;
+    done_buf[col] = d;
+    flags_buf[col] = fl;
+    keep[i] = 1.0f - d;
+    const int od = 6 + P.trend_k;
+    for (int k = 0; k < od; ++k) {
+        cur_obs[(size_t)i * od + k] = o.obs[k];
+        if (t + 1 < T) obs_seq[((size_t)i * T + t + 1) * od + k] = o.obs[k];
+    }
+}
+
+extern "C" int uav_rollout_tail(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg* cfg, const float* y, int64_t y_stride,
+                                int hidden, const float* w_head, const float* b_head, int n_act, float* heads, int64_t heads_stride,
+                                int T, int t, uint64_t seed, uint64_t counter, int64_t index_offset, const int32_t* forced_act,
+                                const double* noise, int32_t* act_out, float* cur_obs, float* obs_seq, float* keep,
+                                int32_t* act_buf, float* val_buf, float* logp_buf, float* keep_buf, float* rew_buf, float* done_buf,
+                                uint8_t* flags_buf, int32_t* nan_count, uav_stream stream) {
+    UAV_REQUIRE(ctx && env_state && y && w_head && b_head && heads && act_out && cur_obs && obs_seq && keep && act_buf && val_buf &&
+                logp_buf && keep_buf && rew_buf && done_buf && flags_buf && nan_count, "uav_rollout_tail: NULL argument");
+    UAV_REQUIRE(n_env > 0 && T > 0 && t >= 0 && t < T, "uav_rollout_tail: n_env=%d T=%d t=%d", n_env, T, t);
+    UAV_REQUIRE(hidden >= 4 && hidden <= 256 && hidden % 4 == 0 && y_stride % 4 == 0 && y_stride >= hidden &&
+                (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (reinterpret_cast<uintptr_t>(w_head) & 15) == 0,
+                "uav_rollout_tail: hidden %d (a multiple of 4 up to 256), y rows 16-byte aligned", hidden);
+    UAV_REQUIRE(heads_stride > n_act, "uav_rollout_tail: heads_stride=%lld n_act=%d", (long long)heads_stride, n_act);
+    EnvParams P;
+    int rc = env_params_from_cfg(ctx, cfg, n_env, P);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((n_env + 15) / 16));
+#define LAUNCH_T(A_)                                                                                                              \
+    hipLaunchKernelGGL(rollout_tail_kernel<A_>, grid, dim3(256), 0, as_stream(stream), P, env_blob_view(env_state, n_env), n_env, \
+                       y, y_stride, hidden, w_head, b_head, heads, heads_stride, T, t, seed, counter, index_offset, forced_act,   \
+                       noise, act_out, cur_obs, obs_seq, keep, act_buf, val_buf, logp_buf, keep_buf, rew_buf, done_buf,           \
+                       flags_buf, nan_count)
+    switch (n_act) {
+        case 2: LAUNCH_T(2); break;
+        case 3: LAUNCH_T(3); break;
+        case 4: LAUNCH_T(4); break;
+        case 5: LAUNCH_T(5); break;
+        case 6: LAUNCH_T(6); break;
+        default: UAV_REQUIRE(false, "uav_rollout_tail: n_act=%d unsupported (2..6)", n_act);
+    }
+#undef LAUNCH_T
     UAV_LAUNCH_CHECK();
     return 0;
 }

@@ -50,6 +50,7 @@ SIGNATURES = {
     "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, I64, P, P, P, P, P, P]),
     "uav_policy_sample_at": (I32, [P, P, I64, I64, I32, U64, U64, I64, P, P, I32, I32, P, P, P, P, P]),
     "uav_store_transition": (I32, [P, I32, I32, I32, P, P, P, P, P, P, P, P, P]),
+    "uav_rollout_tail": (I32, [P, P, I32, P, P, I64, I32, P, P, I32, P, I64, I32, I32, U64, U64, I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "uav_clip_adam": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, P, P, P]),
     "uav_clip_adamw": (I32, [P, P, P, P, P, I64, I64, F32, F32, F32, F32, F32, F32, P, P]),
     "uav_smooth_l1": (I32, [P, P, P, I64, F32, P, P, P]),

@@ -196,6 +196,31 @@ def store_transition(t, keep, rew, done, flags, keep_buf, rew_buf, done_buf, fla
                                      _p(flags_buf, U8, (N, T), "flags_buf"), _stream()), "uav_store_transition")
 
 
+def rollout_tail(env_state, cfg, y_seq, t, w_head, b_head, heads_seq, act_out, cur_obs, obs_seq, keep, act_buf, val_buf, logp_buf,
+                 keep_buf, rew_buf, done_buf, flags_buf, nan_count, seed=0, iteration=0, index_offset=0, forced_act=None, noise=None):
+    """uav_rollout_tail: everything of rollout step t after the recurrent layers in one launch -- heads_seq[:, t] from
+    y_seq[:, t] ([N, T, H] top-layer output), the action draw, the environment step (auto-reset), PPOBuffer.store's columns
+    (act / val / logp / keep / rew / done / flags [N, T] at t; keep [N] <- 1 - done) and the next observation into cur_obs and
+    obs_seq[:, t + 1].  Identical results to gemm_rows + policy_sample_at + env_step + store_transition + the obs copy."""
+    N, T, H = y_seq.shape
+    A1 = heads_seq.shape[-1]
+    od = cur_obs.shape[-1]
+    check(lib().uav_rollout_tail(_h(y_seq), _p(env_state, U8, name="env state"), N, C.byref(cfg),
+                                 C.c_void_p(_p(y_seq, F32, (N, T, H), "y_seq").value + 4 * int(t) * H), T * H, H,
+                                 _p(w_head, F32, (A1, H), "w_head"), _p(b_head, F32, (A1,), "b_head"), A1 - 1,
+                                 C.c_void_p(_p(heads_seq, F32, (N, T, A1), "heads_seq").value + 4 * int(t) * A1), T * A1, T, int(t),
+                                 int(seed), (int(iteration) << 32) | (int(t) & 0xffffffff), int(index_offset),
+                                 _p(forced_act, I32, (N,), "forced_act"), _p(noise, F64, (N, 2), "noise"),
+                                 _p(act_out, I32, (N,), "act_out"), _p(cur_obs, F32, (N, od), "cur_obs"),
+                                 _p(obs_seq, F32, (N, T, od), "obs_seq"), _p(keep, F32, (N,), "keep"),
+                                 _p(act_buf, I32, (N, T), "act_buf"), _p(val_buf, F32, (N, T), "val_buf"),
+                                 _p(logp_buf, F32, (N, T), "logp_buf"), _p(keep_buf, F32, (N, T), "keep_buf"),
+                                 _p(rew_buf, F32, (N, T), "rew_buf"), _p(done_buf, F32, (N, T), "done_buf"),
+                                 _p(flags_buf, U8, (N, T), "flags_buf"), _p(nan_count, I32, (1,), "nan_count"), _stream()),
+          "uav_rollout_tail")
+    return act_out
+
+
 def ppo_loss_heads(heads, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta, loss_sums, dheads, dhead_bias=None):
     """Packed form of ppo_loss: heads [n, A+1] (logits | value) in, dheads [n, A+1] out -- no split/concat copies."""
     n, A1 = heads.shape

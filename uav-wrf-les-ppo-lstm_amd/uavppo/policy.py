@@ -215,13 +215,18 @@ class LSTMActorCritic(_FlatPolicy):
         """Time step t of all layers on the [N, T, ...] arrays of the update (obs_seq [N, T, I] row t already written;
         work['y{l}'], work['stash{l}'] filled at t); keep [N]: this step's restart mask; heads_seq [N, T, A+1] row t =
         actor / critic rows of the top layer."""
+        x = self.step_layers_at(obs_seq, t, work, keep=keep)
+        v = self.views
+        return ops.gemm_rows(x[:, t], v["head.weight"], v["head.bias"], heads_seq[:, t])
+
+    def step_layers_at(self, obs_seq, t, work, keep=None):
+        """The recurrent layers of step_at only; returns the top layer's [N, T, H] output array (row t filled)."""
         x = obs_seq
         for l, sp in enumerate(self._steppers):
             sp.step(x, t, work[f"y{l}"], work[f"stash{l}"], below=self._steppers[l - 1] if l > 0 and self.hidden == 256 else None,
                     keep=keep)
             x = work[f"y{l}"]
-        v = self.views
-        return ops.gemm_rows(x[:, t], v["head.weight"], v["head.bias"], heads_seq[:, t])
+        return x
 
     def step(self, obs, h, c, keep=None, work=None):
         """One time step for N envs (step-wise rollout of configurations the fused rollout kernel does

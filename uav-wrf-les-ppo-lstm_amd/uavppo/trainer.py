@@ -99,6 +99,7 @@ class VecPPOTrainer:
         self.fused_mlp = policy == "mlp" and D == 6
         self.reuse_rollout_forward = True    # epoch 0 adopts the rollout kernel's stash (same parameters)
         self.use_stepper = True              # h = 256 step-wise rollouts through uav_lstm_stepper_* (A/B switch)
+        self.use_fused_tail = True           # ... and heads + sample + env step + store of a step as ONE launch (A/B switch)
         self._rollout_forward_valid = False
         self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
         self.log = []
@@ -306,9 +307,23 @@ class VecPPOTrainer:
         # PPO epoch 0 adopts this forward pass.  Otherwise one uav_lstm_fwd call of T = 1 per layer and step.
         stepper = (self.use_stepper and self.policy.hidden == 256 and self.arith == "fp16x3" and self.num_minibatches == 1
                    and ops.lstm_bwd_caps(self.device, self.obs_dim, 256) != 0)      # 0: the handle is not on the fp16 step path
+        # everything after the recurrent layers as one launch (uav_rollout_tail), unless the per-step info rows are wanted
+        tail = stepper and self.use_fused_tail and self.info is None
         if stepper:
             self.policy.begin_steps(self.h, self.c)
         for t in range(self.T):
+            if tail:
+                if t == 0:
+                    b["obs"][:, 0] = self.cur_obs                  # later rows are written by the tail of the step before
+                top = self.policy.step_layers_at(b["obs"], t, self.work, keep=st["keep"])
+                v = self.policy.views
+                ops.rollout_tail(self.env_state, cfg, top, t, v["head.weight"], v["head.bias"], self.work["heads"], st["act"],
+                                 self.cur_obs, b["obs"], st["keep"], b["act"], b["val"], b["logp"], b["keep"], b["rew"], b["done"],
+                                 b["flags"], self.nan_count, seed=self.seed, iteration=self.iteration,
+                                 index_offset=env_shard(self.rank, self.N)[0],
+                                 forced_act=None if forced_act is None else forced_act[:, t].contiguous(),
+                                 noise=None if noise is None else noise[:, t].contiguous())
+                continue
             if stepper:
                 b["obs"][:, t] = self.cur_obs
                 heads = self.policy.step_at(b["obs"], t, self.work, self.work["heads"], keep=st["keep"])
