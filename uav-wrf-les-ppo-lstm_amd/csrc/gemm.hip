@@ -250,14 +250,14 @@ __global__ __launch_bounds__(256) void rows_dot_kernel(int64_t M, int K, const f
     // four rows per trip: their loads are in flight together (a long M is a stream from HBM, one row per trip would run
     // at the memory latency)
     for (int64_t m0 = wave * 4; m0 < M; m0 += nwave * 4) {
-        float out[4][NO];
-        rd.rows4(A, lda, m0, M, K, lane, out);
+        float red[4];
+        rd.rows4(A, lda, m0, M, K, lane, red);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float mine = 0.f;
 #pragma unroll
             for (int o = 0; o < NO; ++o)
-                if (lane == o) mine = out[r][o];
+                if (lane == o) mine = RowsDot<NO, KQ>::total(red[r], o);
             if (m0 + r < M && lane < n_out) C[(m0 + r) * ldc + lane] = mine + bv;
         }
     }

@@ -556,15 +556,17 @@ __global__ __launch_bounds__(256) void rollout_tail_kernel(
     if (m0 >= n) return;
     RowsDot<8, 1> rd;
     rd.load_w(w_head, K, A + 1, K, lane);
-    float out[4][8];
-    rd.rows4(y, ldy, m0, n, K, lane, out);
+    float red[4];
+    rd.rows4(y, ldy, m0, n, K, lane, red);
     float z[A + 1];
 #pragma unroll
     for (int o = 0; o <= A; ++o) {
         float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (lane == r) v = out[r][o];
+        for (int r = 0; r < 4; ++r) {
+            const float tot = RowsDot<8, 1>::total(red[r], o);
+            if (lane == r) v = tot;
+        }
         z[o] = v + b_head[o];
     }
     const int64_t i64 = m0 + lane;
