@@ -474,6 +474,22 @@ def test_fused_rollout_tail_equals_the_five_launches():
     assert int(a.nan_count.item()) == int(b.nan_count.item()) == 0
 
 
+def test_update_forward_on_the_steppers_equals_layer_by_layer_calls():
+    """The update's forward passes of a stacked h = 256 policy run on the rollout's steppers (all layers step by step, the
+    layer above reading the piece planes of the layer below) instead of one uav_lstm_fwd per layer: same kernels, so after two
+    iterations (2 x 3 optimiser steps, two of them on recomputed forwards each) gradient and parameters are BIT-identical."""
+    from uavppo.trainer import VecPPOTrainer
+    mk = lambda: VecPPOTrainer(72, 11, "lstm", hidden=256, layers=2, variant="v2.1", device=DEV, seed=9, trend_k=2, epochs=3)
+    a, b = mk(), mk()
+    b.policy.use_stepper_forward = False
+    for it in range(2):
+        a.train_iteration(); b.train_iteration()
+        assert torch.equal(a.policy.grad, b.policy.grad), it
+        assert torch.equal(a.policy.flat, b.policy.flat), it
+        for l in range(2):
+            assert torch.equal(a.work[f"y{l}"], b.work[f"y{l}"]) and torch.equal(a.work[f"stash{l}"], b.work[f"stash{l}"]), (it, l)
+
+
 def test_pipelined_stack_backward_equals_layer_by_layer():
     """uav_lstm_bwd_stack (the layers' BPTTs pipelined on internal streams, the layer below one step behind the one above)
     runs the kernels of one uav_lstm_bwd per layer: after two iterations (4 optimiser steps) the parameters are BIT-identical."""

@@ -165,6 +165,26 @@ class LSTMActorCritic(_FlatPolicy):
         saved = []
         work = work or {}
         heads = None
+        if self._interleaved_forward_ok(N, work):
+            # stacked h = 256 layers: the steppers of the rollout (weights split once, the layer above reading the piece planes
+            # of the layer below) step all layers time step by time step -- uav_lstm_fwd layer by layer converts the layer
+            # below's whole output to piece planes first (split_x_kernel) and re-splits the weights per call; same kernels,
+            # BIT-identical stash / y (tests/test_gpu_lstm.py::test_lstm_stepper_equals_sequence_forward)
+            self.begin_steps(h0, c0)
+            keep_t = None if keep is None else keep.t().contiguous()
+            for t in range(T):
+                self.step_layers_at(obs, t, work, keep=None if keep_t is None else keep_t[t])
+            for l in range(self.num_layers):
+                saved.append((x, work[f"stash{l}"], work[f"y{l}"], h0[l]))
+                x = work[f"y{l}"]
+            self._saved = (saved, keep, x)
+            if not want_heads:
+                return x.view(N * T, self.hidden)
+            heads = work.get("heads")
+            if heads is None or heads.shape[0] != N:
+                heads = torch.empty(N, T, self.n_act + 1, dtype=torch.float32, device=obs.device)
+            ops.gemm_rows(x.view(N * T, self.hidden), v["head.weight"], v["head.bias"], heads.view(N * T, self.n_act + 1))
+            return heads.view(N * T, self.n_act + 1)
         for l in range(self.num_layers):
             top = want_heads and l == self.num_layers - 1
             if top:
@@ -196,6 +216,17 @@ class LSTMActorCritic(_FlatPolicy):
         self._saved = (saved, keep, x)
         N, T, H = x.shape
         return x.view(N * T, H)
+
+    def _interleaved_forward_ok(self, N, work):
+        """The update's forward pass can run on the rollout's steppers: a stack of h = 256 layers on the fp16-split step path,
+        steppers already built for this many envs, and the [N, T] arrays they fill present."""
+        if not getattr(self, "use_stepper_forward", True) or self.num_layers < 2 or self.hidden != 256:
+            return False
+        sp = getattr(self, "_steppers", None)
+        if sp is None or sp[0].N != N or ops.lstm_bwd_caps(self.device, self.obs_dim, 256) == 0:
+            return False
+        return all(work.get(f"y{l}") is not None and work[f"y{l}"].shape[0] == N and work.get(f"stash{l}") is not None
+                   for l in range(self.num_layers))
 
     def steppers(self, N, device):
         """One ops.LstmStepper per layer (uav_lstm_stepper_*: h = 256, fp16-split arithmetic), created once."""
