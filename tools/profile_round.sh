@@ -2,7 +2,7 @@
 # rocprofv3 evidence for profiles/: kernel-trace stats of bench.py, then FETCH_SIZE and WRITE_SIZE in separate passes.
 # run on the GPU box from the repo root: bash tools/profile_round.sh <tag>
 set -e
-TAG=${1:-r03_c}
+TAG=${1:-r03_d}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
