@@ -474,6 +474,29 @@ def test_fused_rollout_tail_equals_the_five_launches():
     assert int(a.nan_count.item()) == int(b.nan_count.item()) == 0
 
 
+def test_rollout_tail_refuses_bad_arguments():
+    """uav_rollout_tail's argument checks answer with the reference's error convention (RuntimeError carrying the text of
+    uav_last_error) before anything is launched: a time step outside the horizon, a head count it has no kernel for, a hidden
+    size beyond one 256-wide slab."""
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(8, 4, "lstm", hidden=256, layers=2, variant="v2.1", device=DEV, seed=1, trend_k=2, epochs=1, use_curriculum=False)
+    tr.collect()
+    b, st, v = tr.buf, tr._st, tr.policy.views
+    args = lambda t, heads, w, bh, y: (tr.env_state, tr.env_cfg(), y, t, w, bh, heads, st["act"], tr.cur_obs, b["obs"], st["keep"], b["act"],
+                                       b["val"], b["logp"], b["keep"], b["rew"], b["done"], b["flags"], tr.nan_count)
+    y = tr.work["y1"]
+    before = {k: x.clone() for k, x in b.items()}
+    with pytest.raises(RuntimeError, match="t=4"):
+        ops.rollout_tail(*args(4, tr.work["heads"], v["head.weight"], v["head.bias"], y))
+    with pytest.raises(RuntimeError, match="n_act=7"):
+        ops.rollout_tail(*args(0, torch.zeros(8, 4, 8, device=DEV), torch.zeros(8, 256, device=DEV), torch.zeros(8, device=DEV), y))
+    with pytest.raises(RuntimeError, match="hidden 320"):
+        ops.rollout_tail(*args(0, tr.work["heads"], torch.zeros(6, 320, device=DEV), v["head.bias"], torch.zeros(8, 4, 320, device=DEV)))
+    torch.cuda.synchronize()
+    assert all(torch.equal(before[k], b[k]) for k in before)
+
+
 def test_update_forward_on_the_steppers_equals_layer_by_layer_calls():
     """The update's forward passes of a stacked h = 256 policy run on the rollout's steppers (all layers step by step, the
     layer above reading the piece planes of the layer below) instead of one uav_lstm_fwd per layer: same kernels, so after two
