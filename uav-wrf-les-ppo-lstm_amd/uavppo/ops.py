@@ -69,6 +69,9 @@ class _KernelTimer:
     """Optional HIP-event bracket around named launches on torch's current stream (bench.py uses it
     to time the dominant kernel live inside the timed region).  Disabled = zero overhead."""
 
+    CAP = 48      # brackets kept per name: HIP hands timing events out of a pool of ~1 k; the allocation that grows it stalls
+                  # the host for ~30 ms (seen as one slow iteration around the 37th of a run that bracketed every launch)
+
     def __init__(self):
         self.names, self.events = (), {}
 
@@ -79,7 +82,7 @@ class _KernelTimer:
         self.names, self.events = (), {}
 
     def bracket(self, name):
-        if name not in self.names:
+        if name not in self.names or len(self.events[name]) >= self.CAP:
             return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.events[name].append((a, b))
