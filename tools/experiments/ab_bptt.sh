@@ -2,7 +2,7 @@
 # ablation / tuning builds of bptt_step_h3_kernel (csrc/lstm_generic.hip): tools/bin/libuavppo_bptt_<tag>.so
 # usage: tools/ab_bptt.sh tag "-DBPTT_ABL=1" [tag "defs" ...]
 set -e
-cd "$(dirname "$0")/../uav-wrf-les-ppo-lstm_amd/csrc"
+cd "$(dirname "$0")/../../uav-wrf-les-ppo-lstm_amd/csrc"
 mkdir -p ../../tools/bin build_abl
 args=("$@")
 for ((i = 0; i < ${#args[@]}; i += 2)); do

@@ -2,7 +2,7 @@
 libuavppo (tools/ab_bptt.sh: a7 = products + residual epilogue without its HBM traffic, a8 = epilogue without products), each
 with its own handle, run alone and then together on two streams."""
 import ctypes as C, os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-wrf-les-ppo-lstm_amd")]
 from uavppo import _lib
 dev, N, T, H = torch.device("cuda:0"), 4096, 64, 256

@@ -1,5 +1,5 @@
 """Per-step time of the h = 256 BPTT step launches (uav_lstm_bwd alone, one layer, one stream) at C5's per-GPU shape.
-UAVPPO_LIB selects an instrumented / ablation build (tools/ab_bptt.sh).  Usage: python tools/perf_bptt.py [N] [T]"""
+UAVPPO_LIB selects an instrumented / ablation build (tools/experiments/ab_bptt.sh, on the experiment patch).  Usage: python tools/perf_bptt.py [N] [T]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
