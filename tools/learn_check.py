@@ -19,8 +19,8 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     lr = float(sys.argv[2]) if len(sys.argv) > 2 else 3e-4
     mb = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    if len(sys.argv) > 4 and sys.argv[4] == "c5":
-        N = 1024
+    if len(sys.argv) > 4 and sys.argv[4] in ("c5", "c5full"):
+        N, T = (1024, 128) if sys.argv[4] == "c5" else (4096, 256)       # c5full: BASELINE C5's exact per-GPU shape
         tr = VecPPOTrainer(N, T, "lstm", hidden=256, layers=2, trend_k=2, variant="v2.1", device="cuda:0", seed=1, lr=lr,
                            num_minibatches=mb, use_curriculum=True)
     elif len(sys.argv) > 4 and sys.argv[4] == "mlp":      # the reference's own policy through the fused MLP kernels
