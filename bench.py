@@ -64,7 +64,7 @@ def free_port():
     return port
 
 
-def spawn_ranks(n, cmd, extra_env=None, timeout=None, capture_rank0=False):
+def spawn_ranks(n, cmd, extra_env=None, timeout=None, capture_rank0=False, shared_gpu=False):
     """Start `cmd` n times as FRESH child processes (one per rank, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
     environment), wait for all, return (largest exit code, rank 0's stdout or None).  The caller must not have touched
     the GPU: a rank process initialises HIP itself, nothing is re-exec'ed from a process that already did.  If one rank
@@ -74,8 +74,8 @@ def spawn_ranks(n, cmd, extra_env=None, timeout=None, capture_rank0=False):
     env = dict(os.environ)
     env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
-    if "--backend" in cmd and cmd[cmd.index("--backend") + 1] == "gloo":
-        # gloo = the rehearsal of several ranks SHARING one GPU: each process then gets two hardware queues instead of
+    if shared_gpu:
+        # gloo (decided by the caller from its PARSED --backend, so `--backend=gloo` counts too) = the rehearsal of several ranks SHARING one GPU: each process then gets two hardware queues instead of
         # HIP's default four.  With the default, two C5 ranks oversubscribed the GPU's queue slots and every dependent
         # launch waited a scheduling quantum (49.8 s per iteration against 0.46 s: DESIGN.md 6, gpurun_out/b2_c5_*).
         env.setdefault("GPU_MAX_HW_QUEUES", "2")
@@ -132,17 +132,23 @@ def launch(args, argv):
     weak -> strong sequence stalled in a shared-GPU rehearsal: DESIGN.md 6).  One JSON line on stdout."""
     me = [sys.executable, os.path.abspath(__file__)]
     t0 = time.time()
-    rc, text = spawn_ranks(args.gpus, me + argv, capture_rank0=True)
+    shared = args.backend == "gloo"
+    # generous, config-dependent limit: a rank stuck in a collective or on a GPU wait must not hold the launcher (and the
+    # one JSON line) forever.  On expiry spawn_ranks terminates the children by PID (never re-executes them), rc = 124.
+    per_iter_s = {"c5": 0.25, "c4": 0.02, "c3": 0.02, "c2": 0.01, "mlp": 0.02}.get(args.config, 0.05) * (args.gpus if shared else 1)
+    limit = args.headline_timeout or (600.0 + 20.0 * per_iter_s * (args.steps + args.warmup))
+    rc, text = spawn_ranks(args.gpus, me + argv, capture_rank0=True, timeout=limit, shared_gpu=shared)
     out = last_json_line(text)
     if rc or out is None:
-        sys.stderr.write(f"[bench] headline phase failed (rc {rc})\n")
+        why = f"timed out after {limit:.0f} s; rank processes terminated" if rc == 124 else f"rc {rc}"
+        sys.stderr.write(f"[bench] headline phase failed ({why})\n")
         return rc or 1
     if args.scaling == "weak" and not args.no_strong_phase:
         wall = time.time() - t0
         k2, w2 = max(3, args.steps // 2), min(args.warmup, 2)
         argv2 = ["--gpus", str(args.gpus), "--config", args.config, "--backend", args.backend, "--scaling", "strong",
                  "--steps", str(k2), "--warmup", str(w2), "--no-cpu-baseline"]
-        rc2, text2 = spawn_ranks(args.gpus, me + argv2, capture_rank0=True, timeout=max(180.0, 4.0 * wall))
+        rc2, text2 = spawn_ranks(args.gpus, me + argv2, capture_rank0=True, timeout=max(180.0, 4.0 * wall), shared_gpu=shared)
         o2 = last_json_line(text2)
         if rc2 == 0 and o2:
             out["strong_scaling"] = {"value": o2["value"], "unit": o2["unit"], "num_envs_per_gpu": o2["config"]["num_envs_per_gpu"],
@@ -541,6 +547,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-phase", action="store_true", help="launcher mode: skip the second (strong-scaling) set of ranks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--headline-timeout", type=float, default=0.0, help="launcher mode: seconds before the headline rank set is terminated (0 = config-dependent default)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -70,6 +70,10 @@ a = sys.argv[1:]
 strong = a[a.index("--scaling") + 1] == "strong" if "--scaling" in a else False
 if strong and os.environ.get("FAKE_STRONG") == "hang":
     time.sleep(600)
+if not strong and os.environ.get("FAKE_STRONG") == "headline-hang":
+    time.sleep(600)
+if os.environ.get("FAKE_ENV_OUT") and os.environ["RANK"] == "0" and not strong:
+    open(os.environ["FAKE_ENV_OUT"], "w").write(os.environ.get("GPU_MAX_HW_QUEUES", "unset"))
 if strong and os.environ.get("FAKE_STRONG") == "fail":
     sys.exit(5)
 if os.environ["RANK"] == "0":
@@ -80,7 +84,7 @@ if os.environ["RANK"] == "0":
 '''
 
 
-def _fake_launch(tmp_path, monkeypatch, mode):
+def _fake_launch(tmp_path, monkeypatch, mode, backend="gloo", cap=5):
     """bench.launch() with the rank command replaced by a stand-in: the launcher's own logic (two fresh rank sets, merge,
     a failing or hanging strong phase never loses the headline line) without a GPU."""
     import argparse
@@ -90,9 +94,10 @@ def _fake_launch(tmp_path, monkeypatch, mode):
     monkeypatch.setattr(bench.os.path, "abspath", lambda p: str(fake))
     monkeypatch.setenv("FAKE_STRONG", mode)
     real = bench.spawn_ranks
-    monkeypatch.setattr(bench, "spawn_ranks", lambda n, cmd, **kw: real(n, cmd, **dict(kw, timeout=min(kw.get("timeout") or 5, 5))))
-    args = argparse.Namespace(gpus=2, scaling="weak", no_strong_phase=False, steps=4, warmup=1, config="c2", backend="gloo")
-    return bench.launch(args, ["--gpus", "2", "--config", "c2", "--backend", "gloo"])
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, cmd, **kw: real(n, cmd, **dict(kw, timeout=min(kw.get("timeout") or cap, cap))))
+    args = argparse.Namespace(gpus=2, scaling="weak", no_strong_phase=False, steps=4, warmup=1, config="c2", backend=backend,
+                              headline_timeout=0.0)
+    return bench.launch(args, ["--gpus", "2", "--config", "c2", f"--backend={backend}"])
 
 
 def test_launcher_runs_strong_shape_in_a_second_fresh_rank_set(tmp_path, monkeypatch, capsys):
@@ -108,3 +113,23 @@ def test_launcher_keeps_the_headline_when_the_strong_phase_fails_or_hangs(tmp_pa
         assert _fake_launch(tmp_path, monkeypatch, mode) == 0
         out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
         assert out["value"] == 1.0 and "error" in out["strong_scaling"]
+
+
+def test_launcher_times_out_a_hung_headline_phase(tmp_path, monkeypatch, capsys):
+    """A rank stuck in a collective must not hold the launcher forever: the headline rank set has a limit too; on expiry
+    the children are terminated and the launcher exits non-zero without a JSON line."""
+    rc = _fake_launch(tmp_path, monkeypatch, "headline-hang", cap=3)
+    cap = capsys.readouterr()
+    assert rc == 124 and cap.out.strip() == "" and "timed out" in cap.err
+
+
+def test_shared_gpu_queue_cap_follows_the_parsed_backend(tmp_path, monkeypatch, capsys):
+    """`--backend=gloo` (one token) is a shared-GPU rehearsal exactly like `--backend gloo`: the rank processes get
+    GPU_MAX_HW_QUEUES=2; with nccl (one process per GPU) they do not."""
+    for backend, want in (("gloo", "2"), ("nccl", "unset")):
+        out = tmp_path / f"env_{backend}.txt"
+        monkeypatch.setenv("FAKE_ENV_OUT", str(out))
+        monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+        assert _fake_launch(tmp_path, monkeypatch, "ok", backend=backend) == 0
+        capsys.readouterr()
+        assert out.read_text() == want

@@ -1,9 +1,10 @@
-"""CPU, world_size 2, gloo: the data-parallel exchanges of one iteration (uavppo/dist_utils.py)
+"""CPU, world_size 2 and 8 (the size of the driver's first real multi-GPU run), gloo: the data-parallel exchanges of one iteration (uavppo/dist_utils.py)
 give the same numbers as one process over the whole buffer.  Compute on each rank is the oracle
 (no GPU here); what is under test is the sharding + collective logic the GPU trainer uses."""
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -13,7 +14,7 @@ from oracle import ppo_oracle as po
 
 def _data():
     rng = np.random.RandomState(0)
-    N, T = 8, 16
+    N, T = 16, 16
     obs = rng.rand(N * T, 6).astype(np.float32)
     act = rng.randint(0, 5, N * T)
     adv = (rng.randn(N, T) * 2 + 0.5).astype(np.float32)
@@ -69,15 +70,16 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_exchange_equals_single_process(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_multi_rank_exchange_equals_single_process(tmp_path, world):
     out = str(tmp_path / "r0.pt")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
     got = torch.load(out)
     N, T, obs, act, adv, val, logp, flags, p = _data()
     adv_n, ret = po.normalise(adv, val)                     # single process over the whole buffer
     assert got["cnt"] == N * T
-    assert torch.allclose(got["adv_n"], adv_n[: N * T // 2], atol=1e-6)
+    assert torch.allclose(got["adv_n"], adv_n[: N * T // world], atol=1e-6)
     g = _grad(p, obs, act, logp, adv_n, ret, val.reshape(-1), 1.0 / (N * T))
     assert torch.allclose(got["grad"], g, rtol=1e-4, atol=1e-7)
     assert np.array_equal(got["flags"].numpy(), flags)

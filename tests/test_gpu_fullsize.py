@@ -149,3 +149,69 @@ def test_fullsize_gradient_split_bf16_equals_exact_f32_kernels(trainer):
     assert rel.item() < 2e-5, rel.item()
     assert torch.allclose(sums[0][1:3], sums[1][1:3], rtol=1e-6)              # value-loss and entropy sums
     assert abs((sums[0][0] - sums[1][0]).item()) < 1e-4                        # policy-loss sum: ~0 by cancellation at init
+
+
+@pytest.mark.parametrize("radius", [50.0, 140.0])
+def test_c3_procedural_rollout_rows_equal_oracle(radius):
+    """The benchmarked kernel in the benchmarked mode: rollout_lstm_kernel<128> at C3's exact shape (4096 x 128, h=128,
+    procedural field, own noise, own sampled actions).  Oracle replay of env rows chosen over the whole launch -- the
+    first and last rows, rows of other workgroups / XCDs, and rows in which an episode ENDS (so the restart, the
+    episode-1 field and source, and the keep mask are exercised): every observation / done / keep / flag bit for bit,
+    rewards to 1e-6, the sampled action == the inverse-CDF draw of the recorded logits at the oracle's Philox uniform,
+    values / log-probs against the f32 oracle LSTM on the recorded observations (rows are independent problems).
+    radius 50 is bench.py's start state (episodes rarely end inside 128 steps); radius 140 makes many rows end."""
+    from oracle import procedural_oracle as pr
+    from uavppo.trainer import VecPPOTrainer
+    seed = 1234                                                  # bench.py's seed
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=seed, use_curriculum=False)
+    tr.radius = radius
+    tr.reset()
+    obs0 = tr.cur_obs.cpu().numpy().copy()
+    h0, c0 = tr.h.cpu().clone(), tr.c.cpu().clone()
+    tr.collect()
+    b = {k: v.cpu().numpy() for k, v in tr.buf.items()}
+    heads = tr.work["heads"].cpu().numpy()
+    ended = np.flatnonzero(b["done"].sum(1) > 0)
+    rows = [0, 15, 16, 2047, N - 17, N - 1] + [int(r) for r in ended[:: max(1, len(ended) // 6)][:6]]
+    if radius > 100:
+        assert len(ended) >= 50, len(ended)
+    rows = sorted(set(rows))
+    assert len(rows) >= 8
+    p = {k: v.detach().cpu().clone() for k, v in tr.policy.named_views().items()}
+    n_end = 0
+    for r in rows:
+        ora = pr.ProceduralVecEnv(1, seed, "v2.0", radius=radius, env_offset=r)
+        obs = ora.reset()
+        assert np.array_equal(obs0[r:r + 1], obs), r
+        keep = np.ones(1, np.float32)
+        for t in range(T):
+            assert np.array_equal(b["obs"][r:r + 1, t], obs), (r, t)
+            assert b["keep"][r, t] == keep[0], (r, t)
+            obs, rew, done, reached, _, _ = ora.step(b["act"][r:r + 1, t])
+            assert abs(float(b["rew"][r, t]) - float(np.float32(rew[0]))) <= 1e-6, (r, t)
+            assert bool(b["done"][r, t] > 0) == bool(done[0]), (r, t)
+            assert int(b["flags"][r, t]) == int(done[0]) | (int(reached[0]) << 1), (r, t)
+            keep = 1.0 - done.astype(np.float32)
+            n_end += int(done[0])
+        assert np.array_equal(tr.cur_obs[r:r + 1].cpu().numpy(), obs), r
+    # the Categorical draw of those rows
+    sel = np.asarray(rows)
+    logits = heads[sel][..., :5].astype(np.float32)
+    e = np.exp(logits - logits.max(-1, keepdims=True), dtype=np.float32)
+    pdev = e / e.sum(-1, keepdims=True, dtype=np.float32)
+    u = np.stack([pr.action_uniform(seed, t, sel, 0) for t in range(T)], axis=1)
+    cdf = np.cumsum(pdev, -1, dtype=np.float32)
+    clear = np.all(np.abs(cdf - (u * cdf[..., -1])[..., None]) > 2e-6, axis=-1)
+    want = pr.sample_inverse_cdf(pdev.reshape(-1, 5), u.reshape(-1)).reshape(len(rows), T)
+    assert clear.mean() > 0.99 and np.array_equal(want[clear], b["act"][sel][clear])
+    # policy side of those rows on the recorded inputs: f32 oracle LSTM (torch CPU)
+    with torch.no_grad():
+        probs, value, _, _ = po.lstm_policy_forward(p, torch.from_numpy(b["obs"][sel]).transpose(0, 1), h0[:, sel], c0[:, sel],
+                                                    keep=torch.from_numpy(b["keep"][sel]).transpose(0, 1))
+        lp = po.categorical_logp(probs.transpose(0, 1).reshape(len(rows) * T, -1), torch.from_numpy(b["act"][sel]).reshape(-1).long())
+    assert np.allclose(b["val"][sel], value.transpose(0, 1).numpy().reshape(len(rows), T), atol=2e-5, rtol=1e-4)
+    assert np.allclose(b["logp"][sel], lp.numpy().reshape(len(rows), T), atol=2e-5, rtol=1e-4)
+    assert np.allclose(pdev, probs.transpose(0, 1).numpy(), atol=2e-6)
+    if radius > 100:
+        assert n_end >= 6
+    print(f"C3 procedural replay: rows {rows}, episode ends replayed {n_end}, rows with ends in the launch {len(ended)}")

@@ -57,3 +57,13 @@ NUM_LAYERS = 1
 NUM_MINIBATCHES = 1      # the reference uses ONE minibatch of the whole buffer per epoch (train_ppo2.0.py:44-45)
 GAE_MODE = "reference_exact"   # or "standard" (PPOV1.0/ppo0.0.py:337-350)
 SEED = 1234
+TREND_K = 0              # extra observation channels obs[2](t) - obs[2](t-1-i), i < TREND_K (BASELINE C5: 2)
+FIELD_BANK = None        # None = procedural fields | path to .npz / netCDF (conc, tke, source) | "synth:F" (BASELINE C4: "synth:64")
+ITERATIONS = 200         # vectorised trainer: rollout + update iterations ...
+EPISODES = None          # ... or stop once this many episodes have finished (the reference trains 2000, train_ppo2.0.py:128)
+# data parallel, one process per GPU (torchrun / bench.py's launcher export these); 1 rank when absent
+import os as _os
+WORLD_SIZE = int(_os.environ.get("WORLD_SIZE", "1"))
+RANK = int(_os.environ.get("RANK", "0"))
+LOCAL_RANK = int(_os.environ.get("LOCAL_RANK", "0"))
+DIST_BACKEND = _os.environ.get("UAVPPO_DIST_BACKEND", "nccl")   # "nccl" == RCCL over xGMI; "gloo" only for rehearsals / tests

@@ -11,8 +11,9 @@ import numpy as np
 import pandas as pd
 import torch
 
-from config import (BATCH_SIZE, CLIP_EPSILON, ENTROPY_BETA, ENV_VARIANT, EPOCHS, GAE_MODE, GAMMA, GRID_SIZE, HIDDEN,
-                    HORIZON, LAMBDA, LEARNING_RATE, MAX_STEPS, NUM_ENVS, NUM_LAYERS, NUM_MINIBATCHES, POLICY, SEED)  # noqa: F401
+from config import (BATCH_SIZE, CLIP_EPSILON, DIST_BACKEND, ENTROPY_BETA, ENV_VARIANT, EPISODES, EPOCHS, FIELD_BANK, GAE_MODE, GAMMA,
+                    GRID_SIZE, HIDDEN, HORIZON, ITERATIONS, LAMBDA, LEARNING_RATE, LOCAL_RANK, MAX_STEPS, NUM_ENVS, NUM_LAYERS,
+                    NUM_MINIBATCHES, POLICY, RANK, SEED, TREND_K, WORLD_SIZE)  # noqa: F401
 from environment import MethaneEnv
 from model import PPOActorCritic, PPOBuffer, PPOTrainer
 from uavppo import ops
@@ -80,7 +81,7 @@ def _update_model(buffer, model, optimizer):
 
 def train_ppo(episodes=2000, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth"):
     """Reference-shaped single-environment loop (train_ppo2.0.py:110-261) on the HIP kernels."""
-    if NUM_ENVS > 1 or POLICY != "mlp":
+    if NUM_ENVS > 1 or POLICY != "mlp" or WORLD_SIZE > 1:
         return train_ppo_vectorised(csv_path=csv_path, model_path=model_path)
     env = MethaneEnv()
     model = PPOActorCritic(6, 5)
@@ -126,37 +127,96 @@ def train_ppo(episodes=2000, csv_path="training_results2_0.csv", model_path="mod
     return model, rows
 
 
-def train_ppo_vectorised(iterations=200, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth",
-                         nc_path=None):
-    """NUM_ENVS environments per GPU with the fused kernels; one CSV row per finished episode with the
-    reference's 11 columns (uavppo/episode_log.py), in (iteration, env, time) order."""
-    from uavppo.episode_log import EpisodeLogger
+def _init_distributed():
+    """One process per GPU (torchrun, or bench.py's launcher, exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): bring up the
+    process group BEFORE the trainer is built.  backend "nccl" == RCCL over xGMI; several ranks sharing one
+    GPU (tests, rehearsals) use gloo.  Returns (rank, world, device)."""
+    import torch.distributed as dist
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", LOCAL_RANK % ndev)
+    torch.cuda.set_device(dev)
+    if WORLD_SIZE > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if DIST_BACKEND == "nccl":
+            dist.init_process_group("nccl", rank=RANK, world_size=WORLD_SIZE, device_id=dev)
+        else:
+            dist.init_process_group(DIST_BACKEND, rank=RANK, world_size=WORLD_SIZE)
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dev
+    return 0, 1, dev
+
+
+def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth",
+                         nc_path=None, episodes=None, log_every=10):
+    """NUM_ENVS environments per GPU with the fused kernels, every BASELINE configuration from config.py alone: LSTM or MLP
+    policy, stacked layers, TREND_K observation channels (C5), a materialised FIELD_BANK (C4), WORLD_SIZE ranks (env shards,
+    RCCL gradient all-reduce).  One CSV row per finished episode with the reference's 11 columns (uavppo/episode_log.py) in
+    (iteration, global env, time) order; the run ends after `iterations` rollouts or once `episodes` episodes have finished
+    (the reference trains 2000, train_ppo2.0.py:128), whichever is given (config.ITERATIONS / config.EPISODES otherwise).
+    CSV, checkpoint and trajectory log are written by rank 0 only.
+
+    The per-iteration host copies (info / flags / rew) ride the side stream into pinned memory while the update runs
+    (RolloutMirror); the loop's only host waits are the curriculum's success bits and that copy."""
+    import torch.distributed as dist
+    from uavppo import field_bank
+    from uavppo.episode_log import EpisodeLogger, RolloutMirror
     from uavppo.trainer import VecPPOTrainer
-    tr = VecPPOTrainer(NUM_ENVS, HORIZON, POLICY, hidden=HIDDEN, layers=NUM_LAYERS, variant=ENV_VARIANT, seed=SEED,
+    iterations = ITERATIONS if iterations is None and episodes is None and EPISODES is None else iterations
+    episodes = EPISODES if episodes is None else episodes
+    rank, world, dev = _init_distributed()
+    bank, bank_src = field_bank.load(FIELD_BANK, ENV_VARIANT, dev)
+    tr = VecPPOTrainer(NUM_ENVS, HORIZON, POLICY, hidden=HIDDEN, layers=NUM_LAYERS, variant=ENV_VARIANT, seed=SEED, device=dev,
                        gae_mode=GAE_MODE, num_minibatches=NUM_MINIBATCHES, log_info=True, gamma=GAMMA, lam=LAMBDA,
-                       clip=CLIP_EPSILON, ent_beta=ENTROPY_BETA, lr=LEARNING_RATE, epochs=EPOCHS)
+                       clip=CLIP_EPSILON, ent_beta=ENTROPY_BETA, lr=LEARNING_RATE, epochs=EPOCHS, rank=rank, world_size=world,
+                       bank=bank, bank_sources=bank_src, trend_k=TREND_K)
     log = EpisodeLogger(NUM_ENVS)
+    rows_per_iter = []                  # this rank's rows, iteration by iteration (merged in rank order at the end)
+    mirror = RolloutMirror(tr)
     traj = None
-    if nc_path:                      # the reference's trajectory log (train_ppo2.0.py:119-125,216-227,259)
+    if nc_path and world == 1:       # the reference's trajectory log (train_ppo2.0.py:119-125,216-227,259); single rank only
         from netcdf_writer import NetCDFWriter
         from uavppo.episode_log import TrajectoryLogger
         from config import GAUSSIAN_RADIUS, PEAK_CONCENTRATION
         traj = TrajectoryLogger(NUM_ENVS, NetCDFWriter(nc_path, GRID_SIZE, max_episodes=2000, max_steps=MAX_STEPS),
                                 gaussian=(GAUSSIAN_RADIUS, PEAK_CONCENTRATION) if ENV_VARIANT == "v2.1" else None)
-    for it in range(iterations):
+    it = 0
+    while (iterations is None or it < iterations) and (episodes is None or tr.episodes_done < episodes):
         radius = tr.radius
-        tr.train_iteration()
-        info, flags = tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy()
-        log.add_rollout(tr.buf["rew"].cpu().numpy(), info, flags, radius)
+        mirror.fence()
+        tr.collect()
+        slot = mirror.start()
+        tr.update()
+        tr.update_curriculum()
+        tr.poll_param_range()
+        tr.iteration += 1
+        host = mirror.get(slot)          # landed while the update's kernels were queued / running
+        before = len(log.rows)
+        log.add_rollout(host["rew"], host["info"], host["flags"], radius)
+        rows_per_iter.append(log.rows[before:])
         if traj is not None:
-            traj.add_rollout(info, flags, radius)
-        pl, vl, ent = tr.losses()
-        if (it + 1) % 10 == 0:
-            print(f"It {it + 1} | episodes {log.count} | radius {tr.radius:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
+            traj.add_rollout(host["info"], host["flags"], radius)
+        it += 1
+        if log_every and it % log_every == 0:
+            pl, vl, ent = tr.losses()              # (also where NaN probabilities raise, on every rank together)
+            if rank == 0:
+                print(f"It {it} | episodes {tr.episodes_done} | radius {tr.radius:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
+    tr.losses()
     if traj is not None:
         traj.writer.close()
-    _save(tr.policy.state_dict(), log.rows, csv_path, model_path)
-    return tr, log.rows
+    if world > 1:                        # rank order == global env order (contiguous shards)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows_per_iter)
+        rows = [r for i in range(it) for g in gathered for r in g[i]]
+    else:
+        rows = [r for g in rows_per_iter for r in g]
+    rows = [[k + 1] + list(r[1:]) for k, r in enumerate(rows)]
+    if episodes is not None:
+        rows = rows[:episodes]
+    if rank == 0:
+        _save(tr.policy.state_dict(), rows, csv_path, model_path)
+    if world > 1:
+        dist.barrier()
+    return tr, rows
 
 
 def _save(state_dict, rows, csv_path, model_path):

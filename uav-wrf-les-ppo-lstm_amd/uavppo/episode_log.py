@@ -18,18 +18,25 @@ class EpisodeLogger:
         self.rows = []
 
     def add_rollout(self, rew, info, flags, radius):
-        """rew [N,T] f32, info [N,T,6] f32 (5 reward parts + obs[2] of the step), flags [N,T] u8."""
+        """rew [N,T] f32, info [N,T,>=6] f32 (5 reward parts + obs[2] of the step), flags [N,T] u8.  Returns the number of
+        rows added.  Only env rows in which an episode ENDED get a running sum along T; the others add their row total to
+        the carry (a rollout ends episodes in a small fraction of its rows: the pass over [N, T, 6] is one reduction)."""
         rew, info, flags = np.asarray(rew), np.asarray(info), np.asarray(flags)
         N, T = rew.shape
-        parts = np.concatenate([rew[..., None].astype(np.float64), info[..., :5].astype(np.float64)], axis=2)
-        cs = np.cumsum(parts, axis=1)                                     # [N,T,6]
         n_idx, t_idx = np.nonzero(flags & 1)                              # ended steps, (env, time) order
+        tot = np.empty((N, 6), np.float64)
+        tot[:, 0] = rew.sum(axis=1, dtype=np.float64)
+        tot[:, 1:] = info[..., :5].sum(axis=1, dtype=np.float64)
+        added = 0
         if n_idx.size:
+            rows, inv = np.unique(n_idx, return_inverse=True)             # env rows with at least one ended episode
+            parts = np.concatenate([rew[rows][..., None].astype(np.float64), info[rows][..., :5].astype(np.float64)], axis=2)
+            cs = np.cumsum(parts, axis=1)                                 # [rows, T, 6]
             first = np.ones(n_idx.size, bool)
             first[1:] = n_idx[1:] != n_idx[:-1]
             prev_t = np.where(first, -1, np.roll(t_idx, 1))
-            base = np.where(prev_t[:, None] >= 0, cs[n_idx, np.maximum(prev_t, 0)], 0.0)
-            sums = cs[n_idx, t_idx] - base + np.where(first[:, None], self.carry[n_idx], 0.0)
+            base = np.where(prev_t[:, None] >= 0, cs[inv, np.maximum(prev_t, 0)], 0.0)
+            sums = cs[inv, t_idx] - base + np.where(first[:, None], self.carry[n_idx], 0.0)
             steps = (t_idx - prev_t) + np.where(first, self.steps[n_idx], 0)
             success = (flags[n_idx, t_idx] & 2) > 0
             final_conc = np.where(success, info[n_idx, t_idx, 5].astype(np.float64) * 100.0, 0.0)   # :203
@@ -37,13 +44,70 @@ class EpisodeLogger:
                 self.count += 1
                 self.rows.append([self.count, sums[k, 0], int(success[k]), sums[k, 1], sums[k, 2], sums[k, 3], sums[k, 4],
                                   sums[k, 5], int(steps[k]), final_conc[k], radius])
-        # carry what is left of each row after its last ended episode
-        last = np.full(N, -1)
-        if n_idx.size:
-            last[n_idx] = t_idx                                           # later entries overwrite: last end per env
-        tail = cs[:, -1] - np.where(last[:, None] >= 0, cs[np.arange(N), np.maximum(last, 0)], 0.0)
-        self.carry = np.where(last[:, None] >= 0, tail, self.carry + tail)
-        self.steps = np.where(last >= 0, T - 1 - last, self.steps + T)
+            added = int(n_idx.size)
+            last = np.zeros(rows.size, np.int64)
+            last[inv] = t_idx                                             # later entries overwrite: last end per env row
+            # rows with an ended episode restart their carry behind the last end
+            self.carry[rows] = cs[:, -1] - cs[np.arange(rows.size), last]
+            self.steps[rows] = T - 1 - last
+            keep = np.ones(N, bool)
+            keep[rows] = False
+            self.carry[keep] += tot[keep]
+            self.steps[keep] += T
+        else:
+            self.carry += tot
+            self.steps += T
+        return added
+
+
+class RolloutMirror:
+    """The per-iteration host copies the reference-shaped training log needs (info [N,T,10], flags, rew: 21 + 0.5 + 2 MB at
+    C3) without stalling the GPU: issued on the process's ONE side stream (uavppo/trainer.py: _side_stream) right behind the
+    rollout into a ring of pinned host slots, so they cross PCIe while the update's kernels run; the host reads slot k
+    after waiting for ITS event only, and the next rollout is fenced behind the copy (which finished milliseconds
+    earlier).  Replaces three blocking `.cpu().numpy()` calls per iteration."""
+
+    def __init__(self, trainer, slots=2):
+        import torch
+        from .trainer import _side_stream
+        self.tr = trainer
+        self.side = _side_stream(trainer.device)
+        self.names = [("info", trainer.info), ("flags", trainer.buf["flags"]), ("rew", trainer.buf["rew"])]
+        self.host = [{k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in self.names if v is not None} for _ in range(slots)]
+        self.done = [torch.cuda.Event() for _ in range(slots)]
+        self.ready = torch.cuda.Event()
+        self.pending = [False] * slots
+        self.k = 0
+
+    def fence(self):
+        """Call before the next collect(): the rollout must not overwrite buffers a copy is still reading."""
+        import torch
+        for k, p in enumerate(self.pending):
+            if p:
+                torch.cuda.current_stream().wait_event(self.done[k])
+
+    def start(self):
+        """Call right after collect(): queue the copies of this rollout; returns the slot."""
+        import torch
+        k = self.k
+        self.k = (k + 1) % len(self.host)
+        if self.pending[k]:
+            self.done[k].synchronize()           # the host is a whole ring ahead of its own reads: cannot happen in the loop below
+        self.ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ready)
+            for name, dev in self.names:
+                if dev is not None:
+                    self.host[k][name].copy_(dev, non_blocking=True)
+            self.done[k].record(self.side)
+        self.pending[k] = True
+        return k
+
+    def get(self, k):
+        """numpy views of slot k (valid until the slot is reused, `slots` rollouts later)."""
+        self.done[k].synchronize()
+        self.pending[k] = False
+        return {name: t.numpy() for name, t in self.host[k].items()}
 
 
 class RadiusTracker:

@@ -125,6 +125,8 @@ class VecPPOTrainer:
         self.bank_sources = None if bank_sources is None else torch.as_tensor(bank_sources, dtype=torch.float64).to(d).contiguous()
         self.curriculum = Curriculum() if use_curriculum else None
         self.radius, self.bonus = 50.0, 0.6
+        self.episodes_done = self.successes_done = 0     # finished episodes of the whole job (all ranks), fed by update_curriculum
+        self.last_success_bits = None
         # the curriculum's success bits leave on a side stream right behind the rollout and land in pinned host memory
         # while the update runs: the iteration's one host sync (update_curriculum) then waits for a copy that finished
         # milliseconds ago instead of draining the main stream
@@ -501,7 +503,11 @@ class VecPPOTrainer:
             self._exchange_successes()
         self._succ_ev.synchronize()
         self._succ_pending = False
-        self.curriculum.update_many(unpack_episode_successes(self._succ_host.numpy(), self.buf["flags"]))
+        bits = unpack_episode_successes(self._succ_host.numpy(), self.buf["flags"])
+        self.episodes_done += int(bits.size)            # over ALL ranks, in global (env, time) order
+        self.successes_done += int(bits.sum())
+        self.last_success_bits = bits
+        self.curriculum.update_many(bits)
         self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
 
     def train_iteration(self):
