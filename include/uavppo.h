@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 5   /* 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 6   /* 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -71,10 +71,17 @@ int uav_set_lstm_arith(uav_ctx* ctx, int mode);
 int uav_get_lstm_arith(const uav_ctx* ctx);
 /* A/B switches of the h = 256 step path (tests / measurements only; results are bit-identical or within f32 tolerance):
  *   STEP_F32  uav_lstm_fwd / _bwd at h = 256 take the generic exact-f32 step path instead of the fp16-split step kernels
- *   X_F32     a wide layer input is read as f32 rows by every workgroup instead of pre-split piece planes */
+ *   X_F32     a wide layer input is read as f32 rows by every workgroup instead of pre-split piece planes
+ *   CLUSTER   uav_lstm_fwd at h = 256 runs the persistent cluster kernel (csrc/lstm_cluster.hip: weights resident in registers,
+ *             h_t exchanged between 8 workgroups through L2; bit-identical results) instead of one launch per time step */
 #define UAV_DEBUG_STEP_F32 1u
 #define UAV_DEBUG_X_F32    2u
+#define UAV_DEBUG_CLUSTER 4u
+#define UAV_DEBUG_CLUSTER_ABL 0xf00u   /* measurement only, results are garbage: cluster kernel without 0x100 peer waits, 0x200 stash stores, 0x400 peer fetch, 0x800 products */
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags);
+/* The cluster kernels bound every wait on a peer workgroup; a wait that ran out is counted here (the launch then finishes with
+ * garbage instead of hanging).  out[0] = the count since uav_create (host pointer; synchronises `stream`).  0 on a healthy run. */
+int uav_lstm_cluster_errors(uav_ctx* ctx, unsigned* out, uav_stream stream);
 /* out[0] (f32, device) = max |x[i]| over n floats, a NaN counting as +inf: the range probe for the modes above. */
 int uav_absmax(uav_ctx* ctx, const float* x, int64_t n, float* out, uav_stream stream);
 

@@ -52,14 +52,18 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->ftab = nullptr;
     // process-level override of the default arithmetic, read here once (never on a call path)
     c->lstm_arith = getenv("UAV_LSTM_F32_MFMA") ? UAV_ARITH_F32_MFMA : (getenv("UAV_LSTM_BF16X6") ? UAV_ARITH_BF16X6 : UAV_ARITH_FP16X3);
-    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u);
-    if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
+    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u) |
+               (getenv("UAV_LSTM_CLUSTER") ? UAV_DEBUG_CLUSTER : 0u);
+    c->cluster_err = nullptr;
+    if (hipMalloc(&c->ws, ws_bytes) != hipSuccess || hipMalloc(&c->cluster_err, 256) != hipSuccess || hipMemset(c->cluster_err, 0, 256) != hipSuccess) {
+        (void)hipFree(c->ws);
         delete c;
         uav_set_error("uav_create: hipMalloc(%zu) failed", ws_bytes);
         return 1;
     }
     if (env_init_tables(c) != 0) {
         (void)hipFree(c->ws);
+        (void)hipFree(c->cluster_err);
         (void)hipFree(c->pow075);
         (void)hipFree(c->wave);
         (void)hipFree(c->ftab);
@@ -78,8 +82,15 @@ int uav_set_lstm_arith(uav_ctx* ctx, int mode) {
 int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; }
 
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags) {
-    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32)) == 0, "uav_set_debug_flags: bad argument");
+    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_CLUSTER | UAV_DEBUG_CLUSTER_ABL)) == 0, "uav_set_debug_flags: bad argument");
     ctx->debug = flags;
+    return 0;
+}
+
+int uav_lstm_cluster_errors(uav_ctx* ctx, unsigned* out, uav_stream stream) {
+    UAV_REQUIRE(ctx && out, "uav_lstm_cluster_errors: NULL argument");
+    UAV_CHECK_HIP(hipMemcpyAsync(out, ctx->cluster_err, 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    UAV_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
     return 0;
 }
 
@@ -90,6 +101,7 @@ void uav_destroy(uav_ctx* ctx) {
     for (auto& s : ctx->side)
         if (s) (void)hipStreamDestroy(s);
     (void)hipFree(ctx->ws);
+    (void)hipFree(ctx->cluster_err);
     (void)hipFree(ctx->pow075);
     (void)hipFree(ctx->wave);
     (void)hipFree(ctx->ftab);

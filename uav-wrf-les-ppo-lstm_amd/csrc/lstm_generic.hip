@@ -668,10 +668,18 @@ static bool h3_step_ok(int H) {
 }
 
 // fp16-split step path of uav_lstm_fwd for h = 256 (input projection included: the caller does NOT pre-fill the stash)
+bool lstm_c8_ok(const uav_ctx* ctx, int I, int H);
+bool lstm_c8_fits(int I, int T);
+int lstm_c8_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh, const float* keep,
+                const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn, float* cn, float* stash,
+                hipStream_t st);
+
 int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
                 const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn,
                 float* cn, float* stash, hipStream_t st) {
     constexpr int H = 256;
+    // the whole time loop as ONE persistent cluster launch (lstm_cluster.hip), bit-identical to the per-step launches below
+    if (lstm_c8_ok(ctx, I, H) && lstm_c8_fits(I, T)) return lstm_c8_fwd(ctx, x, I, w_ih, b_ih, b_hh, keep, h0, c0, w_hh, N, T, y, hn, cn, stash, st);
     const int64_t NH = (int64_t)N * H;
     int IP = (I + 31) / 32 * 32;
     IP = IP <= 32 ? 32 : (IP <= 64 ? 64 : (IP <= 128 ? 128 : 256));        // instantiated slab counts: 1, 2, 4, 8

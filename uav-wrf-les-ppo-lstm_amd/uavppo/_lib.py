@@ -40,6 +40,7 @@ SIGNATURES = {
     "uav_set_lstm_arith": (I32, [P, I32]),
     "uav_get_lstm_arith": (I32, [P]),
     "uav_set_debug_flags": (I32, [P, C.c_uint]),
+    "uav_lstm_cluster_errors": (I32, [P, P, P]),
     "uav_absmax": (I32, [P, P, I64, P, P]),
     "uav_gae": (I32, [P, P, P, P, P, I32, I32, F32, F32, I32, P, P]),
     "uav_adv_stats": (I32, [P, P, I64, P, P]),

@@ -276,12 +276,19 @@ class lstm_arith:
         set_lstm_arith(self.prev, self.device)
 
 
-DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2}
+DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "cluster": 4, "abl_wait": 0x100, "abl_stash": 0x200, "abl_fetch": 0x400, "abl_mfma": 0x800}
 
 
 def set_debug_flags(*names, device=None):
     """A/B switches of the h = 256 step path on this device's handle (include/uavppo.h, UAV_DEBUG_*); no names = none."""
     check(lib().uav_set_debug_flags(Context.get(device).handle, sum(DEBUG_FLAGS[n] for n in names)), "uav_set_debug_flags")
+
+
+def lstm_cluster_errors(device=None):
+    """Bounded waits of the h = 256 cluster kernels that ran out since the handle was created (0 on a healthy run); host sync."""
+    out = C.c_uint(0)
+    check(lib().uav_lstm_cluster_errors(Context.get(device).handle, C.byref(out), _stream()), "uav_lstm_cluster_errors")
+    return int(out.value)
 
 
 def get_lstm_arith(device=None):
