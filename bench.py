@@ -388,6 +388,22 @@ def load_traffic(tag_glob="r0*_hbm_traffic_pmc.json"):
                          "correction, MI355X_MICROARCH.md HBM), KB -> bytes, averaged per launch"}
 
 
+def load_sq_counters(which="c3"):
+    """Newest committed SQ-counter summary (tools/profile_pmc_sq.sh -> profiles/r0*_pmc_sq_<which>.json): per kernel
+    mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs) and the SQ wait / active fractions.
+    Same staleness rule as the byte counters (`_meta.csrc_sha` against today's kernel sources)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_sq_%s.json" % which)))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    meta = d.get("_meta", {})
+    now = csrc_digest()
+    return d, {"file": os.path.relpath(files[-1], ROOT), "csrc_sha": meta.get("csrc_sha"), "csrc_sha_now": now,
+               "stale": meta.get("csrc_sha") != now,
+               "calibration": "profiles/r04_b_pmc_sq_calibration.json: a saturated fp16 MFMA loop reads 0.945 at 2.03 PFLOP/s"}
+
+
 def binding_roof(bytes_moved, executed_flops, sec, flop_peak_tflops):
     """The roof that actually binds: the larger of (bytes moved / 8 TB/s) and (EXECUTED matrix flops / the peak of the
     pipe they run on).  executed_flops may be a list of (flops, peak TFLOP/s) pairs for work spread over two pipes: the
@@ -445,6 +461,17 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
                             "peak_GBps": PEAK_HBM_GBPS, "frac_algorithmic": alg_b / sec / 1e9 / PEAK_HBM_GBPS,
                             "frac_implementation": impl_b / sec / 1e9 / PEAK_HBM_GBPS,
                             "pmc_over_algorithmic": (pmc / alg_b) if pmc else None}})
+        # north_star: "evidenced by rocprof ... MFMA utilisation": the matrix pipe's busy fraction from the SQ counters, next to
+        # the analytic one (executed flops / duration / peak).  Measured under the profiler, so at the profiler's clock.
+        sq, sq_src = load_sq_counters("c3" if cfg is CONFIGS["c3"] else "none")
+        if sq and kname in sq:
+            e = sq[kname]
+            out["mfma"].update({"counter_mfma_busy_frac": e.get("mfma_busy_frac"), "counter_wait_any_frac": e.get("wait_any_frac"),
+                                "counter_wait_inst_any_frac": e.get("wait_inst_any_frac"), "counter_active_inst_any_frac": e.get("active_inst_any_frac"),
+                                "counter_source": sq_src,
+                                "counter_note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); counts every MFMA of the kernel (the "
+                                                "fp16 piece products AND the two exact-f32 MFMAs per step that form dy), hence a little above the "
+                                                "analytic fp16-only fraction"})
     # whole iteration (per GPU): 8(d) per env-step figures x units, against the measured iteration time
     I = 6 + cfg.get("trend_k", 0)
     if kind == "lstm":
@@ -501,18 +528,65 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
     return out
 
 
-def predicted_8gpu(cfg_name, cfg, N, T, ms_iter, n_params):
+def measure_exchanges(dev, n_params, own_group):
+    """Per-call time of the iteration's three exchanges through the process group that is up (RCCL; with `own_group` a ONE-rank
+    communicator brought up just for this, after the timed region): HIP events around 50 calls each, on the stream the
+    collectives are issued on.  One rank measures what a collective costs to ISSUE and run with nobody to talk to -- the floor
+    under the 8-rank latency, which only the driver's multi-GPU node can measure."""
+    import torch
+    import torch.distributed as dist
+    out = {}
+    try:
+        if own_group:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        world = dist.get_world_size()
+        grad = torch.zeros(n_params, dtype=torch.float32, device=dev)
+        stats = torch.zeros(3, dtype=torch.float64, device=dev)
+        msg = torch.zeros(4 + 16384 + 1, dtype=torch.uint8, device=dev)
+        parts = [torch.empty_like(msg) for _ in range(world)]
+        calls = {f"grad_allreduce_{n_params * 4 // 1024}KB": lambda: dist.all_reduce(grad),
+                 "adv_stats_allreduce_3_doubles": lambda: dist.all_reduce(stats),
+                 "success_allgather_16KB": lambda: dist.all_gather(parts, msg)}
+        for name, fn in calls.items():
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            out[name] = e0.elapsed_time(e1) * 1e3 / 50
+        out["world"] = world
+        out["backend"] = dist.get_backend()
+        if own_group:
+            dist.destroy_process_group()
+    except Exception as e:   # the probe must never cost the bench its line
+        out["error"] = repr(e)[:200]
+    return out
+
+
+def predicted_8gpu(cfg_name, cfg, N, T, ms_iter, n_params, measured=None):
     """What the first 8-GPU SCALE record should show, from THIS run's one-GPU iteration time: weak scaling =
     8 x the per-GPU work in (t_1 + the iteration's exchanges); the exchanges are 5 all-reduces of the flat gradient
-    (latency-bound at h=128: ASSUMED 50 us each over xGMI at 8 ranks, 120 us at C5's 3.2 MB) + one 3-double all-reduce
-    + one 16 KB all-gather on a side stream (ASSUMED 60 us together, the all-gather overlapped)."""
-    ar_us = 50.0 if n_params * 4 < (1 << 20) else 120.0
-    t_x = (5 * ar_us + 60.0) * 1e-3
-    weak = 8 * N * T / ((ms_iter + t_x) * 1e-3)
-    out = {"from_ms_per_step_1gpu": ms_iter, "assumed_exchange_ms_per_iteration": t_x,
-           "weak_8gpu_env_steps_per_s": weak, "weak_8gpu_over_1gpu": weak / (N * T / (ms_iter * 1e-3)),
+    (latency-bound over xGMI at 8 ranks: a RANGE of 50-150 us each, 120-300 us at C5's 3.2 MB; never measured, no 8-GPU node)
+    + one 3-double all-reduce + one 16 KB all-gather on a side stream (30-90 us together, the all-gather overlapped).
+    `measured_one_rank_us`: what each exchange costs through a one-rank RCCL communicator on this GPU (the issue floor)."""
+    small = n_params * 4 < (1 << 20)
+    lo, hi = (50.0, 150.0) if small else (120.0, 300.0)
+    t_lo, t_hi = (5 * lo + 30.0) * 1e-3, (5 * hi + 90.0) * 1e-3
+    one = N * T / (ms_iter * 1e-3)
+    w_hi, w_lo = 8 * N * T / ((ms_iter + t_lo) * 1e-3), 8 * N * T / ((ms_iter + t_hi) * 1e-3)
+    out = {"from_ms_per_step_1gpu": ms_iter, "assumed_exchange_ms_per_iteration": [t_lo, t_hi],
+           "assumed_us_per_gradient_allreduce_8_ranks": [lo, hi],
+           "weak_8gpu_env_steps_per_s": [w_lo, w_hi], "weak_8gpu_over_1gpu": [w_lo / one, w_hi / one],
            "note": "sequence kernels take T x (one workgroup's step latency) whatever the number of workgroups up to one per CU, "
                    "so splitting a config's envs over more GPUs (strong scaling) leaves the iteration time nearly flat"}
+    if measured:
+        out["measured_one_rank_us"] = measured
     if cfg_name == "c4":
         out["vs_one_gpu_holding_all_8192_envs"] = ("one GPU with 8192 envs runs two 16-env tiles per CU, ~2 x the C3 iteration (~14 ms, ~75 M "
                                                    "env-steps/s): 8 GPUs at 1024 envs each are predicted ~2.8-3 x that, NOT north_star's >= 6 x")
@@ -547,6 +621,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong-phase", action="store_true", help="launcher mode: skip the second (strong-scaling) set of ranks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--no-exchange-probe", action="store_true", help="skip timing the iteration's collectives after the timed region")
     ap.add_argument("--headline-timeout", type=float, default=0.0, help="launcher mode: seconds before the headline rank set is terminated (0 = config-dependent default)")
     args = ap.parse_args()
 
@@ -627,7 +702,12 @@ def main():
     # (the strong-scaling shape is NOT timed in these processes: launch() runs it in a second set of fresh ranks; under
     #  torchrun ask for it with --scaling strong)
     if world == 1:
-        out["predicted_8gpu"] = predicted_8gpu(args.config, cfg, N, T, dt / args.steps * 1e3, tr.policy.num_params())
+        measured = None
+        if not args.no_exchange_probe:
+            measured = measure_exchanges(dev, tr.policy.num_params(), own_group=not dist.is_initialized())
+        out["predicted_8gpu"] = predicted_8gpu(args.config, cfg, N, T, dt / args.steps * 1e3, tr.policy.num_params(), measured)
+    elif not args.no_exchange_probe:
+        out["measured_exchange_us"] = measure_exchanges(dev, tr.policy.num_params(), own_group=False)
     if rehearsal:
         out["rehearsal"] = f"one-rank {args.backend} communicator, all exchanges issued (UAVPPO_FORCE_COLLECTIVES=1)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -77,7 +77,8 @@ int uav_get_lstm_arith(const uav_ctx* ctx);
 #define UAV_DEBUG_STEP_F32 1u
 #define UAV_DEBUG_X_F32    2u
 #define UAV_DEBUG_CLUSTER 4u
-#define UAV_DEBUG_CLUSTER_ABL 0xf00u   /* measurement only, results are garbage: cluster kernel without 0x100 peer waits, 0x200 stash stores, 0x400 peer fetch, 0x800 products */
+#define UAV_DEBUG_CLUSTER_ABL 0x1f00u  /* measurement only: cluster kernel without 0x100 peer waits, 0x200 stash stores, 0x400 peer fetch, 0x800 products (garbage results);
+                                          0x1000: hand-off payload by write-through stores even when a cluster sits on one XCD (same results) */
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags);
 /* The cluster kernels bound every wait on a peer workgroup; a wait that ran out is counted here (the launch then finishes with
  * garbage instead of hanging).  out[0] = the count since uav_create (host pointer; synchronises `stream`).  0 on a healthy run. */

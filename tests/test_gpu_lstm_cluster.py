@@ -23,12 +23,12 @@ def _case(N, T, I, seed, mask_p=0.15):
     return [t.to(DEV).contiguous() for t in (x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)]
 
 
-def _both(args):
+def _both(args, *extra):
     from uavppo import ops
     ops.set_debug_flags()
     ref = ops.lstm_fwd(*args)
     torch.cuda.synchronize()
-    ops.set_debug_flags("cluster")
+    ops.set_debug_flags("cluster", *extra)
     try:
         got = ops.lstm_fwd(*args)
         torch.cuda.synchronize()
@@ -56,6 +56,17 @@ def cluster_on():
     ops.set_debug_flags("cluster")
     yield
     ops.set_debug_flags()
+
+
+@pytest.mark.parametrize("N,T,I", [(4096, 9, 8), (4096 + 64, 6, 256), (333, 12, 8)])
+def test_cluster_forward_hand_off_by_write_through_stores(N, T, I):
+    """The hand-off payload normally stays in the L2 of the XCD a cluster was MEASURED to sit on (plain stores, L1-bypassing
+    loads); clusters spread over several XCDs use write-through (sc1) stores.  Force that form: same bits."""
+    from uavppo import ops
+    args = _case(N, T, I, seed=N + T + I)
+    (y0, hn0, cn0, st0), (y1, hn1, cn1, st1) = _both(args, "cluster_sc1")
+    assert ops.lstm_cluster_errors() == 0
+    assert torch.equal(y0, y1) and torch.equal(hn0, hn1) and torch.equal(cn0, cn1) and torch.equal(st0, st1)
 
 
 def test_cluster_forward_matches_torch_lstm(cluster_on):

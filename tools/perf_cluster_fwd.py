@@ -24,7 +24,7 @@ for I in (8, 256):
              "c-nomfma": ["abl_mfma"], "c-nowait-nostash": ["abl_wait", "abl_stash"], "c-only-mfma": ["abl_wait", "abl_stash", "abl_fetch"],
              "c-nothing": ["abl_wait", "abl_stash", "abl_fetch", "abl_mfma"]}
     if len(sys.argv) > 3 and sys.argv[3] == "short":
-        MODES = {k: MODES[k] for k in ("per-step", "cluster")}
+        MODES = {"per-step": None, "cluster": [], "cluster-sc1": ["cluster_sc1"]}
     for mode, fl in MODES.items():
         ops.set_debug_flags(*([] if fl is None else ["cluster"] + fl))
         for _ in range(2):
@@ -50,8 +50,8 @@ for I in (8, 256):
         fn = _lib.lib().uav_c8_profile
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         fn(ops.Context.get(torch.device(dev)).handle, out)
-        names = ["top: masks + c_prev/h_prev stores", "products", "barrier 1", "x loads + cell + h stores", "vmcnt(0)", "barrier 2", "flag + x planes",
-                 "poll", "barrier 3", "peer fetch", "stash stores", "barrier 4"]
+        names = ["top: masks + x loads", "products + cell + h stores", "peer fetch: issue", "peer fetch: latency", "publish vmcnt(0)", "barrier 2", "flag + x planes",
+                 "poll", "barrier 3", "peer fetch: LDS stores", "stash stores", "barrier 4"]
         steps = T * (((N + 63) // 64 + 31) // 32)
         tot = sum(out)
         print(f"I={I}: cycles per tile-step of wave 0, workgroup 0 ({steps} tile-steps; total {tot / steps:.0f}):")

@@ -33,7 +33,9 @@ struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived c
 // ---- f64 log, cos/sin and exp for the procedural field and the Box-Muller normals, table-driven.  The arguments are not
 // arbitrary doubles: log is needed of a 24-bit integer, cos/sin of a 24-bit fraction of a turn, exp of -d^2 / 2 sigma^2 in
 // [-300, 0].  A table entry (host libm, correctly rounded) + a few polynomial terms of a remainder below 2^-12 / 2 pi / 1024 /
-// ln 2 / 128 gives the value to ~3e-16 -- libm accuracy, the oracle's numpy calls agree to 1e-15 -- in a third of the
+// ln 2 / 128 gives the value to an ABSOLUTE error of ~1e-15 (relative ~3e-16 except -ln u just past the near / far switch of
+// ft_neglog_u24, where ~2.4e-4 is formed from terms of ~0.69: relative 5e-13, absolute still 1e-15) -- the oracle's numpy calls
+// agree to 1e-15 -- in a third of the
 // instructions of the general-purpose routines, which sat on the chain of the wave that paces the fused rollouts.
 constexpr int FT_LOG = 0, FT_LOG_N = 4096;            // log(1 + i / 4096)
 constexpr int FT_CS = FT_LOG + FT_LOG_N, FT_CS_N = 1024;   // cos, sin (2 pi i / 1024), interleaved

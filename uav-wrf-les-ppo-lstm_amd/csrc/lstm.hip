@@ -1362,9 +1362,6 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_h3k_kernel(
                 split2h(__builtin_amdgcn_ldexpf(dg[q][r], ex), p0, p1);
                 bp[q >> 1][0][4 * (q & 1) + r] = p0; bp[q >> 1][1][4 * (q & 1) + r] = p1;
             }
-            if (live)
-                *reinterpret_cast<float4*>(dgates + (srow + t) * (4 * H) + q * H + uo) =
-                    float4{dg[q][0], dg[q][1], dg[q][2], dg[q][3]};
         }
         X6_PROF_DEP(bp[1][1]); X6_PROF_DEP(bp[0][0]);
         X6_PROF_MARK(3);
@@ -1379,6 +1376,14 @@ __global__ __launch_bounds__(H * 4) void lstm_bwd_h3k_kernel(
                 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[m][sb][0], bp[sb][1], a1, 0, 0, 0);
             }
             part[(m * NW + w) * 64 + lane] = (a0 + a1 * H3_LO) * unscale;
+        }
+        // the step's four dG stores behind the products (same place in the wave's issue order as before: between the ring DMA
+        // and the small piece, so the counted waits are unchanged): they queued in front of the products for the slowest
+        // wave, which everybody then waited for at b1; here they drain under the partial-sum reduce
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dgates + (srow + t) * (4 * H) + q * H + uo) = float4{dg[q][0], dg[q][1], dg[q][2], dg[q][3]};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         X6_PROF_MARK(4);

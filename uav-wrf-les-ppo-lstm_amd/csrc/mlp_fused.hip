@@ -477,6 +477,7 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P_arg, EnvBl
     __shared__ unsigned short vis[MT * NVIS];
     __shared__ EnvState es_s[MT];
     __shared__ double env_tab[ENV_LDS_TABLE_DOUBLES];            // pow(vc, 0.75) | ripple factors (env_core.h)
+    static_assert(ROLL_LDS + sizeof(vis) + sizeof(es_s) + sizeof(env_tab) <= 160 * 1024, "rollout_mlp_kernel: LDS over 160 KB per workgroup");
     EnvParams P = P_arg;
     env_tables_to_lds(P, env_tab, threadIdx.x, 512);
 

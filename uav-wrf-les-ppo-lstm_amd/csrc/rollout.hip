@@ -101,6 +101,10 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P_arg, En
     __shared__ float trs[4 * RMT * 8];                            // the step's transition, parked by wave 0, stored by the last gate wave
     __shared__ __attribute__((aligned(16))) f32x4 acc0[4 * 64];  // wave 0's next-step accumulators, computed by the gate waves
     __shared__ double env_tab[ENV_LDS_TABLE_DOUBLES];            // pow(vc, 0.75) | ripple factors (env_core.h)
+    // one workgroup per CU at h = 128 (~145 KB with the 66 KB of env tables; h = 64: ~111 KB): any growth of a table or of the
+    // geometry must fail HERE, not as a launch error on the GPU box
+    static_assert(G::LDS + sizeof(xbuf) + sizeof(kbuf) + sizeof(hd) + sizeof(vis) + sizeof(es_s) + sizeof(trs) + sizeof(acc0) +
+                      sizeof(env_tab) <= 160 * 1024, "rollout_lstm_kernel: LDS over 160 KB per workgroup");
     EnvParams P = P_arg;
     env_tables_to_lds(P, env_tab, threadIdx.x, H * 4);
 

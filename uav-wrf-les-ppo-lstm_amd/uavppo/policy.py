@@ -165,7 +165,7 @@ class LSTMActorCritic(_FlatPolicy):
         saved = []
         work = work or {}
         heads = None
-        if self._interleaved_forward_ok(N, work):
+        if self._interleaved_forward_ok(N, work, T):
             # stacked h = 256 layers: the steppers of the rollout (weights split once, the layer above reading the piece planes
             # of the layer below) step all layers time step by time step -- uav_lstm_fwd layer by layer converts the layer
             # below's whole output to piece planes first (split_x_kernel) and re-splits the weights per call; same kernels,
@@ -217,15 +217,20 @@ class LSTMActorCritic(_FlatPolicy):
         N, T, H = x.shape
         return x.view(N * T, H)
 
-    def _interleaved_forward_ok(self, N, work):
+    def _interleaved_forward_ok(self, N, work, T=None):
         """The update's forward pass can run on the rollout's steppers: a stack of h = 256 layers on the fp16-split step path,
-        steppers already built for this many envs, and the [N, T] arrays they fill present."""
+        steppers already built for this many envs, and the [N, T] arrays they fill present WITH this call's T (a caller whose
+        obs has another horizon than the preallocated work arrays takes the uav_lstm_fwd layer loop, which allocates).
+        NOTE: that path runs on the ROLLOUT's steppers and overwrites their hn / cn and piece planes; a rollout copies its
+        final state out (trainer._collect_stepwise_lstm) before any update can run, and begin_steps() re-seeds them."""
         if not getattr(self, "use_stepper_forward", True) or self.num_layers < 2 or self.hidden != 256:
             return False
         sp = getattr(self, "_steppers", None)
         if sp is None or sp[0].N != N or ops.lstm_bwd_caps(self.device, self.obs_dim, 256) == 0:
             return False
         return all(work.get(f"y{l}") is not None and work[f"y{l}"].shape[0] == N and work.get(f"stash{l}") is not None
+                   and work[f"stash{l}"].shape[0] == N
+                   and (T is None or (work[f"y{l}"].shape[1] == T and work[f"stash{l}"].shape[1] == T))
                    for l in range(self.num_layers))
 
     def steppers(self, N, device):
