@@ -106,3 +106,94 @@ def test_cluster_forward_is_deterministic_and_tiles_are_independent(cluster_on):
     y3, hn3, cn3, st3 = ops.lstm_fwd(*sub)
     assert torch.equal(y[sl], y3) and torch.equal(st[sl], st3) and torch.equal(cn[sl], cn3)
     assert ops.lstm_cluster_errors() == 0
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def _bwd_case(N, T, I, seed, top):
+    """A layer's forward (per-step path) and an upstream gradient: dy [N,T,H], or for the top layer dheads [N,T,6] + w_head."""
+    from uavppo import ops
+    args = _case(N, T, I, seed, mask_p=0.1)
+    ops.set_debug_flags()
+    y, hn, cn, stash = ops.lstm_fwd(*args)
+    g = torch.Generator("cpu").manual_seed(seed + 1)
+    up = {}
+    if top:
+        up["dheads"] = (torch.randn(N, T, 6, generator=g) / (N * T)).to(DEV)
+        up["w_head"] = (torch.randn(6, H, generator=g) * 0.1).to(DEV)
+    else:
+        up["dy"] = (torch.randn(N, T, H, generator=g) / (N * T)).to(DEV)
+    return args, y, stash, up
+
+
+def _run_bwd(args, y, stash, up, need_dx, *flags, arith="fp16x3"):
+    from uavppo import ops
+    x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh = args
+    ops.set_debug_flags(*flags)
+    ops.set_lstm_arith(arith)
+    try:
+        r = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, need_dx=need_dx, **up)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_debug_flags()
+        ops.set_lstm_arith("fp16x3")
+    return {k: r[k].clone() for k in ("dgates", "dh0", "dc0", "dx", "dw_hh", "db") if r.get(k) is not None}
+
+
+@pytest.mark.parametrize("N,T,I,top", [(64, 5, 8, False), (100, 7, 8, True), (64, 6, 256, False), (150, 5, 256, True),
+                                       (4096, 4, 8, False), (4096 + 64, 3, 256, True), (2048 + 37, 5, 256, False)])
+def test_cluster_backward_has_the_per_step_paths_accuracy(N, T, I, top):
+    """The cluster BPTT scales an env's gate gradients per WORKGROUP (128 gate rows) instead of per env (1024), so its products
+    round differently from the per-step kernels': judged against the exact-f32-MFMA path, its error must stay within twice
+    theirs (+ f32 noise).  dgates of the LAST step involve no product: bit-identical.  No bounded wait may have run out."""
+    from uavppo import ops
+    args, y, stash, up = _bwd_case(N, T, I, seed=N + 3 * T + I, top=top)
+    need_dx = I == 256
+    up_ref = up if not top else {"dy": (up["dheads"].reshape(-1, 6) @ up["w_head"]).reshape(N, T, H)}      # (that path takes dy only)
+    ref = _run_bwd(args, y, stash, up_ref, need_dx, arith="f32_mfma")
+    step = _run_bwd(args, y, stash, up, need_dx)
+    e0 = ops.lstm_cluster_errors()
+    clu = _run_bwd(args, y, stash, up, need_dx, "cluster")
+    assert ops.lstm_cluster_errors() == e0
+    assert torch.equal(clu["dgates"][:, T - 1], step["dgates"][:, T - 1])
+    for k in ref:
+        assert torch.isfinite(clu[k]).all(), k
+        scale = ref[k].abs().max().item()
+        es, ec = (step[k] - ref[k]).abs().max().item(), (clu[k] - ref[k]).abs().max().item()
+        assert ec <= 2.0 * es + 2e-6 * scale, (k, ec, es, scale)
+
+
+def test_cluster_backward_stack_equals_layer_by_layer_and_is_deterministic():
+    """uav_lstm_bwd_stack on the cluster kernels (top layer from dheads, dx handed down) == one uav_lstm_bwd per layer, bit for
+    bit, twice."""
+    from uavppo import ops
+    N, T = 300, 6
+    a1, y1, st1, _ = _bwd_case(N, T, 8, seed=41, top=False)
+    a2 = _case(N, T, 256, seed=42, mask_p=0.1)
+    a2[0], a2[1] = y1, a1[1]
+    ops.set_debug_flags()
+    y2, _, _, st2 = ops.lstm_fwd(*a2)
+    g = torch.Generator("cpu").manual_seed(7)
+    dheads = (torch.randn(N, T, 6, generator=g) / (N * T)).to(DEV)
+    w_head = (torch.randn(6, H, generator=g) * 0.1).to(DEV)
+    keep = a1[1]
+
+    def stack():
+        layers = [dict(stash=st2, w_hh=a2[5], w_ih=a2[4], dgates=torch.empty(N, T, 4 * H, device=DEV), dx=torch.empty(N, T, H, device=DEV)),
+                  dict(stash=st1, w_hh=a1[5], w_ih=None, dgates=torch.empty(N, T, 4 * H, device=DEV), dx=None)]
+        ops.lstm_bwd_stack(layers, keep, dheads=dheads, w_head=w_head)
+        torch.cuda.synchronize()
+        return layers
+    ops.set_debug_flags("cluster")
+    try:
+        la, lb = stack(), stack()
+        top = ops.lstm_bwd(a2[0], keep, st2, a2[4], a2[5], y2, a2[2], dheads=dheads, w_head=w_head, need_dx=True)
+        low = ops.lstm_bwd(a1[0], keep, st1, a1[4], a1[5], y1, a1[2], dy=top["dx"])
+        torch.cuda.synchronize()
+    finally:
+        ops.set_debug_flags()
+    for l in range(2):
+        assert torch.equal(la[l]["dgates"], lb[l]["dgates"])
+    assert torch.equal(la[0]["dx"], lb[0]["dx"])
+    assert torch.equal(la[0]["dgates"], top["dgates"]) and torch.equal(la[0]["dx"], top["dx"])
+    assert torch.equal(la[1]["dgates"], low["dgates"])
+    assert ops.lstm_cluster_errors() == 0

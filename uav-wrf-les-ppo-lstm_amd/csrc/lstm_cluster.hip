@@ -527,6 +527,403 @@ extern "C" int uav_c8_profile(uav_ctx* ctx, unsigned long long* out12) {
 }
 #endif
 
+// ================================================================================================ backward (BPTT)
+// One launch = the whole BPTT of one h = 256 layer, same clusters as the forward: a workgroup owns the gate rows of its 32 units.
+//   per step t (descending), per 64-env tile:
+//     cell backward for (env, 8 units) per thread -- stash rows, dy (or dheads . W_head for the top layer) and the dgates rows are
+//       whole 128-byte lines per (env, gate), four lanes each;
+//     dG (this workgroup's 128 gate rows of the tile) block-scaled per env by a power of two (largest magnitude in [2^13, 2^14),
+//       exact), split into two fp16 pieces, parked in LDS as the MFMA B operand;
+//     partial dh_{t-1}[all 256 units] = W_hh[own 128 rows]^T dG: wave w forms output units 64 w .. + 63 over the whole K = 128,
+//       weights resident (W_hh^T slices: 128 AGPRs per wave; a stacked layer also W_ih^T for dx_t: another 128);
+//     the partial tiles go to the workgroups that OWN those units through the same L2 hand-off as the forward's h_t (f32, 8 KB
+//       per (owner, source) pair and step); an owner sums its eight source blocks in a fixed order (deterministic), masks by
+//       keep[:, t] (folded into the scale) and has dh_{t-1} of its units; dx_t likewise, written to HBM by the owner.
+// The per-env scale is per WORKGROUP here (the per-step kernels scale an env's whole 1024-row dG by one power of two), so the
+// products round differently: equal to the per-step path to f32 accuracy (tests/test_gpu_lstm_cluster.py), not bit for bit.
+struct C8BwdArgs {
+    const float* keep;     // [N][T] or null
+    const float* stash;    // [N][T][6H]
+    const float* w_hh;     // [4H][H]
+    const float* w_ih;     // [4H][H] (dx only)
+    const float* dy;       // [N][T][H], or null: the top layer forms dy = dheads . w_head itself
+    const float* dheads;   // [N*T][NH]
+    const float* w_head;   // [NH][H]
+    const float* dhn;      // [N][H] or null
+    const float* dcn;
+    float* dgates;         // [N][T][4H]
+    float* dx;             // [N][T][H] or null
+    float* dh0;
+    float* dc0;
+    float* xp;             // partial exchange [2][ncl][G owners][G sources][E][UC] f32 (dh), then the same for dx
+    unsigned* flags;
+    unsigned* err;
+    int NH, N, T, ntile, ncl;
+    unsigned xp_bytes, xq_off;     // bytes of the whole exchange buffer; byte offset of the dx half
+    unsigned abl;
+};
+
+namespace c8 {
+constexpr int RSG = 128 + 8;              // halves per env row of a dG piece plane
+constexpr int GPLANE = E * RSG;
+constexpr int PBLK = E * UC;              // floats per (owner, source) block of the partial exchange (8 KB)
+}  // namespace c8
+
+// TOP: the layer under the heads (dy = dheads . w_head formed here); compile-time, so that the rows loaded a step ahead reach the
+// next iteration in the registers they were loaded into (a run-time `if (dy)` merges two definitions: copies, hence a wait on the spot)
+template <bool DX, bool TOP>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_c8_kernel(const C8BwdArgs a) {
+    using namespace c8;
+#ifdef UAV_C8_PROFILE
+    unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    unsigned short* gpl = lds;                                              // dG pieces [2][E][RSG]
+    float* isc_h = reinterpret_cast<float*>(lds + 2 * GPLANE);              // [E] inverse scale x keep[:, t]  (dh_{t-1})
+    float* isc_x = isc_h + E;                                               // [E] inverse scale               (dx_t)
+    float* whd = isc_x + E;                                                 // [8][UC] head weights of the own units (top layer)
+    f16x8* wxl = reinterpret_cast<f16x8*>(whd + 8 * UC);                    // DX: row tiles 2, 3 of W_ih^T per wave [2][4 waves][4 s][2][64 lanes]
+    unsigned* kb = reinterpret_cast<unsigned*>(wxl + (DX ? 2 * 4 * 4 * 2 * 64 : 0));  // keep != 0 bits [T][2]
+    __shared__ int s_dead, s_same;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, rg = lane >> 4;
+    const int b = blockIdx.x;
+    const int cl = (b >> 6) * 8 + (b & 7), cu = (b >> 3) & 7;
+    if (cl >= a.ncl) return;
+    const int T = a.T, N = a.N, NH = a.NH;
+    const int ev = tid >> 2, q8 = (tid & 3) * 8;            // element view: env ev of the tile, own units q8 .. q8 + 7
+    const int ug = UC * cu + q8;                           // their global index
+    if (tid == 0) s_dead = 0;
+
+    // ---- resident weights (A operand): rows = the 64 output units of this wave, K = this workgroup's 128 gate rows in the
+    // order (gate s, own unit): lane (j, rg) of row tile rt feeds output unit 64 w + 16 rt + j, k = 32 s + 8 rg + i
+    f16x8 wa[4][4][2];
+    f16x8 wxa[2][4][2];                // (DX only; dead otherwise) row tiles 0, 1: 2 x 128 weight registers would take EVERY AGPR and the
+                                       // compiler then spilled 40 of them to scratch; row tiles 2, 3 are read from LDS (16 reads per step)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = 64 * w + 16 * rt + j;
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = a.w_hh[(size_t)(s * H + UC * cu + 8 * rg + i) * H + col];
+            c8_split8(v, wa[rt][s][0], wa[rt][s][1]);
+            asm volatile("" : "+a"(wa[rt][s][0]));
+            asm volatile("" : "+a"(wa[rt][s][1]));
+            if (DX) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = a.w_ih[(size_t)(s * H + UC * cu + 8 * rg + i) * H + col];
+                if (rt < 2) {
+                    c8_split8(v, wxa[rt][s][0], wxa[rt][s][1]);
+                    asm volatile("" : "+a"(wxa[rt][s][0]));
+                    asm volatile("" : "+a"(wxa[rt][s][1]));
+                } else {
+                    f16x8 p0, p1;
+                    c8_split8(v, p0, p1);
+                    wxl[((((rt - 2) * 4 + w) * 4 + s) * 2 + 0) * 64 + lane] = p0;
+                    wxl[((((rt - 2) * 4 + w) * 4 + s) * 2 + 1) * 64 + lane] = p1;
+                }
+            }
+        }
+    if (TOP)
+        for (int i = tid; i < 8 * UC; i += 256) whd[i] = (i / UC < NH) ? a.w_head[(size_t)(i / UC) * H + UC * cu + (i % UC)] : 0.f;
+
+    const __amdgpu_buffer_rsrc_t xp_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, a.xp_bytes, 0x00020000);
+    unsigned* my_flag = a.flags + (size_t)(cl * G + cu) * FLAG_STRIDE;
+    const unsigned* peer_flag = a.flags + (size_t)(cl * G + (lane & 7)) * FLAG_STRIDE;
+    bool dead = (a.abl & 1u) != 0;
+    unsigned gstep = 0;
+    bool same_xcd = false;
+    {   // placement of the cluster, measured (see the forward kernel)
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 0xfu;
+        if (tid == 0) __hip_atomic_store(my_flag + 1, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+            unsigned v = lane < G ? 0u : 1u, spins = 0;
+            while (true) {
+                if (v == 0u) v = __hip_atomic_load(peer_flag + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64(v == 0u) == 0ull) break;
+                if (++spins > SPIN_LIMIT) {
+                    if (lane == 0) { atomicAdd(a.err, 1u); s_dead = 1; }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool mine = lane >= G || v == xcc + 1u;
+            if (lane == 0) s_same = (__builtin_amdgcn_ballot_w64(!mine) == 0ull && !(a.abl & 0x10u)) ? 1 : 0;
+        }
+        __syncthreads();
+        same_xcd = s_same != 0;
+        dead = dead || s_dead != 0;
+    }
+
+    for (int tile = cl; tile < a.ntile; tile += a.ncl) {
+        const int e0 = tile * E;
+        const int n = e0 + ev, nc = min(n, N - 1);
+        const bool live = n < N;
+        __syncthreads();
+        for (int t = w; t < T; t += 4) {
+            const bool kv = a.keep ? a.keep[(size_t)min(e0 + lane, N - 1) * T + t] != 0.f : true;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(kv);
+            if (lane == 0) { kb[2 * t] = (unsigned)m; kb[2 * t + 1] = (unsigned)(m >> 32); }
+        }
+        float dh_rec[8], dc_nx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            dh_rec[i] = a.dhn ? a.dhn[(size_t)nc * H + ug + i] : 0.f;
+            dc_nx[i] = a.dcn ? a.dcn[(size_t)nc * H + ug + i] : 0.f;
+        }
+        // the step's inputs of this thread's (env, 8 units): gates i f g o, c_prev (stash row) and dy -- or the row's dheads
+        f32x4 sv[5][2], dyv[2];          // (kept in the loads' own vector type: a conversion here would wait for them on the spot)
+        float dhd[8];
+        auto load_step = [&](int t) {
+            const size_t row = (size_t)nc * T + t;
+            const float* sp = a.stash + row * (6 * H) + ug;
+#pragma unroll
+            for (int g = 0; g < 5; ++g) {
+                // (nontemporal: streamed once -- keep the L2 for the hand-off blocks)
+                sv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + g * H));
+                sv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(sp + g * H + 4));
+            }
+            if (!TOP) {
+                dyv[0] = *reinterpret_cast<const f32x4*>(a.dy + row * H + ug);
+                dyv[1] = *reinterpret_cast<const f32x4*>(a.dy + row * H + ug + 4);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 8; ++h) dhd[h] = a.dheads[row * NH + min(h, NH - 1)];
+            }
+        };
+        load_step(T - 1);
+        __syncthreads();
+
+#ifdef UAV_C8_PROFILE
+        last_ = __builtin_readcyclecounter();
+#endif
+        for (int t = T - 1; t >= 0; --t, ++gstep) {
+            const uint2 mk = *reinterpret_cast<const uint2*>(kb + 2 * t);
+            const float kp = (((ev >> 5) ? mk.y : mk.x) >> (ev & 31)) & 1u ? 1.f : 0.f;
+            // ---- cell backward (train_ppo2.0.py:85's autograd through nn.LSTM's cell, as cell_bwd_h3_kernel)
+            float gi[8], gf[8], gg[8], go[8], cp[8], dyr[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gi[4 * h + r] = sv[0][h][r]; gf[4 * h + r] = sv[1][h][r]; gg[4 * h + r] = sv[2][h][r]; go[4 * h + r] = sv[3][h][r];
+                    cp[4 * h + r] = sv[4][h][r];
+                }
+            }
+            if (!TOP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { dyr[r] = dyv[0][r]; dyr[4 + r] = dyv[1][r]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dyr[i] = 0.f;
+                for (int h = 0; h < NH; ++h) {
+                    const float d = dhd[h];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dyr[i] = fmaf(d, whd[h * UC + q8 + i], dyr[i]);
+                }
+            }
+            float g4[4][8], m = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dh = dyr[i] + dh_rec[i];
+                const float c = gf[i] * cp[i] + gi[i] * gg[i];
+                const float tch = fast_tanh(c);
+                const float dc = dh * go[i] * (1.0f - tch * tch) + dc_nx[i];
+                g4[0][i] = dc * gg[i] * gi[i] * (1.0f - gi[i]);
+                g4[1][i] = dc * cp[i] * gf[i] * (1.0f - gf[i]);
+                g4[2][i] = dc * gi[i] * (1.0f - gg[i] * gg[i]);
+                g4[3][i] = dh * tch * go[i] * (1.0f - go[i]);
+                dc_nx[i] = dc * gf[i] * kp;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) m = fmaxf(m, fabsf(g4[g][i]));
+            }
+            C8_STAMP(0);
+            if (live && !(a.abl & 2u)) {
+                float* gp = a.dgates + ((size_t)n * T + t) * (4 * H) + ug;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    __builtin_nontemporal_store(f32x4{g4[g][0], g4[g][1], g4[g][2], g4[g][3]}, reinterpret_cast<f32x4*>(gp + g * H));
+                    __builtin_nontemporal_store(f32x4{g4[g][4], g4[g][5], g4[g][6], g4[g][7]}, reinterpret_cast<f32x4*>(gp + g * H + 4));
+                }
+            }
+            C8_STAMP(1);
+            // the env's 128 values of this workgroup: max over its four lanes; power of two 2^e with m 2^e in [2^13, 2^14)
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            int ex = 0;
+            if (m > 0.f && m < 3.0e38f) {
+                ex = 13 - (int)((__float_as_uint(m) >> 23) & 0xff) + 127;
+                ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+            }
+            const float sc = __uint_as_float((unsigned)(127 + ex) << 23), isc = __uint_as_float((unsigned)(127 - ex) << 23);
+            if ((tid & 3) == 0) { isc_h[ev] = isc * kp; isc_x[ev] = isc; }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = g4[g][i] * sc;
+                f16x8 p0, p1;
+                c8_split8(v, p0, p1);
+                *reinterpret_cast<f16x8*>(gpl + ev * RSG + 32 * g + q8) = p0;
+                *reinterpret_cast<f16x8*>(gpl + GPLANE + ev * RSG + 32 * g + q8) = p1;
+            }
+            C8_STAMP(2);
+            lds_barrier();                   // B1: the tile's dG pieces and scales are in LDS
+            C8_STAMP(3);
+            // next step's rows NOW: their HBM latency passes under the products, and nothing slow is in flight when wave 0 polls
+            // (a poll's flag load returns behind every older load of its wave: issued after the flag they cost 12 k cycles a step)
+            if (t > 0) load_step(t - 1);
+
+            // ---- partial dh_{t-1} (and dx_t) of ALL 256 units from this workgroup's 128 gate rows
+            const unsigned par = (gstep & 1u) * (unsigned)(a.ncl * G * G * PBLK);
+            auto product = [&](auto wfrag, const float* iscale, unsigned half_off) {
+#pragma unroll
+              for (int ch = 0; ch < NCT; ch += 2) {      // two column tiles at a time: 64 accumulator registers beside the rows in flight
+                f32x4 acc[4][NCT], acl[4][NCT];           // (only [.][ch], [.][ch + 1] are live)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int c = ch; c < ch + 2; ++c) acc[rt][c] = acl[rt][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(a.abl & 8u)) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        f16x8 w0[4], w1[4];
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt) wfrag(rt, s, w0[rt], w1[rt]);
+#pragma unroll
+                        for (int c = ch; c < ch + 2; ++c) {
+                            const unsigned short* gr = gpl + (16 * c + j) * RSG + 32 * s + 8 * rg;
+                            const f16x8 b0 = c8_ldh8(gr), b1 = c8_ldh8(gr + GPLANE);
+#pragma unroll
+                            for (int rt = 0; rt < 4; ++rt) {
+                                acl[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[rt], b0, acl[rt][c], 0, 0, 0);
+                                acc[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[rt], b0, acc[rt][c], 0, 0, 0);
+                                acl[rt][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[rt], b1, acl[rt][c], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                // lane (j, rg) of tile (rt, c): output units 64 w + 16 rt + 4 rg .. + 3 of env 16 c + j.  A row-tile PAIR (rt even, odd)
+                // is the 32 units of one owner: 128 bytes per env, of which a lane holds two 16-byte quarters 64 bytes apart.  The
+                // odd tile's quarters are exchanged between lanes j and j ^ 8, so that ONE store instruction
+                // writes whole 128-byte lines of 8 envs (lanes j < 8: the even tile's quarter of env j; lanes j >= 8: the odd tile's
+                // quarter of env j - 8) and a second one the other 8 envs -- instead of four instructions of 64-byte half lines
+#pragma unroll
+                for (int c = ch; c < ch + 2; ++c) {
+                    const float is = iscale[16 * c + j];
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        const f32x4 ve = (acc[2 * rp][c] + acl[2 * rp][c] * H3_LO) * is;
+                        const f32x4 vo = (acc[2 * rp + 1][c] + acl[2 * rp + 1][c] * H3_LO) * is;
+                        u32x4 rot;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            rot[r] = __builtin_bit_cast(unsigned, __shfl_xor(vo[r], 8, 64));      // (a DPP row_ror:8 of these MFMA results read wrong values)
+                        const u32x4 eb = __builtin_bit_cast(u32x4, ve);
+                        const int owner = 2 * w + rp;
+                        const unsigned blk = par + (unsigned)(((cl * G + owner) * G + cu) * PBLK);
+                        const bool lo8 = j < 8;
+                        // instruction 1: envs 16 c + 0..7; instruction 2: envs 16 c + 8..15
+                        const u32x4 d1 = lo8 ? eb : rot, d2 = lo8 ? rot : eb;
+                        const unsigned o1 = (blk + (unsigned)((16 * c + (j & 7)) * UC + (lo8 ? 0 : 16) + 4 * rg)) * 4u + half_off;
+                        const unsigned o2 = (blk + (unsigned)((16 * c + 8 + (j & 7)) * UC + (lo8 ? 16 : 0) + 4 * rg)) * 4u + half_off;
+                        if (same_xcd) {
+                            __builtin_amdgcn_raw_buffer_store_b128(d1, xp_rsrc, o1, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(d2, xp_rsrc, o2, 0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b128(d1, xp_rsrc, o1, 0, 16);
+                            __builtin_amdgcn_raw_buffer_store_b128(d2, xp_rsrc, o2, 0, 16);
+                        }
+                    }
+                }
+              }
+            };
+            product([&](int rt, int s, f16x8& p0, f16x8& p1) { p0 = wa[rt][s][0]; p1 = wa[rt][s][1]; }, isc_h, 0u);
+            if constexpr (DX)
+                product([&](int rt, int s, f16x8& p0, f16x8& p1) {
+                    if (rt < 2) { p0 = wxa[rt][s][0]; p1 = wxa[rt][s][1]; }
+                    else { p0 = wxl[((((rt - 2) * 4 + w) * 4 + s) * 2 + 0) * 64 + lane]; p1 = wxl[((((rt - 2) * 4 + w) * 4 + s) * 2 + 1) * 64 + lane]; }
+                }, isc_x, a.xq_off);
+            C8_STAMP(4);
+            // ---- publish
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            C8_STAMP(5);
+            __builtin_amdgcn_s_barrier();    // B2 (also: every wave has read the dG pieces and scales of this step)
+            C8_STAMP(6);
+            if (tid == 0) __hip_atomic_store(my_flag, gstep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (w == 0 && !dead) {
+                bool ok = lane >= G || lane == cu;
+                unsigned spins = 0;
+                while (true) {
+                    if (!ok) ok = __hip_atomic_load(peer_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gstep + 1u;
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (++spins > SPIN_LIMIT) {
+                        if (lane == 0) { atomicAdd(a.err, 1u); s_dead = 1; }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            C8_STAMP(7);
+            __builtin_amdgcn_s_barrier();    // B3
+            C8_STAMP(8);
+            dead = s_dead != 0 || (a.abl & 1u);
+            // ---- this workgroup's units: sum of the eight source blocks, fixed order
+            auto gather = [&](auto policy, unsigned half_off, float (&out)[8]) {
+                constexpr int AUX = decltype(policy)::value;
+                u32x4 pv[G][2];
+#pragma unroll
+                for (int src = 0; src < G; ++src)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        pv[src][h] = __builtin_amdgcn_raw_buffer_load_b128(
+                            xp_rsrc, (par + (unsigned)(((cl * G + cu) * G + src) * PBLK + ev * UC + q8 + 4 * h)) * 4u + half_off, 0, AUX);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) out[i] = 0.f;
+#pragma unroll
+                for (int src = 0; src < G; ++src)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, pv[src][h]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[4 * h + r] += v[r];
+                    }
+            };
+            if (!(a.abl & 4u)) {
+                if (same_xcd) gather(std::integral_constant<int, 2>{}, 0u, dh_rec);
+                else gather(std::integral_constant<int, 16>{}, 0u, dh_rec);
+                if (DX) {
+                    float dxv[8];
+                    if (same_xcd) gather(std::integral_constant<int, 2>{}, a.xq_off, dxv);
+                    else gather(std::integral_constant<int, 16>{}, a.xq_off, dxv);
+                    if (live && !(a.abl & 2u)) {
+                        float* xo = a.dx + ((size_t)n * T + t) * H + ug;
+                        *reinterpret_cast<float4*>(xo) = float4{dxv[0], dxv[1], dxv[2], dxv[3]};
+                        *reinterpret_cast<float4*>(xo + 4) = float4{dxv[4], dxv[5], dxv[6], dxv[7]};
+                    }
+                }
+            }
+            C8_STAMP(9);
+        }
+        if (live) {
+            if (a.dh0) {
+                *reinterpret_cast<float4*>(a.dh0 + (size_t)n * H + ug) = float4{dh_rec[0], dh_rec[1], dh_rec[2], dh_rec[3]};
+                *reinterpret_cast<float4*>(a.dh0 + (size_t)n * H + ug + 4) = float4{dh_rec[4], dh_rec[5], dh_rec[6], dh_rec[7]};
+            }
+            if (a.dc0) {
+                *reinterpret_cast<float4*>(a.dc0 + (size_t)n * H + ug) = float4{dc_nx[0], dc_nx[1], dc_nx[2], dc_nx[3]};
+                *reinterpret_cast<float4*>(a.dc0 + (size_t)n * H + ug + 4) = float4{dc_nx[4], dc_nx[5], dc_nx[6], dc_nx[7]};
+            }
+        }
+    }
+#ifdef UAV_C8_PROFILE
+    if (blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 12; ++k) reinterpret_cast<unsigned long long*>(a.err + 2)[k] = prof_[k];
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static size_t c8_lds_bytes(bool wide, int T) {      // a first layer double-buffers its planes
     return (size_t)(wide ? 1 : 2) * ((size_t)2 * c8::PLANE * 2 + (size_t)2 * c8::E * (wide ? 264 : 40) * 2) + (size_t)T * 8;
@@ -575,6 +972,53 @@ int lstm_c8_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
         UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_fwd_c8_kernel<1>), 160 * 1024 - 64));
         hipLaunchKernelGGL(lstm_fwd_c8_kernel<1>, dim3(grid), dim3(256), lds, st, a);
     }
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+static size_t c8_bwd_lds_bytes(int T, bool dx = true) {
+    return (size_t)2 * c8::GPLANE * 2 + (size_t)(2 * c8::E + 8 * c8::UC) * 4 + (dx ? (size_t)2 * 4 * 4 * 2 * 64 * 16 : 0) + (size_t)T * 8;
+}
+bool lstm_c8_bwd_fits(int T) { return c8_bwd_lds_bytes(T) <= (160u << 10) - 64; }
+
+// one layer's BPTT as one cluster launch; dx (and w_ih) only for a layer that feeds one below (I = H)
+int lstm_c8_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy, const float* dheads,
+                const float* w_head, int n_heads, const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0,
+                float* dc0, const float* w_ih, float* dx, hipStream_t st) {
+    using namespace c8;
+    UAV_REQUIRE(dy || (dheads && w_head && n_heads > 0 && n_heads <= 8), "lstm cluster bwd: dy or dheads + w_head (1..8 heads)");
+    const int ntile = (N + E - 1) / E;
+    int max_cl = ctx->num_cu / G;
+    if (max_cl > MAX_CLUSTERS) max_cl = MAX_CLUSTERS;
+    const int ncl = ntile < max_cl ? ntile : max_cl;
+    const size_t half = (size_t)2 * MAX_CLUSTERS * G * G * PBLK * 4;          // bytes of one exchange buffer (both parities)
+    const size_t flag_bytes = (size_t)MAX_CLUSTERS * G * FLAG_STRIDE * 4;
+    const size_t need = 2 * half + flag_bytes;
+    UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm cluster bwd: workspace too small");
+    char* base = (char*)ctx->ws + ctx->ws_bytes - need;
+    C8BwdArgs a;
+    a.keep = keep; a.stash = stash; a.w_hh = w_hh; a.w_ih = w_ih; a.dy = dy; a.dheads = dheads; a.w_head = w_head;
+    a.dhn = dhn; a.dcn = dcn; a.dgates = dgates; a.dx = dx; a.dh0 = dh0; a.dc0 = dc0;
+    a.xp = (float*)base;
+    a.xp_bytes = (unsigned)(2 * half);
+    a.xq_off = (unsigned)half;
+    a.flags = (unsigned*)(base + 2 * half);
+    a.err = ctx->cluster_err;
+    a.NH = n_heads; a.N = N; a.T = T; a.ntile = ntile; a.ncl = ncl;
+    a.abl = (g_uav_debug >> 8) & 0x1fu;
+    UAV_CHECK_HIP(hipMemsetAsync(a.flags, 0, flag_bytes, st));
+    const int grid = 64 * ((ncl + 7) / 8);
+    const size_t lds = c8_bwd_lds_bytes(T, dx != nullptr);
+    UAV_REQUIRE(lds <= (160u << 10) - 64, "lstm cluster bwd: T = %d needs %zu bytes of LDS", T, lds);
+    UAV_REQUIRE(!dx || w_ih, "lstm cluster bwd: dx needs w_ih");
+#define C8_BWD_LAUNCH(DX_, TOP_)                                                                                            \
+    do {                                                                                                                    \
+        UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&lstm_bwd_c8_kernel<DX_, TOP_>), 160 * 1024 - 64));         \
+        hipLaunchKernelGGL((lstm_bwd_c8_kernel<DX_, TOP_>), dim3(grid), dim3(256), lds, st, a);                             \
+    } while (0)
+    if (dx) { if (dy) C8_BWD_LAUNCH(true, false); else C8_BWD_LAUNCH(true, true); }
+    else { if (dy) C8_BWD_LAUNCH(false, false); else C8_BWD_LAUNCH(false, true); }
+#undef C8_BWD_LAUNCH
     UAV_LAUNCH_CHECK();
     return 0;
 }
