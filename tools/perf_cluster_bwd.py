@@ -28,7 +28,7 @@ for I, dx in ((8, False), (256, True)):
         ops.check(lib.uav_lstm_bwd(ops._h(dy), ops._p(keep), ops._p(stash), ops._p(w_hh), ops._p(dy), None, None, 0, None, None, N, T, H,
                                    ops._p(dgates), ops._p(dh0), ops._p(dc0), ops._p(w_ih) if dx else None, H if dx else 8,
                                    ops._p(dxo) if dx else None, ops._stream()), "uav_lstm_bwd")
-    for mode, fl in (("per-step", []), ("cluster", ["cluster"]), ("c-nowait", ["cluster", "abl_wait"]), ("c-nostores", ["cluster", "abl_stash"]),
+    for mode, fl in (("per-step", []), ("cluster", ["cluster"]), ("cluster-sc1", ["cluster", "cluster_sc1"]), ("c-nowait", ["cluster", "abl_wait"]), ("c-nostores", ["cluster", "abl_stash"]),
                      ("c-nofetch", ["cluster", "abl_wait", "abl_fetch"]), ("c-nomfma", ["cluster", "abl_mfma"])):
         ops.set_debug_flags(*fl)
         for _ in range(2):
