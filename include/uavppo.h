@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 6   /* 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 7   /* 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum); 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -344,7 +344,19 @@ typedef struct uav_env_cfg {
     uint64_t seed;          /* counter-RNG key (procedural fields, sources, step noise)     */
     const double* bank;     /* [F][500][500][2] (conc, tke) f64, materialised mode          */
     const double* bank_src; /* [F][2] source positions, materialised mode                   */
+    const void*   curriculum; /* device pointer to a uav_curriculum state, or NULL: when set, every env kernel reads
+                                 radius / bonus / bonus_is_f64 from it at launch and ignores the three fields above -- the
+                                 curriculum then never crosses to the host (uav_curriculum_update) */
 } uav_env_cfg;
+
+/* ---- T1 on the device: PPOTrainer.update (model.py:131-164) for all episodes that ended in a rollout, fed by the messages of
+ * uav_pack_success_bits.  `state` is an opaque device block of uav_curriculum_state_bytes() bytes; its first four doubles are
+ * { current_radius, explore_bonus, bonus_is_f64 (0 / 1), overflow flag }, then int64 { episodes seen, successes seen }, then
+ * int32 { window length, successes in the window }.  uav_curriculum_update walks msgs[world][4 + cap + 1] rank by rank, episode
+ * by episode, in ONE thread (the window logic is sequential; a few thousand episodes cost tens of microseconds on a side stream). */
+size_t uav_curriculum_state_bytes(void);
+int uav_curriculum_init(uav_ctx* ctx, void* state, double radius, double bonus, int bonus_is_f64, uav_stream stream);
+int uav_curriculum_update(uav_ctx* ctx, void* state, const uint8_t* msgs, int world, int cap, uav_stream stream);
 
 size_t uav_env_state_bytes(int n_env);
 /* reset every env (environment.py:41-49); obs_out f32 [n_env][6 + trend_k] */

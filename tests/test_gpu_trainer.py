@@ -915,3 +915,30 @@ def test_new_entry_points_reject_bad_arguments():
     assert b"uav_set_lstm_arith" in _lib.lib().uav_last_error()
     with pytest.raises(RuntimeError, match="expected a contiguous tensor|expected shape"):
         ops.absmax(z(8, 8)[:, ::2])
+
+
+def test_device_curriculum_equals_host_curriculum_in_the_loop():
+    """The curriculum on the device (default: no host synchronisation in train_iteration) against the host-side class fed by the
+    same success bits: after every iteration the same episode counts and window length, radius / bonus to 1e-12 (device pow vs
+    libm), and -- the env kernels reading them from the device block -- the same rollouts bit for bit."""
+    from uavppo.trainer import VecPPOTrainer
+    kw = dict(policy="lstm", hidden=64, device=DEV, seed=5, epochs=1)
+    a = VecPPOTrainer(512, 64, device_curriculum=True, **kw)
+    b = VecPPOTrainer(512, 64, device_curriculum=False, **kw)
+    for tr in (a, b):
+        tr.radius = 200.0            # many episodes end: the 120-episode window fills several times per rollout
+        tr.reset()
+    b.curriculum.current_radius = 200.0      # (host mode: the class keeps its own copy; the device block IS the state)
+    assert a.device_curriculum and not b.device_curriculum
+    for it in range(5):
+        for tr in (a, b):
+            tr.train_iteration()
+        assert a.episodes_done == b.episodes_done and a.successes_done == b.successes_done, it
+        assert len(a.curriculum.success_history) == len(b.curriculum.success_history)
+        assert np.isclose(a.radius, b.radius, rtol=1e-12, atol=0) and np.isclose(float(a.bonus), float(b.bonus), rtol=1e-12, atol=0)
+        assert isinstance(a.bonus, np.float64) == isinstance(b.bonus, np.float64)
+        if a.radius == b.radius and float(a.bonus) == float(b.bonus):
+            assert torch.equal(a.buf["obs"], b.buf["obs"]) and torch.equal(a.buf["flags"], b.buf["flags"])
+    assert a.episodes_done > 600 and a.radius < 200.0
+    # the lagged mirror the training script reads (never waits): at most one rollout behind
+    assert 0 < a.episodes_lagged <= a.episodes_done

@@ -338,3 +338,52 @@ def test_pack_success_bits_matches_bruteforce(ops):
         assert cnt == ended.sum() and msg.shape == (4 + cap + 1,)
         k = min(cnt, cap)
         assert np.array_equal(msg[4:4 + k], want[:k]) and not msg[4 + k:].any()
+
+
+def test_device_curriculum_matches_the_reference_traces(golden):
+    """uav_curriculum_update (PPOTrainer.update, model.py:131-164, on the device) against the reference's own traces
+    (tests/golden/curriculum.npz): fed one episode per call, radius / bonus after every episode to 1e-12 (device pow vs libm),
+    the np.float64 switch of the bonus at the first full window; fed in random chunks through uav_pack_success_bits' message
+    format over three 'ranks', the same final state; counters and window length as the host class."""
+    from uavppo import ops
+    from uavppo.curriculum import Curriculum
+    g = golden("curriculum.npz")
+    cap = 64
+    rng = np.random.RandomState(3)
+
+    def message(bits):
+        m = np.zeros(4 + cap + 1, np.uint8)
+        m[:4] = np.frombuffer(np.int32(len(bits)).tobytes(), np.uint8)
+        m[4:4 + len(bits)] = np.asarray(bits, np.uint8)
+        return m
+    for name in sorted({k.split("/")[0] for k in g.files if "/" in k}):
+        seq, trace = g[f"{name}/seq"], g[f"{name}/trace"]
+        st = ops.curriculum_state(DEV)
+        host = Curriculum()
+        for i, s in enumerate(seq[:400]):
+            ops.curriculum_update(st, torch.from_numpy(message([int(s)])[None]).to(DEV), cap)
+            host.update(bool(s))
+            if i % 7 == 0 or i + 1 == min(len(seq), 400):
+                d = ops.curriculum_read(st.cpu().numpy())
+                assert np.allclose([d["radius"], d["bonus"]], trace[i][:2], rtol=1e-12, atol=0), (name, i)
+                assert d["bonus_is_f64"] == isinstance(host.explore_bonus, np.float64)
+                assert d["hist_len"] == len(host.success_history) and d["episodes"] == i + 1
+        # the whole sequence in chunks over three message rows per call
+        st2 = ops.curriculum_state(DEV)
+        i = 0
+        while i < len(seq):
+            rows = []
+            for _ in range(3):
+                k = int(rng.randint(0, cap + 1))
+                rows.append(message([int(v) for v in seq[i:i + k]]))
+                i += len(seq[i:i + k])
+            ops.curriculum_update(st2, torch.from_numpy(np.stack(rows)).to(DEV), cap)
+        d2 = ops.curriculum_read(st2.cpu().numpy())
+        assert np.allclose([d2["radius"], d2["bonus"]], trace[len(seq) - 1][:2], rtol=1e-12, atol=0), name
+        assert d2["episodes"] == len(seq) and d2["successes"] == int(np.sum(seq)) and not d2["overflow"]
+    # more episodes in a message than it holds: flagged
+    st3 = ops.curriculum_state(DEV)
+    m = message([1] * cap)
+    m[:4] = np.frombuffer(np.int32(cap + 5).tobytes(), np.uint8)
+    ops.curriculum_update(st3, torch.from_numpy(m[None]).to(DEV), cap)
+    assert ops.curriculum_read(st3.cpu().numpy())["overflow"]

@@ -44,7 +44,7 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
                 "env: field_mode %d", cfg->field_mode);
     if (cfg->field_mode == UAV_FIELD_MATERIALISED)
         UAV_REQUIRE(cfg->bank && cfg->bank_src && cfg->n_fields > 0, "env: materialised mode needs bank, bank_src, n_fields");
-    UAV_REQUIRE(cfg->radius > 0.0, "env: radius must be positive");
+    UAV_REQUIRE(cfg->curriculum || cfg->radius > 0.0, "env: radius must be positive");
     P.variant = cfg->variant;
     P.field_mode = cfg->field_mode;
     P.n_fields = cfg->n_fields;
@@ -68,6 +68,7 @@ int env_params_from_cfg(const uav_ctx* ctx, const uav_env_cfg* cfg, int n_env, E
     P.pow_near = nullptr;
     P.pow_near_n = 0;
     P.ftab = ctx->ftab;
+    P.curr = reinterpret_cast<const double*>(cfg->curriculum);
     return 0;
 }
 
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(EnvParams P, EnvBlob b, i
                                                        float* __restrict__ term_obs, double* __restrict__ rew64) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    env_params_refresh(P);
     EnvState s = env_load(b, i);
     unsigned short* vis = b.visited + (size_t)i * NVIS;
     const int eg = P.env_offset + i;

@@ -28,7 +28,20 @@ struct EnvParams {            // kernel-argument copy of uav_env_cfg + derived c
     const double* pow_near;   // optional copy of pow075[0 .. pow_near_n) in faster memory (the fused rollouts' LDS), else NULL
     int pow_near_n;
     const double* ftab;       // [FT_N] host-libm tables of the f64 log / cos-sin / exp below (global, or the rollouts' LDS copy)
+    const double* curr;       // device-side curriculum state (uav_curriculum_*), or NULL: { radius, bonus, bonus_is_f64, .. }
 };
+
+// With a device-side curriculum the three curriculum values of a launch come from device memory (wave-uniform loads at kernel
+// entry) instead of the host's copy in the kernel arguments: the host then never has to wait for the episode outcomes.
+__device__ __forceinline__ void env_params_refresh(EnvParams& P) {
+    if (P.curr) {
+        const double r = P.curr[0];
+        P.radius = r;
+        P.bonus = P.curr[1];
+        P.bonus_is_f64 = P.curr[2] != 0.0;
+        P.reach_bonus = fmin(500.0, 150.0 * (50.0 / r));                  // environment.py:151, as env_params_from_cfg
+    }
+}
 
 // ---- f64 log, cos/sin and exp for the procedural field and the Box-Muller normals, table-driven.  The arguments are not
 // arbitrary doubles: log is needed of a 24-bit integer, cos/sin of a 24-bit fraction of a turn, exp of -d^2 / 2 sigma^2 in

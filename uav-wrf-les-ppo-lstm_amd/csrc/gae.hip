@@ -186,6 +186,59 @@ __global__ __launch_bounds__(1024) void pack_success_kernel(const uint8_t* __res
     });
 }
 
+// ---- T1 on the device.  PPOTrainer.update (model.py:131-164), one finished episode at a time in the order of the messages
+// (rank, then (env, time) inside a rank = global (env, time) order), f64 throughout like the reference's Python / numpy scalars.
+struct CurriculumState {
+    double radius, bonus, bonus_is_f64, overflow;      // read by the env kernels (env_params_refresh): the first three
+    long long episodes, successes;                     // finished episodes / successes seen since init
+    int hist_len, win_succ;                            // the 120-episode window: its length and the successes in it
+    int pad_[2];
+};
+constexpr double CUR_MIN_RADIUS = 5.0, CUR_INITIAL_RADIUS = 50.0, CUR_RADIUS_DECAY = 0.9;       // config.py:27-29
+constexpr double CUR_SUCCESS_THRESHOLD = 0.6, CUR_DECAY_FACTOR = 0.999;                         // config.py:30, 22
+constexpr int CUR_WINDOW = 120;                                                                // config.py:31
+
+__global__ void curriculum_init_kernel(CurriculumState* s, double radius, double bonus, int is_f64) {
+    if (threadIdx.x != 0) return;
+    s->radius = radius; s->bonus = bonus; s->bonus_is_f64 = is_f64 ? 1.0 : 0.0; s->overflow = 0.0;
+    s->episodes = 0; s->successes = 0; s->hist_len = 0; s->win_succ = 0;
+}
+
+__global__ void curriculum_update_kernel(CurriculumState* st, const uint8_t* __restrict__ msgs, int world, int cap) {
+    if (threadIdx.x != 0) return;
+    CurriculumState s = *st;
+    const size_t len = (size_t)4 + cap + 1;
+    for (int r = 0; r < world; ++r) {
+        const uint8_t* m = msgs + (size_t)r * len;
+        long long cnt = (long long)m[0] | ((long long)m[1] << 8) | ((long long)m[2] << 16) | ((long long)m[3] << 24);
+        if (cnt > cap) { s.overflow = 1.0; cnt = cap; }      // (a rank ended more episodes than its message holds: flagged, the rest dropped)
+        for (long long k = 0; k < cnt; ++k) {
+            const int success = m[4 + k] != 0;
+            const double env_radius = s.radius;                                     // :132
+            s.episodes += 1; s.successes += success;
+            s.hist_len += 1; s.win_succ += success;                                 // :135-137 (the window never exceeds 120: cleared when full)
+            const bool full = s.hist_len >= CUR_WINDOW;
+            double rate = 0.0;
+            if (full) {
+                rate = (double)s.win_succ / (double)s.hist_len;                     // np.mean of the window
+                s.bonus = s.bonus * pow(CUR_DECAY_FACTOR, 1.0 + rate);              // :140-142 (an np.float64 from here on)
+                s.bonus_is_f64 = 1.0;
+            }
+            s.bonus = fmax(s.bonus, 0.1);                                           // :144
+            if (full) {
+                if (rate > CUR_SUCCESS_THRESHOLD)                                   // :148-152
+                    s.radius = fmax(CUR_MIN_RADIUS, s.radius * pow(CUR_RADIUS_DECAY, 2.0 + 3.0 * (rate - CUR_SUCCESS_THRESHOLD)));
+                else if (rate < 0.25)                                               // :153-157
+                    s.radius = fmin(CUR_INITIAL_RADIUS, s.radius * 1.1);
+                const double d = s.radius - env_radius;
+                if (fabs(d) > 5.0) s.radius = env_radius + 5.0 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));      // :160-161
+                s.hist_len = 0; s.win_succ = 0;                                     // :164
+            }
+        }
+    }
+    *st = s;
+}
+
 extern "C" {
 
 int uav_gae(uav_ctx* ctx, const float* rew, const float* val, const float* done,
@@ -225,6 +278,22 @@ int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t 
     return 0;
 }
 
+
+size_t uav_curriculum_state_bytes(void) { return sizeof(CurriculumState); }
+
+int uav_curriculum_init(uav_ctx* ctx, void* state, double radius, double bonus, int bonus_is_f64, uav_stream stream) {
+    UAV_REQUIRE(ctx && state && radius > 0.0, "uav_curriculum_init: bad argument");
+    hipLaunchKernelGGL(curriculum_init_kernel, dim3(1), dim3(64), 0, as_stream(stream), (CurriculumState*)state, radius, bonus, bonus_is_f64);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+int uav_curriculum_update(uav_ctx* ctx, void* state, const uint8_t* msgs, int world, int cap, uav_stream stream) {
+    UAV_REQUIRE(ctx && state && msgs && world > 0 && cap > 0, "uav_curriculum_update: bad argument");
+    hipLaunchKernelGGL(curriculum_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), (CurriculumState*)state, msgs, world, cap);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
 
 int uav_pack_success_bits(uav_ctx* ctx, const uint8_t* flags, int64_t n, int cap, uint8_t* msg, uav_stream stream) {
     UAV_REQUIRE(ctx && flags && msg && n > 0 && cap > 0, "uav_pack_success_bits: bad argument");

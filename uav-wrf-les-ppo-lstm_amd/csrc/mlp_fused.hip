@@ -479,6 +479,7 @@ __global__ __launch_bounds__(512) void rollout_mlp_kernel(EnvParams P_arg, EnvBl
     __shared__ double env_tab[ENV_LDS_TABLE_DOUBLES];            // pow(vc, 0.75) | ripple factors (env_core.h)
     static_assert(ROLL_LDS + sizeof(vis) + sizeof(es_s) + sizeof(env_tab) <= 160 * 1024, "rollout_mlp_kernel: LDS over 160 KB per workgroup");
     EnvParams P = P_arg;
+    env_params_refresh(P);
     env_tables_to_lds(P, env_tab, threadIdx.x, 512);
 
     const int lane = threadIdx.x & 63;

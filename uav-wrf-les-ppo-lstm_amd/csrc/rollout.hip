@@ -106,6 +106,7 @@ __global__ __launch_bounds__(H * 4) void rollout_lstm_kernel(EnvParams P_arg, En
     static_assert(G::LDS + sizeof(xbuf) + sizeof(kbuf) + sizeof(hd) + sizeof(vis) + sizeof(es_s) + sizeof(trs) + sizeof(acc0) +
                       sizeof(env_tab) <= 160 * 1024, "rollout_lstm_kernel: LDS over 160 KB per workgroup");
     EnvParams P = P_arg;
+    env_params_refresh(P);
     env_tables_to_lds(P, env_tab, threadIdx.x, H * 4);
 
     const float* w_ih = params;
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(256) void rollout_tail_kernel(
     const int lane = threadIdx.x & 63;
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
     if (m0 >= n) return;
+    env_params_refresh(P);
     RowsDot<8, 1> rd;
     rd.load_w(w_head, K, A + 1, K, lane);
     float red[4];

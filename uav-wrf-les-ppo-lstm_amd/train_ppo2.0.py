@@ -180,8 +180,23 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
         traj = TrajectoryLogger(NUM_ENVS, NetCDFWriter(nc_path, GRID_SIZE, max_episodes=2000, max_steps=MAX_STEPS),
                                 gaussian=(GAUSSIAN_RADIUS, PEAK_CONCENTRATION) if ENV_VARIANT == "v2.1" else None)
     it = 0
-    while (iterations is None or it < iterations) and (episodes is None or tr.episodes_done < episodes):
-        radius = tr.radius
+    pending = None                   # (pinned slot, curriculum mirror slot) of the rollout whose rows are written one iteration later
+
+    def log_rollout(p):
+        slot, cslot, radius = p
+        host = mirror.get(slot)          # landed while the update's kernels were queued / running
+        if radius is None:
+            radius = tr.rollout_radius(cslot)
+        before = len(log.rows)
+        log.add_rollout(host["rew"], host["info"], host["flags"], radius)
+        rows_per_iter.append(log.rows[before:])
+        if traj is not None:
+            traj.add_rollout(host["info"], host["flags"], radius)
+
+    # The loop never waits for the device except for copies that landed an iteration ago: the curriculum lives on the device
+    # (uavppo/trainer.py, device_curriculum), the per-iteration logs are read from pinned mirrors one iteration late, the episode
+    # count that ends the run is the lagged one (the run may collect one or two rollouts more than it needs; rows are cut).
+    while (iterations is None or it < iterations) and (episodes is None or tr.episodes_lagged < episodes):
         mirror.fence()
         tr.collect()
         slot = mirror.start()
@@ -189,17 +204,16 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
         tr.update_curriculum()
         tr.poll_param_range()
         tr.iteration += 1
-        host = mirror.get(slot)          # landed while the update's kernels were queued / running
-        before = len(log.rows)
-        log.add_rollout(host["rew"], host["info"], host["flags"], radius)
-        rows_per_iter.append(log.rows[before:])
-        if traj is not None:
-            traj.add_rollout(host["info"], host["flags"], radius)
+        if pending is not None:
+            log_rollout(pending)
+        pending = (slot, tr.last_mirror_slot, None) if tr.device_curriculum else (slot, None, tr.rollout_radius())
         it += 1
         if log_every and it % log_every == 0:
             pl, vl, ent = tr.losses()              # (also where NaN probabilities raise, on every rank together)
             if rank == 0:
-                print(f"It {it} | episodes {tr.episodes_done} | radius {tr.radius:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
+                print(f"It {it} | episodes {tr.episodes_lagged} | radius {tr.radius_lagged:.1f} | policy {pl:.4f} value {vl:.4f} entropy {ent:.4f}")
+    if pending is not None:
+        log_rollout(pending)
     tr.losses()
     if traj is not None:
         traj.writer.close()

@@ -23,7 +23,7 @@ class EnvCfg(C.Structure):
                 ("bonus_is_f64", C.c_int32), ("env_offset", C.c_int32), ("n_env_total", C.c_int32),
                 ("trend_k", C.c_int32), ("pad_", C.c_int32),
                 ("radius", C.c_double), ("bonus", C.c_double),
-                ("seed", C.c_uint64), ("bank", C.c_void_p), ("bank_src", C.c_void_p)]
+                ("seed", C.c_uint64), ("bank", C.c_void_p), ("bank_src", C.c_void_p), ("curriculum", C.c_void_p)]
 
 
 class LstmBwdLayer(C.Structure):
@@ -46,6 +46,9 @@ SIGNATURES = {
     "uav_adv_stats": (I32, [P, P, I64, P, P]),
     "uav_adv_normalise": (I32, [P, P, P, I64, P, P, P, P]),
     "uav_pack_success_bits": (I32, [P, P, I64, I32, P, P]),
+    "uav_curriculum_state_bytes": (SZ, []),
+    "uav_curriculum_init": (I32, [P, P, C.c_double, C.c_double, I32, P]),
+    "uav_curriculum_update": (I32, [P, P, P, I32, I32, P]),
     "uav_ppo_loss": (I32, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, F32, P, P, P, P, P]),
     "uav_ppo_loss_from_y": (I32, [P, P, P, P, P, P, P, P, P, I64, I32, I32, F32, F32, F32, P, P, P, P]),
     "uav_policy_sample": (I32, [P, P, I64, I32, P, U64, U64, I64, P, P, P, P, P, P]),

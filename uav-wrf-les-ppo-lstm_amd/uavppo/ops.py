@@ -140,6 +140,36 @@ def pack_success_bits(flags, cap, out=None):
     return out
 
 
+def curriculum_state(device, radius=50.0, bonus=0.6, bonus_is_f64=False):
+    """A device-side curriculum state (uav_curriculum_*): opaque u8 block, initialised."""
+    st = torch.zeros(int(lib().uav_curriculum_state_bytes()), dtype=U8, device=device)
+    curriculum_init(st, radius, bonus, bonus_is_f64)
+    return st
+
+
+def curriculum_init(state, radius, bonus, bonus_is_f64=False):
+    check(lib().uav_curriculum_init(_h(state), _p(state, U8, name="curriculum state"), float(radius), float(bonus), int(bool(bonus_is_f64)),
+                                    _stream()), "uav_curriculum_init")
+
+
+def curriculum_update(state, msgs, cap):
+    """Feed the success messages of all ranks (u8 [world, 4 + cap + 1], uav_pack_success_bits) to the device-side curriculum."""
+    world = int(msgs.shape[0])
+    check(lib().uav_curriculum_update(_h(state), _p(state, U8, name="curriculum state"), _p(msgs, U8, (world, 4 + cap + 1), "msgs"), world,
+                                      int(cap), _stream()), "uav_curriculum_update")
+
+
+def curriculum_read(state_host):
+    """Decode a HOST copy (numpy u8 / torch cpu u8) of a curriculum state -> dict."""
+    import numpy as np
+    b = np.asarray(state_host, dtype=np.uint8)
+    d = b[:32].view(np.float64)
+    q = b[32:48].view(np.int64)
+    i = b[48:56].view(np.int32)
+    return {"radius": float(d[0]), "bonus": float(d[1]), "bonus_is_f64": bool(d[2] != 0.0), "overflow": bool(d[3] != 0.0),
+            "episodes": int(q[0]), "successes": int(q[1]), "hist_len": int(i[0]), "win_succ": int(i[1])}
+
+
 # ----------------------------------------------------------------------------- U2 / K3
 def ppo_loss(logits, value, act, logp_old, adv, ret, val_old, inv_n, clip, ent_beta,
              loss_sums=None, dlogits=None, dvalue=None, dhead_bias=None):
@@ -415,7 +445,7 @@ def env_state_bytes(n_env):
     return int(lib().uav_env_state_bytes(int(n_env)))
 
 
-def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_offset=0, n_env_total=0, trend_k=0):
+def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_offset=0, n_env_total=0, trend_k=0, curriculum=None):
     """uav_env_cfg (host struct).  bonus: python float -> the reference's f32 expression,
     numpy.float64 -> its f64 expression (see csrc/env_core.h, environment.py:133)."""
     import numpy as np
@@ -430,6 +460,7 @@ def make_env_cfg(variant, radius, bonus, seed=0, bank=None, bank_src=None, env_o
     cfg.radius = float(radius)
     cfg.bonus = float(bonus)
     cfg.seed = int(seed)
+    cfg.curriculum = None if curriculum is None else _p(curriculum, U8, name="curriculum state").value
     if bank is not None:
         F_ = bank.shape[0]
         cfg.bank = _p(bank, F64, (F_, 500, 500, 2), "bank").value

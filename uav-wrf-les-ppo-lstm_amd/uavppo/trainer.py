@@ -48,10 +48,30 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+class _DeviceCurriculumView:
+    """What callers read off `trainer.curriculum` when the curriculum lives on the device (each access waits for the device)."""
+
+    def __init__(self, tr):
+        self._tr = tr
+
+    @property
+    def current_radius(self):
+        return self._tr.radius
+
+    @property
+    def explore_bonus(self):
+        return self._tr.bonus
+
+    @property
+    def success_history(self):
+        self._tr._sync_curriculum()
+        return [None] * self._tr._hist_len          # the window's LENGTH is what callers look at; its bits stay on the device
+
+
 class VecPPOTrainer:
     def __init__(self, num_envs, horizon, policy="lstm", hidden=128, layers=1, variant="v2.0", device="cuda",
                  seed=1234, gae_mode="reference_exact", num_minibatches=1, bank=None, bank_sources=None,
-                 rank=0, world_size=1, use_curriculum=True, trend_k=0, log_info=False, **hp):
+                 rank=0, world_size=1, use_curriculum=True, trend_k=0, log_info=False, device_curriculum=None, **hp):
         self.hp = dict(DEFAULTS)
         self.hp.update(hp)
         self.N, self.T = int(num_envs), int(horizon)
@@ -123,10 +143,27 @@ class VecPPOTrainer:
         self.cur_obs = torch.zeros(N, D, **f32)
         self.bank = None if bank is None else torch.as_tensor(bank, dtype=torch.float64).to(d).contiguous()
         self.bank_sources = None if bank_sources is None else torch.as_tensor(bank_sources, dtype=torch.float64).to(d).contiguous()
-        self.curriculum = Curriculum() if use_curriculum else None
-        self.radius, self.bonus = 50.0, 0.6
-        self.episodes_done = self.successes_done = 0     # finished episodes of the whole job (all ranks), fed by update_curriculum
+        # T1.  device_curriculum (the default with a curriculum): the 120-episode window, radius and bonus live in a device block
+        # (uav_curriculum_*), updated by a one-thread kernel on the side stream from the gathered success messages and read by
+        # the env kernels at launch -- the loop has no host synchronisation left.  False: the host-side Curriculum class (the
+        # reference's arithmetic in Python; what the N = 1 PPOTrainer of model.py uses), one wait per iteration.
+        self.device_curriculum = bool(use_curriculum) if device_curriculum is None else bool(device_curriculum and use_curriculum)
+        self._radius, self._bonus = 50.0, 0.6
+        self._episodes_done = self._successes_done = 0   # finished episodes of the whole job (all ranks)
+        self._hist_len = 0
         self.last_success_bits = None
+        if self.device_curriculum:
+            self._curr = ops.curriculum_state(self.device, self._radius, self._bonus)
+            self._curr_host = torch.zeros(4, self._curr.numel(), dtype=torch.uint8).pin_memory()     # ring of lagged host mirrors
+            self._curr_evs = [torch.cuda.Event() for _ in range(4)]
+            self._curr_queue, self._curr_next = [], 0
+            self.last_mirror_slot = 0
+            self._curr_done_ev = torch.cuda.Event()
+            self._curr_pending = False
+            self.curriculum = _DeviceCurriculumView(self)
+        else:
+            self._curr = None
+            self.curriculum = Curriculum() if use_curriculum else None
         # the curriculum's success bits leave on a side stream right behind the rollout and land in pinned host memory
         # while the update runs: the iteration's one host sync (update_curriculum) then waits for a copy that finished
         # milliseconds ago instead of draining the main stream
@@ -163,9 +200,96 @@ class VecPPOTrainer:
 
     # ------------------------------------------------------------------------------------------
     def env_cfg(self):
-        return ops.make_env_cfg(self.variant, self.radius, self.bonus, self.seed, self.bank, self.bank_sources,
+        return ops.make_env_cfg(self.variant, self._radius, self._bonus, self.seed, self.bank, self.bank_sources,
                                 env_offset=env_shard(self.rank, self.N)[0], n_env_total=self.world * self.N,
-                                trend_k=self.trend_k)
+                                trend_k=self.trend_k, curriculum=self._curr)
+
+    # ------------------------------------------------------------------------------------------ T1 state
+    # radius / bonus / episode counters.  Host curriculum: plain attributes.  Device curriculum: the truth is on the device; the
+    # getters below WAIT for it (tests, logging at the end of a run); the training loop itself never calls them -- it reads the
+    # lagged mirror (`radius_lagged`, `episodes_lagged`: the state as of the rollout before last, copied to pinned memory on
+    # the side stream).
+    def _sync_curriculum(self):
+        if not self.device_curriculum:
+            return
+        if self._succ_pending and not self._succ_exchanged and not self._coll:
+            self._exchange_successes()         # (with several ranks the exchange is a collective: only update() / collect() issue it)
+        if self._curr_pending:
+            self._curr_done_ev.synchronize()
+        d = ops.curriculum_read(self._curr.cpu().numpy())
+        if d["overflow"]:
+            raise RuntimeError(f"device curriculum: a rank ended more than {SUCC_CAP} episodes in one rollout (message capacity)")
+        self._radius = d["radius"]
+        self._bonus = np.float64(d["bonus"]) if d["bonus_is_f64"] else d["bonus"]
+        self._episodes_done, self._successes_done, self._hist_len = d["episodes"], d["successes"], d["hist_len"]
+
+    def sync_curriculum(self):
+        self._sync_curriculum()
+
+    def _poll_curriculum_mirror(self):
+        """Newest landed mirror of the device state (never waits)."""
+        latest = None
+        while self._curr_queue and self._curr_evs[self._curr_queue[0]].query():
+            latest = self._curr_queue.pop(0)
+        if latest is not None:
+            d = ops.curriculum_read(self._curr_host[latest].numpy())
+            self._radius = d["radius"]
+            self._bonus = np.float64(d["bonus"]) if d["bonus_is_f64"] else d["bonus"]
+            self._episodes_done, self._successes_done, self._hist_len = d["episodes"], d["successes"], d["hist_len"]
+
+    def rollout_radius(self, k=None):
+        """The radius the LAST collected rollout ran with (device curriculum: from its lagged mirror, slot k = the value of
+        `last_mirror_slot` taken right after that rollout's update_curriculum(); waits only for that 64-byte copy)."""
+        if not self.device_curriculum:
+            return self._rollout_radius
+        k = self.last_mirror_slot if k is None else k
+        self._curr_evs[k].synchronize()
+        return ops.curriculum_read(self._curr_host[k].numpy())["radius"]
+
+    @property
+    def radius(self):
+        self._sync_curriculum()
+        return self._radius
+
+    @radius.setter
+    def radius(self, v):
+        self._radius = float(v)
+        if self.device_curriculum:
+            self._curr[:32].view(torch.float64)[0] = self._radius
+
+    @property
+    def bonus(self):
+        self._sync_curriculum()
+        return self._bonus
+
+    @bonus.setter
+    def bonus(self, v):
+        self._bonus = v
+        if self.device_curriculum:
+            self._curr[:32].view(torch.float64)[1] = float(v)
+            self._curr[:32].view(torch.float64)[2] = 1.0 if isinstance(v, np.float64) else 0.0
+
+    @property
+    def radius_lagged(self):
+        if self.device_curriculum:
+            self._poll_curriculum_mirror()
+        return self._radius
+
+    @property
+    def episodes_lagged(self):
+        if self.device_curriculum:
+            self._poll_curriculum_mirror()
+        return self._episodes_done
+
+    @property
+    def episodes_done(self):
+        self._sync_curriculum()
+        return self._episodes_done
+
+    @property
+    def successes_done(self):
+        self._sync_curriculum()
+        return self._successes_done
 
     # ------------------------------------------------------------------------------------------ range guard
     # The fp16-split kernels need |w| < 65504, |x| < 4096, |h0| < 64 (include/uavppo.h).  What can leave that range, and
@@ -237,8 +361,14 @@ class VecPPOTrainer:
     def collect(self, forced_act=None, noise=None):
         """Fill the (env, T, feat) buffers with one rollout of T steps per env."""
         self._rollout_forward_valid = False
+        self._rollout_radius = self._radius    # (host curriculum: what this rollout runs with)
         if self._succ_pending:                 # a previous rollout's flags may still be read by the pack kernel on the side stream
             torch.cuda.current_stream().wait_event(self._pack_ev)
+        if self.device_curriculum:
+            if self._succ_pending and not self._succ_exchanged:     # collect() twice without an update(): finish the first one's exchange
+                self._exchange_successes()
+            if self._curr_pending:             # the env kernels read radius / bonus from the device state: a GPU-side wait, no host sync
+                torch.cuda.current_stream().wait_event(self._curr_done_ev)
         if self._guarded():
             self.poll_param_range()
             self._measure_params()
@@ -287,8 +417,23 @@ class VecPPOTrainer:
             if tuple(msgs.shape) != tuple(self._succ_host.shape):       # e.g. world_size > 1 without a process group
                 raise RuntimeError(f"success exchange returned {tuple(msgs.shape)}, expected {tuple(self._succ_host.shape)}: "
                                    "is torch.distributed initialised for world_size > 1?")
-            self._succ_host.copy_(msgs, non_blocking=True)
-            self._succ_ev.record(self._side)
+            if self.device_curriculum:
+                # lagged host mirror of the state as it was for THIS rollout, then the update itself: one thread walks the
+                # messages rank by rank, episode by episode (model.py:131-164)
+                k = self._curr_next
+                self._curr_next = (k + 1) % len(self._curr_evs)
+                if k in self._curr_queue:                       # the host is a whole ring ahead: drop the oldest mirror
+                    self._curr_queue.remove(k)
+                self._curr_host[k].copy_(self._curr, non_blocking=True)
+                self._curr_evs[k].record(self._side)
+                self._curr_queue.append(k)
+                self.last_mirror_slot = k
+                ops.curriculum_update(self._curr, msgs, SUCC_CAP)
+                self._curr_done_ev.record(self._side)
+                self._curr_pending = True
+            else:
+                self._succ_host.copy_(msgs, non_blocking=True)
+                self._succ_ev.record(self._side)
         self._succ_exchanged = True
 
     def _collect_stepwise_lstm(self, forced_act=None, noise=None):
@@ -492,6 +637,19 @@ class VecPPOTrainer:
         global (env, time)-ordered sequence to its replicated curriculum."""
         if self.curriculum is None:
             return
+        if self.device_curriculum:             # no host wait: the messages were (or are now) queued, the device does the rest
+            if not self._succ_pending:         # flags not produced by collect(): pack them now
+                self._roll_ev.record()
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(self._roll_ev)
+                    self._succ_msg = pack_local_successes(self.buf["flags"])
+                    self._pack_ev.record(self._side)
+                self._succ_pending, self._succ_exchanged = True, False
+            if not self._succ_exchanged:
+                self._exchange_successes()
+            self._succ_pending = False
+            self._poll_curriculum_mirror()
+            return
         if not self._succ_pending:             # flags not produced by collect(): pack and exchange them now
             msgs = exchange_successes(pack_local_successes(self.buf["flags"]))
             if tuple(msgs.shape) != tuple(self._succ_host.shape):
@@ -504,11 +662,11 @@ class VecPPOTrainer:
         self._succ_ev.synchronize()
         self._succ_pending = False
         bits = unpack_episode_successes(self._succ_host.numpy(), self.buf["flags"])
-        self.episodes_done += int(bits.size)            # over ALL ranks, in global (env, time) order
-        self.successes_done += int(bits.sum())
+        self._episodes_done += int(bits.size)            # over ALL ranks, in global (env, time) order
+        self._successes_done += int(bits.sum())
         self.last_success_bits = bits
         self.curriculum.update_many(bits)
-        self.radius, self.bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
+        self._radius, self._bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
 
     def train_iteration(self):
         self.collect()
