@@ -143,7 +143,7 @@ def launch(args, argv):
         why = f"timed out after {limit:.0f} s; rank processes terminated" if rc == 124 else f"rc {rc}"
         sys.stderr.write(f"[bench] headline phase failed ({why})\n")
         return rc or 1
-    if args.scaling == "weak" and not args.no_strong_phase:
+    if args.scaling == "weak" and not args.no_strong_phase and CONFIGS[args.config]["num_envs"] % args.gpus == 0:
         wall = time.time() - t0
         k2, w2 = max(3, args.steps // 2), min(args.warmup, 2)
         argv2 = ["--gpus", str(args.gpus), "--config", args.config, "--backend", args.backend, "--scaling", "strong",
@@ -569,6 +569,28 @@ def measure_exchanges(dev, n_params, own_group):
     return out
 
 
+def measure_exchanges_isolated(local, n_params, timeout=90.0):
+    """The one-rank RCCL probe in a FRESH child process with a time limit: bringing up a communicator is the one step of this
+    program that talks to a runtime outside the build, and the bench line must not depend on it.  The child touches the GPU
+    itself (nothing is exec'ed from this process's HIP state); on expiry it is killed by PID and the probe reports the fact."""
+    code = ("import json, os, sys\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "import torch, bench\n"
+            f"torch.cuda.set_device({int(local)})\n"
+            f"r = bench.measure_exchanges(torch.device('cuda', {int(local)}), {int(n_params)}, own_group=True)\n"
+            "print('PROBE ' + json.dumps(r), flush=True)\n")
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout)
+        for line in p.stdout.splitlines():
+            if line.startswith("PROBE "):
+                return json.loads(line[6:])
+        return {"error": f"probe child exited {p.returncode} without a result: {p.stderr[-200:]}"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"probe child killed after {timeout:.0f} s"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def predicted_8gpu(cfg_name, cfg, N, T, ms_iter, n_params, measured=None):
     """What the first 8-GPU SCALE record should show, from THIS run's one-GPU iteration time: weak scaling =
     8 x the per-GPU work in (t_1 + the iteration's exchanges); the exchanges are 5 all-reduces of the flat gradient
@@ -663,7 +685,7 @@ def main():
     kind = cfg.get("policy", "lstm")
     T, H = cfg["horizon"], cfg["hidden"]
     n_cfg = cfg["num_envs"]
-    if n_cfg % world:
+    if n_cfg % world and args.scaling == "strong":
         raise SystemExit(f"config {args.config}: {n_cfg} envs do not split over {world} ranks")
     n_weak, n_strong = n_cfg, n_cfg // world
     N = n_weak if args.scaling == "weak" else n_strong
@@ -704,7 +726,8 @@ def main():
     if world == 1:
         measured = None
         if not args.no_exchange_probe:
-            measured = measure_exchanges(dev, tr.policy.num_params(), own_group=not dist.is_initialized())
+            measured = (measure_exchanges(dev, tr.policy.num_params(), own_group=False) if dist.is_initialized()
+                        else measure_exchanges_isolated(local, tr.policy.num_params()))
         out["predicted_8gpu"] = predicted_8gpu(args.config, cfg, N, T, dt / args.steps * 1e3, tr.policy.num_params(), measured)
     elif not args.no_exchange_probe:
         out["measured_exchange_us"] = measure_exchanges(dev, tr.policy.num_params(), own_group=False)

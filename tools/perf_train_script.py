@@ -12,17 +12,25 @@ sys.path[:0] = [ROOT, PKG]
 import config  # noqa: E402
 import torch  # noqa: E402
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for k, v in dict(NUM_ENVS=4096, HORIZON=128, POLICY="lstm", HIDDEN=128, NUM_LAYERS=1).items():
     setattr(config, k, v)
 spec = importlib.util.spec_from_file_location("train_ppo2_0", os.path.join(PKG, "train_ppo2.0.py"))
 m = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(m)
-m.train_ppo_vectorised(iterations=5, csv_path=None, model_path=None, log_every=0)          # warm-up (allocations, RCCL-free)
+m.train_ppo_vectorised(iterations=5, csv_path=None, model_path=None, log_every=0)          # warm-up (allocations)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-tr, rows = m.train_ppo_vectorised(iterations=iters, csv_path="/tmp/perf_train_script.csv", model_path=None, log_every=0)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"train_ppo_vectorised: {iters} iterations of 4096 x 128 in {dt:.3f} s = {iters * 4096 * 128 / dt / 1e6:.1f} M env-steps/s "
-      f"({1e3 * dt / iters:.2f} ms per iteration, {len(rows)} CSV rows; includes building the trainer)")
+
+
+def run(n):
+    t0 = time.perf_counter()
+    tr, rows = m.train_ppo_vectorised(iterations=n, csv_path="/tmp/perf_train_script.csv", model_path=None, log_every=0)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, len(rows)
+
+
+t_small, _ = run(10)
+t_big, nrows = run(10 + iters)
+dt = t_big - t_small                     # the trainer's construction and the CSV write of the common part cancel
+print(f"train_ppo_vectorised at C3's shape: {iters} iterations of 4096 x 128 in {dt:.3f} s = {iters * 4096 * 128 / dt / 1e6:.1f} M env-steps/s "
+      f"({1e3 * dt / iters:.2f} ms per iteration; {nrows} CSV rows in the long run; difference of a {10 + iters}- and a 10-iteration call)")

@@ -20,7 +20,7 @@ PKG = os.path.join(ROOT, "uav-wrf-les-ppo-lstm_amd")
 sys.path[:0] = [ROOT, PKG]
 import config  # noqa: E402
 
-REF = {"v2.0": (1299, 1142500, 8.386), "v2.1": (1272, 1145498, 8.276)}
+REF = {"v2.0": (1299, 1142500, 8.386), "v2.1": (1272, 1145498, 8.276), "v1.1": (1283, 1098470, float("nan"))}
 
 
 def run(variant, seed, n, t):

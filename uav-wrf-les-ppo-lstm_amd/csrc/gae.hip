@@ -204,39 +204,59 @@ __global__ void curriculum_init_kernel(CurriculumState* s, double radius, double
     s->episodes = 0; s->successes = 0; s->hist_len = 0; s->win_succ = 0;
 }
 
-__global__ void curriculum_update_kernel(CurriculumState* st, const uint8_t* __restrict__ msgs, int world, int cap) {
-    if (threadIdx.x != 0) return;
-    CurriculumState s = *st;
+// One wave: the 64 lanes stage a message chunk in LDS (a byte load from global memory costs the single walking thread a full
+// round trip: ~0.3 us per episode, 265 us for a C3 rollout's ~800 episodes), lane 0 walks it.
+__global__ __launch_bounds__(64) void curriculum_update_kernel(CurriculumState* st, const uint8_t* __restrict__ msgs, int world, int cap) {
+    constexpr int CH = 4096;
+    __shared__ uint8_t chunk[CH];
+    __shared__ CurriculumState sh;
+    const int lane = threadIdx.x;
+    if (lane == 0) sh = *st;
+    __syncthreads();
     const size_t len = (size_t)4 + cap + 1;
     for (int r = 0; r < world; ++r) {
         const uint8_t* m = msgs + (size_t)r * len;
         long long cnt = (long long)m[0] | ((long long)m[1] << 8) | ((long long)m[2] << 16) | ((long long)m[3] << 24);
-        if (cnt > cap) { s.overflow = 1.0; cnt = cap; }      // (a rank ended more episodes than its message holds: flagged, the rest dropped)
-        for (long long k = 0; k < cnt; ++k) {
-            const int success = m[4 + k] != 0;
-            const double env_radius = s.radius;                                     // :132
-            s.episodes += 1; s.successes += success;
-            s.hist_len += 1; s.win_succ += success;                                 // :135-137 (the window never exceeds 120: cleared when full)
-            const bool full = s.hist_len >= CUR_WINDOW;
-            double rate = 0.0;
-            if (full) {
-                rate = (double)s.win_succ / (double)s.hist_len;                     // np.mean of the window
-                s.bonus = s.bonus * pow(CUR_DECAY_FACTOR, 1.0 + rate);              // :140-142 (an np.float64 from here on)
-                s.bonus_is_f64 = 1.0;
-            }
-            s.bonus = fmax(s.bonus, 0.1);                                           // :144
-            if (full) {
-                if (rate > CUR_SUCCESS_THRESHOLD)                                   // :148-152
-                    s.radius = fmax(CUR_MIN_RADIUS, s.radius * pow(CUR_RADIUS_DECAY, 2.0 + 3.0 * (rate - CUR_SUCCESS_THRESHOLD)));
-                else if (rate < 0.25)                                               // :153-157
-                    s.radius = fmin(CUR_INITIAL_RADIUS, s.radius * 1.1);
-                const double d = s.radius - env_radius;
-                if (fabs(d) > 5.0) s.radius = env_radius + 5.0 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));      // :160-161
-                s.hist_len = 0; s.win_succ = 0;                                     // :164
+        if (cnt > cap) {       // (a rank ended more episodes than its message holds: flagged, the rest dropped)
+            if (lane == 0) sh.overflow = 1.0;
+            cnt = cap;
+        }
+        for (long long base = 0; base < cnt; base += CH) {
+            const int nb = (int)((cnt - base < CH) ? cnt - base : CH);
+            __syncthreads();
+            for (int i = lane; i < nb; i += 64) chunk[i] = m[4 + base + i];
+            __syncthreads();
+            if (lane == 0) {
+                CurriculumState s = sh;
+                for (int k = 0; k < nb; ++k) {
+                    const int success = chunk[k] != 0;
+                    const double env_radius = s.radius;                                     // :132
+                    s.episodes += 1; s.successes += success;
+                    s.hist_len += 1; s.win_succ += success;                                 // :135-137 (the window never exceeds 120: cleared when full)
+                    const bool full = s.hist_len >= CUR_WINDOW;
+                    double rate = 0.0;
+                    if (full) {
+                        rate = (double)s.win_succ / (double)s.hist_len;                     // np.mean of the window
+                        s.bonus = s.bonus * pow(CUR_DECAY_FACTOR, 1.0 + rate);              // :140-142 (an np.float64 from here on)
+                        s.bonus_is_f64 = 1.0;
+                    }
+                    s.bonus = fmax(s.bonus, 0.1);                                           // :144
+                    if (full) {
+                        if (rate > CUR_SUCCESS_THRESHOLD)                                   // :148-152
+                            s.radius = fmax(CUR_MIN_RADIUS, s.radius * pow(CUR_RADIUS_DECAY, 2.0 + 3.0 * (rate - CUR_SUCCESS_THRESHOLD)));
+                        else if (rate < 0.25)                                               // :153-157
+                            s.radius = fmin(CUR_INITIAL_RADIUS, s.radius * 1.1);
+                        const double d = s.radius - env_radius;
+                        if (fabs(d) > 5.0) s.radius = env_radius + 5.0 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));      // :160-161
+                        s.hist_len = 0; s.win_succ = 0;                                     // :164
+                    }
+                }
+                sh = s;
             }
         }
     }
-    *st = s;
+    __syncthreads();
+    if (lane == 0) *st = sh;
 }
 
 extern "C" {
