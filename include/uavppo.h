@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 7   /* 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum); 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 7   /* 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -354,6 +354,15 @@ typedef struct uav_env_cfg {
  * { current_radius, explore_bonus, bonus_is_f64 (0 / 1), overflow flag }, then int64 { episodes seen, successes seen }, then
  * int32 { window length, successes in the window }.  uav_curriculum_update walks msgs[world][4 + cap + 1] rank by rank, episode
  * by episode, in ONE thread (the window logic is sequential; a few thousand episodes cost tens of microseconds on a side stream). */
+/* ---- N1 on the device: the per-episode sums behind the reference's 11 CSV columns (train_ppo2.0.py:129-135, filled at
+ * :177-183, :200-206, :230-242) for every episode that ENDED in a rollout.  rew f32 [n_env][T], info f32 [n_env][T][10] (5 reward
+ * parts | obs[2] | ..), flags u8 [n_env][T] (bit0 done, bit1 reached).  carry f64 [n_env][8]: running sums of { total reward, the 5
+ * parts } and the step count of the episode in progress, updated in place (episodes span rollouts; zero it once).  Every ended
+ * episode appends one row of 12 doubles { global env index, t, total, conc, explore, move, tke, boundary, steps, success,
+ * final_conc (obs[2] x 100 when reached, else 0), 0 } to rows [cap][12] in ARBITRARY order (count[0] = number appended, int32, zero
+ * it first; rows beyond cap are counted but dropped): a caller sorts by (env, t).  Sums are f64 and sequential in t, like a host loop. */
+int uav_episode_rows(uav_ctx* ctx, const float* rew, const float* info, const uint8_t* flags, int n_env, int T, int env_offset,
+                     double* carry, double* rows, int cap, int32_t* count, uav_stream stream);
 size_t uav_curriculum_state_bytes(void);
 int uav_curriculum_init(uav_ctx* ctx, void* state, double radius, double bonus, int bonus_is_f64, uav_stream stream);
 int uav_curriculum_update(uav_ctx* ctx, void* state, const uint8_t* msgs, int world, int cap, uav_stream stream);

@@ -395,3 +395,27 @@ def test_ppov11_loop_matches_reference_golden(golden):
     assert [r[8] for r in rows] == ep[:, 2].tolist() and [r[2] for r in rows] == ep[:, 1].tolist()
     assert np.allclose([r[1] for r in rows], ep[:, 0], rtol=1e-6)
     assert np.allclose([r[10] for r in rows], ep[:, 3]) and np.allclose(trainer.current_radius, g["curriculum"][-1, 0])
+
+
+def test_device_episode_log_equals_the_host_logger():
+    """uav_episode_rows (the CSV sums on the device, only the ended episodes' rows cross to the host) against EpisodeLogger over the
+    raw buffers, six rollouts with episodes spanning them: same episodes in the same order, integers equal, sums to 1e-9."""
+    from uavppo.episode_log import DeviceEpisodeLog, EpisodeLogger
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(300, 48, "mlp", device="cuda:0", seed=21, log_info=True, use_curriculum=False)
+    tr.radius = 120.0
+    tr.reset()
+    dev, host = DeviceEpisodeLog(tr), EpisodeLogger(300)
+    for it in range(6):
+        dev.fence()
+        tr.collect()
+        k = dev.start()
+        host.add_rollout(tr.buf["rew"].cpu().numpy(), tr.info.cpu().numpy(), tr.buf["flags"].cpu().numpy(), 120.0 - it)
+        dev.get(k, 120.0 - it)
+        tr.update()
+    dev_rows = dev.row_lists()
+    assert len(dev_rows) == len(host.rows) > 100
+    for a, b in zip(dev_rows, host.rows):
+        assert a[0] == b[0] and a[2] == b[2] and a[8] == b[8] and a[10] == b[10]
+        assert np.allclose([a[1], a[3], a[4], a[5], a[6], a[7], a[9]], [b[1], b[3], b[4], b[5], b[6], b[7], b[9]], rtol=1e-12, atol=1e-9)
+    assert any(r[8] > 48 for r in dev_rows)          # episodes that span rollouts

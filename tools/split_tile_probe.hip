@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <algorithm>
 #include <vector>
 
@@ -167,6 +168,107 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void lstm_probe_kernel(const flo
     }
 }
 
+// "halves": verdict r3 item 5.  ONE workgroup per 16-env tile as in `whole`, but the tile's two 8-env halves run half a step
+// apart: while the gate arithmetic of half B's step t - 1 (lanes j >= 8) issues, the MFMAs of half A's step t are in flight, and
+// vice versa.  Every product still computes all 16 columns (the other half's are ignored: the matrix pipe is mostly idle anyway) and
+// every gate instruction runs with half its lanes masked -- twice the instructions, but the MFMA latency and the VALU work of ONE
+// wave overlap (an MFMA holds the SIMD's vector issue for half its duration only).  Same arithmetic per env as `whole`: same h_T.
+__global__ __launch_bounds__(512) void lstm_probe_halves_kernel(const float* __restrict__ w_hh, const float* __restrict__ bias,
+                                                               const float* __restrict__ h0, float* __restrict__ h_out, int T) {
+    __shared__ __attribute__((aligned(16))) unsigned short hpl[2 * PLANE];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x;
+    const int uw = 16 * w + j, uo = 16 * w + 4 * kq;
+    f16x8 wb[4][NS][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float* src = w_hh + (size_t)(q * H + uw) * H + 32 * s + 8 * kq;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                _Float16 p0, p1;
+                split2h(src[i], p0, p1);
+                wb[q][s][0][i] = p0; wb[q][s][1][i] = p1;
+            }
+        }
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = f32x4{bias[q * H + uo], bias[q * H + uo + 1], bias[q * H + uo + 2], bias[q * H + uo + 3]};
+    float c_reg[4] = {0.f, 0.f, 0.f, 0.f}, hh[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < MT * H; i += blockDim.x) {
+        const int e = i / H, u = i % H;
+        _Float16 p0, p1;
+        split2h(h0[(size_t)(tile * MT + e) * H + u], p0, p1);
+        hpl[e * RS + u] = __builtin_bit_cast(unsigned short, p0);
+        hpl[PLANE + e * RS + u] = __builtin_bit_cast(unsigned short, p1);
+    }
+    lds_barrier();
+    const bool isA = j < 8;
+    auto products = [&](f32x4 (&acc)[4], f32x4 (&acl)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[q] = bq[q]; acl[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const unsigned short* hrow = hpl + j * RS + 8 * kq;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(hrow + 32 * s);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(hrow + PLANE + 32 * s);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acl[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[q][s][1], a0, acl[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[q][s][0], a0, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acl[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[q][s][0], a1, acl[q], 0, 0, 0);
+        }
+    };
+    // the gate arithmetic of the lanes of one half (`mine`), from that half's accumulators; parks h in LDS
+    auto cell = [&](const f32x4 (&acc)[4], const f32x4 (&acl)[4], bool mine) {
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gi = fsig(acc[0][r] + acl[0][r] * LO), gf = fsig(acc[1][r] + acl[1][r] * LO);
+                const float gg = ftanh(acc[2][r] + acl[2][r] * LO), go = fsig(acc[3][r] + acl[3][r] * LO);
+                c_reg[r] = gf * c_reg[r] + gi * gg;
+                hh[r] = go * ftanh(c_reg[r]);
+            }
+            unsigned short b[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                _Float16 p0, p1;
+                split2h(hh[r], p0, p1);
+                b[0][r] = __builtin_bit_cast(unsigned short, p0); b[1][r] = __builtin_bit_cast(unsigned short, p1);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                uint2 v;
+                v.x = (unsigned)b[pc][0] | ((unsigned)b[pc][1] << 16);
+                v.y = (unsigned)b[pc][2] | ((unsigned)b[pc][3] << 16);
+                *reinterpret_cast<uint2*>(hpl + pc * PLANE + j * RS + uo) = v;
+            }
+        }
+    };
+    f32x4 accA[4], aclA[4], accB[4], aclB[4];
+    // prologue: half B's first products (its columns of the tile's h_{-1})
+    products(accB, aclB);
+    for (int t = 0; t < T; ++t) {
+        // phase 1: half A's products of step t in flight under half B's cell of step t  (B's accumulators came from phase 2 of the
+        // iteration before -- or the prologue -- and saw h_B(t-1))
+        products(accA, aclA);
+        cell(accB, aclB, !isA);
+        lds_barrier();                                   // h_B(t) in LDS; nobody reads h_A(t-1) any more
+        // phase 2: half B's products of step t + 1 in flight under half A's cell of step t
+        if (t + 1 < T) products(accB, aclB);
+        cell(accA, aclA, isA);
+        lds_barrier();                                   // h_A(t) in LDS
+    }
+    {
+        const int e = tile * MT + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h_out[(size_t)e * H + uo + r] = hh[r];
+    }
+}
+
 template <typename F>
 static double time_ms(F&& launch, int reps = 7) {
     hipEvent_t a, b;
@@ -198,7 +300,7 @@ int main(int argc, char** argv) {
     for (auto& v : w) v = rnd() * 0.18f;
     for (auto& v : b) v = rnd() * 0.1f;
     for (auto& v : h0) v = rnd();
-    float *dw, *db, *dh0, *dout[3];
+    float *dw, *db, *dh0, *dout[4];
     unsigned short* xbuf;
     unsigned *flags, *err;
     CK(hipMalloc(&dw, w.size() * 4)); CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&dh0, h0.size() * 4));
@@ -220,6 +322,24 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(lstm_probe_kernel<true>, dim3(2 * tiles), dim3(256), 0, 0, dw, db, dh0, dout[1 + v], T, stride, xbuf, flags, err);
         });
         printf("%s: %.3f ms = %.3f us per step  (%.2fx the whole-tile schedule)\n", names[v], t, 1e3 * t / T, whole / t);
+    }
+    const double halves = time_ms([&] { hipLaunchKernelGGL(lstm_probe_halves_kernel, dim3(tiles), dim3(512), 0, 0, dw, db, dh0, dout[3], T); });
+    printf("halves (1 workgroup per tile, its two 8-env halves half a step apart): %.3f ms = %.3f us per step  (%.2fx the whole-tile schedule)\n",
+           halves, 1e3 * halves / T, whole / halves);
+    {
+        std::vector<float> r0h(h0.size()), r3(h0.size());
+        CK(hipMemcpy(r0h.data(), dout[0], r0h.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(r3.data(), dout[3], r3.size() * 4, hipMemcpyDeviceToHost));
+        size_t badh = 0;
+        double worst = 0.0;
+        for (size_t i = 0; i < r0h.size(); ++i) {
+            badh += (r0h[i] != r3[i]);
+            const double d = fabs((double)r0h[i] - (double)r3[i]);
+            if (d > worst) worst = d;
+        }
+        // (the two kernels are compiled with contraction on: acc + acl * LO fuses in one and not in the other, hence last-bit differences)
+        printf("h_T differences halves vs whole: %zu of %zu values, largest %.3g\n", badh, r0h.size(), worst);
+        if (worst > 1e-5) return 1;
     }
     unsigned herr = 0;
     CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));

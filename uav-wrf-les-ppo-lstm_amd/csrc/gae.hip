@@ -204,6 +204,49 @@ __global__ void curriculum_init_kernel(CurriculumState* s, double radius, double
     s->episodes = 0; s->successes = 0; s->hist_len = 0; s->win_succ = 0;
 }
 
+// N1: one thread walks one env row through the rollout (f64 running sums, sequential in t: what a host loop over the buffers
+// does), and appends a row for every episode that ends.  64-thread blocks: 4096 envs = 64 workgroups on a side stream.
+__global__ __launch_bounds__(64) void episode_rows_kernel(const float* __restrict__ rew, const float* __restrict__ info,
+                                                          const uint8_t* __restrict__ flags, int n, int T, int env_offset,
+                                                          double* __restrict__ carry, double* __restrict__ rows, int cap,
+                                                          int32_t* __restrict__ count) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= n) return;
+    double s[6], steps;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = carry[(size_t)e * 8 + k];
+    steps = carry[(size_t)e * 8 + 6];
+    const float* r = rew + (size_t)e * T;
+    const float* in = info + (size_t)e * T * 10;
+    const uint8_t* f = flags + (size_t)e * T;
+    for (int t = 0; t < T; ++t) {
+        s[0] += (double)r[t];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[1 + k] += (double)in[(size_t)t * 10 + k];
+        steps += 1.0;
+        const uint8_t fl = f[t];
+        if (fl & 1) {
+            const int slot = atomicAdd(count, 1);
+            if (slot < cap) {
+                double* o = rows + (size_t)slot * 12;
+                o[0] = (double)(env_offset + e); o[1] = (double)t;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) o[2 + k] = s[k];
+                o[8] = steps;
+                o[9] = (fl & 2) ? 1.0 : 0.0;
+                o[10] = (fl & 2) ? (double)in[(size_t)t * 10 + 5] * 100.0 : 0.0;           // train_ppo2.0.py:203
+                o[11] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s[k] = 0.0;
+            steps = 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) carry[(size_t)e * 8 + k] = s[k];
+    carry[(size_t)e * 8 + 6] = steps;
+}
+
 // One wave: the 64 lanes stage a message chunk in LDS (a byte load from global memory costs the single walking thread a full
 // round trip: ~0.3 us per episode, 265 us for a C3 rollout's ~800 episodes), lane 0 walks it.
 __global__ __launch_bounds__(64) void curriculum_update_kernel(CurriculumState* st, const uint8_t* __restrict__ msgs, int world, int cap) {
@@ -298,6 +341,15 @@ int uav_adv_normalise(uav_ctx* ctx, const float* adv, const float* val, int64_t 
     return 0;
 }
 
+
+int uav_episode_rows(uav_ctx* ctx, const float* rew, const float* info, const uint8_t* flags, int n_env, int T, int env_offset,
+                     double* carry, double* rows, int cap, int32_t* count, uav_stream stream) {
+    UAV_REQUIRE(ctx && rew && info && flags && carry && rows && count && n_env > 0 && T > 0 && cap > 0, "uav_episode_rows: bad argument");
+    hipLaunchKernelGGL(episode_rows_kernel, dim3((n_env + 63) / 64), dim3(64), 0, as_stream(stream), rew, info, flags, n_env, T, env_offset,
+                       carry, rows, cap, count);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
 
 size_t uav_curriculum_state_bytes(void) { return sizeof(CurriculumState); }
 

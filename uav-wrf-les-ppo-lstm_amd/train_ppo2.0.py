@@ -159,7 +159,7 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
     (RolloutMirror); the loop's only host waits are the curriculum's success bits and that copy."""
     import torch.distributed as dist
     from uavppo import field_bank
-    from uavppo.episode_log import EpisodeLogger, RolloutMirror
+    from uavppo.episode_log import DeviceEpisodeLog, EpisodeLogger, RolloutMirror
     from uavppo.trainer import VecPPOTrainer
     iterations = ITERATIONS if iterations is None and episodes is None and EPISODES is None else iterations
     episodes = EPISODES if episodes is None else episodes
@@ -169,10 +169,14 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
                        gae_mode=GAE_MODE, num_minibatches=NUM_MINIBATCHES, log_info=True, gamma=GAMMA, lam=LAMBDA,
                        clip=CLIP_EPSILON, ent_beta=ENTROPY_BETA, lr=LEARNING_RATE, epochs=EPOCHS, rank=rank, world_size=world,
                        bank=bank, bank_sources=bank_src, trend_k=TREND_K)
-    log = EpisodeLogger(NUM_ENVS)
     rows_per_iter = []                  # this rank's rows, iteration by iteration (merged in rank order at the end)
-    mirror = RolloutMirror(tr)
     traj = None
+    # The CSV rows are reduced on the device (uav_episode_rows: f64 running sums per env row, one 12-double row per ended episode)
+    # and only they cross to the host.  With a trajectory log (nc_path) the raw per-step buffers are needed on the host anyway:
+    # then they are mirrored whole and the host-side EpisodeLogger takes the sums.
+    use_dev_log = not nc_path
+    log = DeviceEpisodeLog(tr) if use_dev_log else EpisodeLogger(NUM_ENVS)
+    mirror = log if use_dev_log else RolloutMirror(tr)
     if nc_path and world == 1:       # the reference's trajectory log (train_ppo2.0.py:119-125,216-227,259); single rank only
         from netcdf_writer import NetCDFWriter
         from uavppo.episode_log import TrajectoryLogger
@@ -184,9 +188,12 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
 
     def log_rollout(p):
         slot, cslot, radius = p
-        host = mirror.get(slot)          # landed while the update's kernels were queued / running
         if radius is None:
             radius = tr.rollout_radius(cslot)
+        if use_dev_log:
+            rows_per_iter.append(log.get(slot, radius))      # landed while the update's kernels were queued / running
+            return
+        host = mirror.get(slot)
         before = len(log.rows)
         log.add_rollout(host["rew"], host["info"], host["flags"], radius)
         rows_per_iter.append(log.rows[before:])
@@ -217,6 +224,8 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
     tr.losses()
     if traj is not None:
         traj.writer.close()
+    if use_dev_log:                      # numpy blocks per iteration -> lists with the reference's types
+        rows_per_iter = [[[int(r[0]), r[1], int(r[2])] + r[3:8] + [int(r[8])] + r[9:] for r in a.tolist()] for a in rows_per_iter]
     if world > 1:                        # rank order == global env order (contiguous shards)
         gathered = [None] * world
         dist.all_gather_object(gathered, rows_per_iter)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "uav_adv_stats": (I32, [P, P, I64, P, P]),
     "uav_adv_normalise": (I32, [P, P, P, I64, P, P, P, P]),
     "uav_pack_success_bits": (I32, [P, P, I64, I32, P, P]),
+    "uav_episode_rows": (I32, [P, P, P, P, I32, I32, I32, P, P, I32, P, P]),
     "uav_curriculum_state_bytes": (SZ, []),
     "uav_curriculum_init": (I32, [P, P, C.c_double, C.c_double, I32, P]),
     "uav_curriculum_update": (I32, [P, P, P, I32, I32, P]),

@@ -60,6 +60,93 @@ class EpisodeLogger:
         return added
 
 
+class DeviceEpisodeLog:
+    """EpisodeLogger's rows with the sums taken ON THE DEVICE (uav_episode_rows): one thread per env row walks the rollout's
+    rew / info / flags with f64 running sums and appends a 12-double row per ended episode; only those rows (1.5 MB of pinned
+    capacity per rollout instead of the 23 MB of raw buffers at C3) cross to the host, on the process's side stream while the
+    update runs.  start() right after collect(), fence() before the next collect(), get(slot, radius) any time later: sorts the
+    slot's rows into (env, time) order and appends the reference's 11 columns.  Episodes span rollouts: the running sums of the
+    episodes in progress stay in a device block."""
+    CAP = 16384
+
+    def __init__(self, trainer, slots=2):
+        import torch
+        from .trainer import _side_stream
+        if trainer.info is None:
+            raise ValueError("DeviceEpisodeLog needs a trainer built with log_info=True")
+        self.tr = trainer
+        d = trainer.device
+        self.side = _side_stream(d)
+        self.carry = torch.zeros(trainer.N, 8, dtype=torch.float64, device=d)
+        self.rows_dev = [torch.zeros(self.CAP, 12, dtype=torch.float64, device=d) for _ in range(slots)]
+        self.count_dev = [torch.zeros(1, dtype=torch.int32, device=d) for _ in range(slots)]
+        self.rows_host = [torch.zeros(self.CAP, 12, dtype=torch.float64).pin_memory() for _ in range(slots)]
+        self.count_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(slots)]
+        self.done = [torch.cuda.Event() for _ in range(slots)]
+        self.ready = torch.cuda.Event()
+        self.pending = [False] * slots
+        self.k = 0
+        self.rows, self.count = [], 0
+
+    def fence(self):
+        import torch
+        for k, p in enumerate(self.pending):
+            if p:
+                torch.cuda.current_stream().wait_event(self.done[k])
+
+    def start(self):
+        import torch
+        from . import ops
+        from .dist_utils import env_shard
+        k = self.k
+        self.k = (k + 1) % len(self.done)
+        if self.pending[k]:
+            self.done[k].synchronize()
+        tr = self.tr
+        self.ready.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.ready)
+            self.count_dev[k].zero_()
+            ops.episode_rows(tr.buf["rew"], tr.info, tr.buf["flags"], self.carry, self.rows_dev[k], self.count_dev[k],
+                             env_offset=env_shard(tr.rank, tr.N)[0])
+            self.count_host[k].copy_(self.count_dev[k], non_blocking=True)
+            self.rows_host[k].copy_(self.rows_dev[k], non_blocking=True)
+            self.done[k].record(self.side)
+        self.pending[k] = True
+        return k
+
+    def get(self, k, radius):
+        """Append slot k's episodes (global (env, time) order inside the rollout); returns them as a float64 array [c, 11] in the
+        reference's column order (numpy all the way: a Python list per row cost 3.5 ms per C3 rollout)."""
+        self.done[k].synchronize()
+        self.pending[k] = False
+        c = int(self.count_host[k][0])
+        if c > self.CAP:
+            raise RuntimeError(f"DeviceEpisodeLog: {c} episodes ended in one rollout, capacity {self.CAP}")
+        r = self.rows_host[k][:c].numpy()
+        r = r[np.lexsort((r[:, 1], r[:, 0]))]
+        out = np.empty((c, 11), np.float64)
+        out[:, 0] = self.count + 1 + np.arange(c)
+        out[:, 1] = r[:, 2]                      # Total_Reward
+        out[:, 2] = r[:, 9]                      # Success
+        out[:, 3:8] = r[:, 3:8]                  # Conc / Explore / Move / TKE / Boundary
+        out[:, 8] = r[:, 8]                      # Steps
+        out[:, 9] = r[:, 10]                     # Final_Conc
+        out[:, 10] = radius
+        self.count += c
+        self.rows.append(out)
+        return out
+
+    def row_lists(self):
+        """All rows so far as Python lists with the reference's types (ints for Episode / Success / Steps)."""
+        out = []
+        for a in self.rows:
+            for r in a.tolist():
+                r[0], r[2], r[8] = int(r[0]), int(r[2]), int(r[8])
+                out.append(r)
+        return out
+
+
 class RolloutMirror:
     """The per-iteration host copies the reference-shaped training log needs (info [N,T,10], flags, rew: 21 + 0.5 + 2 MB at
     C3) without stalling the GPU: issued on the process's ONE side stream (uavppo/trainer.py: _side_stream) right behind the

@@ -140,6 +140,16 @@ def pack_success_bits(flags, cap, out=None):
     return out
 
 
+def episode_rows(rew, info, flags, carry, rows, count, env_offset=0):
+    """uav_episode_rows: per-episode sums of the episodes that ended in this rollout, appended to rows [cap, 12] f64 in arbitrary
+    order (count i32 [1], zeroed by the caller); carry f64 [N, 8] holds the episodes in progress."""
+    N, T = rew.shape
+    check(lib().uav_episode_rows(_h(rew), _p(rew, F32, (N, T), "rew"), _p(info, F32, (N, T, 10), "info"), _p(flags, U8, (N, T), "flags"),
+                                 N, T, int(env_offset), _p(carry, torch.float64, (N, 8), "carry"),
+                                 _p(rows, torch.float64, (rows.shape[0], 12), "rows"), int(rows.shape[0]), _p(count, I32, (1,), "count"),
+                                 _stream()), "uav_episode_rows")
+
+
 def curriculum_state(device, radius=50.0, bonus=0.6, bonus_is_f64=False):
     """A device-side curriculum state (uav_curriculum_*): opaque u8 block, initialised."""
     st = torch.zeros(int(lib().uav_curriculum_state_bytes()), dtype=U8, device=device)

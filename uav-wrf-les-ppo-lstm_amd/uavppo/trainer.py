@@ -251,10 +251,16 @@ class VecPPOTrainer:
         self._sync_curriculum()
         return self._radius
 
+    def _before_host_write(self):
+        """A host-side write into the device block must land behind the side stream's pending update of it."""
+        if self._curr_pending:
+            torch.cuda.current_stream().wait_event(self._curr_done_ev)
+
     @radius.setter
     def radius(self, v):
         self._radius = float(v)
         if self.device_curriculum:
+            self._before_host_write()
             self._curr[:32].view(torch.float64)[0] = self._radius
 
     @property
@@ -266,6 +272,7 @@ class VecPPOTrainer:
     def bonus(self, v):
         self._bonus = v
         if self.device_curriculum:
+            self._before_host_write()
             self._curr[:32].view(torch.float64)[1] = float(v)
             self._curr[:32].view(torch.float64)[2] = 1.0 if isinstance(v, np.float64) else 0.0
 
