@@ -269,33 +269,42 @@ __global__ __launch_bounds__(64) void curriculum_update_kernel(CurriculumState* 
             __syncthreads();
             for (int i = lane; i < nb; i += 64) chunk[i] = m[4 + base + i];
             __syncthreads();
-            if (lane == 0) {
-                CurriculumState s = sh;
-                for (int k = 0; k < nb; ++k) {
-                    const int success = chunk[k] != 0;
-                    const double env_radius = s.radius;                                     // :132
-                    s.episodes += 1; s.successes += success;
-                    s.hist_len += 1; s.win_succ += success;                                 // :135-137 (the window never exceeds 120: cleared when full)
-                    const bool full = s.hist_len >= CUR_WINDOW;
-                    double rate = 0.0;
-                    if (full) {
-                        rate = (double)s.win_succ / (double)s.hist_len;                     // np.mean of the window
-                        s.bonus = s.bonus * pow(CUR_DECAY_FACTOR, 1.0 + rate);              // :140-142 (an np.float64 from here on)
-                        s.bonus_is_f64 = 1.0;
-                    }
-                    s.bonus = fmax(s.bonus, 0.1);                                           // :144
-                    if (full) {
-                        if (rate > CUR_SUCCESS_THRESHOLD)                                   // :148-152
-                            s.radius = fmax(CUR_MIN_RADIUS, s.radius * pow(CUR_RADIUS_DECAY, 2.0 + 3.0 * (rate - CUR_SUCCESS_THRESHOLD)));
-                        else if (rate < 0.25)                                               // :153-157
-                            s.radius = fmin(CUR_INITIAL_RADIUS, s.radius * 1.1);
-                        const double d = s.radius - env_radius;
-                        if (fabs(d) > 5.0) s.radius = env_radius + 5.0 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));      // :160-161
-                        s.hist_len = 0; s.win_succ = 0;                                     // :164
-                    }
+            // Between two window closes an episode only adds to four counters, so the 64 lanes count the successes of
+            // the events up to the next close together (ballot + popcount) and every lane then carries the same state
+            // through the close's f64 arithmetic: one serial step per 120 episodes instead of one per episode.
+            CurriculumState s = sh;
+            for (int k = 0; k < nb;) {
+                const int need = CUR_WINDOW - s.hist_len;                                   // >= 1: the window is cleared when full
+                const int n = (nb - k < need) ? nb - k : need;
+                int succ = 0;
+                for (int j = 0; j < n; j += 64) {
+                    const int i = j + lane;
+                    succ += __popcll(__ballot(i < n && chunk[k + i] != 0));
                 }
-                sh = s;
+                k += n;
+                const double env_radius = s.radius;                                         // :132
+                s.episodes += n; s.successes += succ;
+                s.hist_len += n; s.win_succ += succ;                                        // :135-137
+                const bool full = s.hist_len >= CUR_WINDOW;
+                double rate = 0.0;
+                if (full) {
+                    rate = (double)s.win_succ / (double)s.hist_len;                         // np.mean of the window
+                    s.bonus = s.bonus * pow(CUR_DECAY_FACTOR, 1.0 + rate);                  // :140-142 (an np.float64 from here on)
+                    s.bonus_is_f64 = 1.0;
+                }
+                s.bonus = fmax(s.bonus, 0.1);                                               // :144 (idempotent: once per group is once per episode)
+                if (full) {
+                    if (rate > CUR_SUCCESS_THRESHOLD)                                       // :148-152
+                        s.radius = fmax(CUR_MIN_RADIUS, s.radius * pow(CUR_RADIUS_DECAY, 2.0 + 3.0 * (rate - CUR_SUCCESS_THRESHOLD)));
+                    else if (rate < 0.25)                                                   // :153-157
+                        s.radius = fmin(CUR_INITIAL_RADIUS, s.radius * 1.1);
+                    const double d = s.radius - env_radius;
+                    if (fabs(d) > 5.0) s.radius = env_radius + 5.0 * (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0));      // :160-161
+                    s.hist_len = 0; s.win_succ = 0;                                         // :164
+                }
             }
+            __syncthreads();
+            if (lane == 0) sh = s;
         }
     }
     __syncthreads();
