@@ -77,6 +77,7 @@ int uav_get_lstm_arith(const uav_ctx* ctx);
 #define UAV_DEBUG_STEP_F32 1u
 #define UAV_DEBUG_X_F32    2u
 #define UAV_DEBUG_CLUSTER 4u
+#define UAV_DEBUG_GEMM_TN_OFF 0x10u   /* the dW-shaped split-fp16 products on the older one-slab-in-flight kernel (same results; an A/B switch) */
 #define UAV_DEBUG_CLUSTER_FWD_ONLY 8u   /* with CLUSTER: only uav_lstm_fwd takes the cluster kernel, the BPTT keeps the per-step kernels */
 #define UAV_DEBUG_CLUSTER_ABL 0x1f00u  /* measurement only: cluster kernel without 0x100 peer waits, 0x200 stash stores, 0x400 peer fetch, 0x800 products (garbage results);
                                           0x1000: hand-off payload by write-through stores even when a cluster sits on one XCD (same results) */

@@ -233,6 +233,33 @@ def test_gemm_split_fp16_block_scale(ops, magnitude):
         assert e16 <= 1.5 * e32 + 1e-7, (rows, e16, e32)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 32 * 1000), (128, 512, 32 * 7), (256, 256, 64), (128, 256, 32), (384, 768, 32 * 1001)])
+def test_gemm_split_fp16_dw_kernel_equals_the_general_kernel(ops, M, N, K):
+    """The dW shape (both operands contiguous along their rows, whole 32-row slabs, 256-column tiles) runs on gemm_h3_tn8_kernel:
+    bit for bit the general kernel's result (UAV_DEBUG_GEMM_TN_OFF), with and without split-K, odd and even slab counts, a
+    single slab, block-scaled A, accumulate; and f32-accurate against f64."""
+    rng = np.random.RandomState(M + N + K)
+    a = (rng.randn(K, M) * 3e-5).astype(np.float32)
+    a[:, : M // 8] *= 1e-4
+    b = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    da, db = dev(a), dev(b)
+    amax = ops.absmax(da)
+    c0 = dev(rng.randn(M, N).astype(np.float32) * 1e-4)
+    got = ops.gemm(da, db, True, False, split_fp16=True, a_absmax=amax)
+    acc = ops.gemm(da, db, True, False, out=c0.clone(), accumulate=True, split_fp16=True, a_absmax=amax)
+    ops.set_debug_flags("gemm_tn_off")
+    try:
+        ref = ops.gemm(da, db, True, False, split_fp16=True, a_absmax=amax)
+        ref_acc = ops.gemm(da, db, True, False, out=c0.clone(), accumulate=True, split_fp16=True, a_absmax=amax)
+    finally:
+        ops.set_debug_flags()
+    assert torch.equal(got, ref) and torch.equal(acc, ref_acc)
+    want = a.T.astype(np.float64) @ b.astype(np.float64)
+    f32 = ops.gemm(da, db, True, False).cpu().numpy()
+    scale = np.abs(want).max()
+    assert np.abs(got.cpu().numpy() - want).max() / scale <= 1.5 * np.abs(f32 - want).max() / scale + 1e-7
+
+
 def test_gemm_split_fp16_refuses_other_shapes(ops):
     a, b = torch.zeros(100, 64, device=DEV), torch.zeros(64, 128, device=DEV)
     with pytest.raises(RuntimeError, match="not supported"):

@@ -47,6 +47,19 @@ def main():
         rel = ((a - b).abs().max() / a.abs().max()).item()
         print(f"{name}: exact-f32 {t32:.3f} ms ({flop / t32 / 1e9:.0f} TF)   split-fp16 {t16:.3f} ms ({flop / t16 / 1e9:.0f} TF f32-equiv, "
               f"{3 * flop / t16 / 1e9:.0f} TF executed)   max |diff| / max = {rel:.2e}", flush=True)
+    # the dW shape on the two split-fp16 kernels: the TN kernel (default) against the general one (UAV_DEBUG_GEMM_TN_OFF); same bits
+    outs = {}
+    for name, flags in (("tn kernel", ()), ("older kernel", ("gemm_tn_off",))):
+        ops.set_debug_flags(*flags)
+        for bname, b in (("y [rows x 256]", y1),):
+            t = timeit(lambda: ops.gemm(dg, b, trans_a=True, split_fp16=True, a_absmax=amax))
+            outs[(name, bname)] = ops.gemm(dg, b, trans_a=True, split_fp16=True, a_absmax=amax)
+            print(f"dW = dG^T {bname:30s} {name:13s} {t:.3f} ms ({3 * flop / t / 1e9:.0f} TF executed, "
+                  f"{(dg.numel() + b.numel()) * 4 / t / 1e6:.0f} GB/s of operand bytes)", flush=True)
+    ops.set_debug_flags()
+    for bname in ("y [rows x 256]",):
+        same = torch.equal(outs[("tn kernel", bname)], outs[("older kernel", bname)])
+        print(f"  {bname}: tn kernel == older kernel bit for bit: {same}")
     t = timeit(lambda: ops.colsum(dg))
     print(f"colsum [rows x 1024]: {t:.3f} ms ({dg.numel() * 4 / t / 1e6:.0f} GB/s)")
 

@@ -82,7 +82,7 @@ int uav_set_lstm_arith(uav_ctx* ctx, int mode) {
 int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; }
 
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags) {
-    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_CLUSTER | UAV_DEBUG_CLUSTER_FWD_ONLY | UAV_DEBUG_CLUSTER_ABL)) == 0, "uav_set_debug_flags: bad argument");
+    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_CLUSTER | UAV_DEBUG_CLUSTER_FWD_ONLY | UAV_DEBUG_CLUSTER_ABL | UAV_DEBUG_GEMM_TN_OFF)) == 0, "uav_set_debug_flags: bad argument");
     ctx->debug = flags;
     return 0;
 }

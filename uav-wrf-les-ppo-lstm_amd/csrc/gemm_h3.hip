@@ -29,6 +29,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #ifndef H3_ABL
 #define H3_ABL 0        // ablation builds only (tools/ab_gemm_h3.sh): 1 no split arithmetic, 2 no loads, 3 no MFMAs, 4 no commit
@@ -263,6 +264,193 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(int64_t M, int64_t N, int6
         }
 }
 
+// ------------------------------------------------------------------------------ TN kernel (the dW shape)
+// dW = dG^T [h_prev | y]: both operands contiguous along their ROW index, K = envs x steps down the columns.  Same arithmetic,
+// tile and K order as gemm_h3_kernel -- the results are bit-identical -- with the instruction streams rebuilt
+// (profiles/r04_gemm_tn_ablation.log: 2.31 -> 1.86 ms at 1 M x 1024 x 256):
+//   * a thread's share of a slab is a 4-row x 2-k A item and a 4-row x 4-k B item read as dwordx4 along the row index (6 loads
+//     per slab instead of 24 dword loads; whole 128-byte lines per 32 lanes), addressed as a wave-uniform row pointer + a
+//     32-bit lane byte offset; two slabs are in flight while a third is multiplied;
+//   * an item's four rows go to LDS rows e * ROWS/4 + rg (row = 4 rg + e), which keeps the piece planes k-contiguous for the
+//     b128 fragment reads; tile rows / columns are therefore PERMUTED inside the workgroup and un-permuted by the epilogue;
+//   * the MFMAs are inline asm with the accumulator TIED to the destination ("+a"): left to the register allocator, the
+//     accumulator chains of the unrolled loop bodies are renamed into one another and copied back by ~125 v_accvgpr moves
+//     per slab; one value of the next slab is split after each of the first MFMAs of a column tile, the loads follow the
+//     units that free their registers (a burst of loads stops the wave's issue for the bytes' transfer time), and a
+//     scheduling barrier after every MFMA pins that order (without it every fragment read and split is hoisted and spills);
+//   * EIGHT waves, two per SIMD, 64 x 64 wave tiles: 128 accumulator registers + two slabs of staging (2 x 24) + one column
+//     tile of B fragments ahead fit the 256 registers a wave has at this occupancy.  What binds now is LDS: per slab 128 KB
+//     of fragment reads + 48 KB of piece writes per CU at 128 B per clock take as long as the MFMAs.
+struct Tn8Regs {
+    f32x4 a[2];            // A item: rows 4 arg .. + 3 in the components, k = 2 akp + q
+    f32x4 b[4];            // B item: rows 4 brg .. + 3, k = 4 w + q
+};
+
+__global__ __launch_bounds__(512) void gemm_h3_tn8_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                          int64_t ldc, int accumulate, int64_t k_per_split,
+                                                          float* __restrict__ slabs, const unsigned* __restrict__ a_absmax,
+                                                          int tm, int tn, int S) {
+    constexpr int BN = 256;
+    using TL = H3Tile<BN>;
+    constexpr int NTW = 4;                                // 16-column tiles per wave (wave tile 64 x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned short sm16[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int G = (S > 1) ? tm * tn : tn, ngroups = (S > 1) ? S : tm;
+    const int g = (slot / G) * 8 + xcd, within = slot % G;
+    if (g >= ngroups) return;
+    const int z = (S > 1) ? g : 0;
+    const int mi = (S > 1) ? within % tm : g, ni = (S > 1) ? within / tm : within;
+    const int64_t m0 = (int64_t)mi * HM, n0 = (int64_t)ni * BN;
+    const int64_t kb = (int64_t)z * k_per_split;
+    const int64_t ke = (kb + k_per_split < K) ? kb + k_per_split : K;
+    const int nslab = (int)((ke - kb) / HK);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int fi = lane & 15, kq = lane >> 4;
+    const float sa = block_scale(a_absmax);
+
+    const int arg = t & 31, akp = t >> 5;                 // A item: rows 4 arg .., k 2 akp, 2 akp + 1
+    const int brg = lane;                                 // B item: rows 4 brg .., k 4 w ..
+    const float* Bp = B + n0;
+    const float* Ap = A + m0;
+    const unsigned ldbu = (unsigned)ldb, ldau = (unsigned)lda;
+    const unsigned oab = ((unsigned)(2 * akp) * ldau + 4u * (unsigned)arg) * 4u;
+    const unsigned obb = 16u * (unsigned)brg;
+    auto load_one = [&](Tn8Regs& r, int slab, int item, int q) {
+        slab = slab < nslab ? slab : nslab - 1;
+        const int64_t k0 = kb + (int64_t)slab * HK;
+        if (item == 0) {
+            const char* ua = reinterpret_cast<const char*>(Ap + (k0 + q) * lda);
+            r.a[q] = *reinterpret_cast<const f32x4*>(ua + oab);
+        } else {
+            const char* ub = reinterpret_cast<const char*>(Bp + (k0 + 4 * w + q) * (int64_t)ldbu);
+            r.b[q] = *reinterpret_cast<const f32x4*>(ub + obb);
+        }
+    };
+    // values in commit order: B rows first (16 values: unit e = v >> 2, k q = v & 3), then the A rows (8 values: e = v >> 1, q = v & 1)
+    auto value = [&](const Tn8Regs& r, int v, float sca) -> float {
+        return v < 16 ? r.b[v & 3][v >> 2] : r.a[(v - 16) & 1][(v - 16) >> 1] * sca;
+    };
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f16x4 lo4, hi4;
+    f16x2 lo2, hi2;
+    auto commit_value = [&](const Tn8Regs& r, unsigned short* np, int v, float sca) {
+        _Float16 p0, p1;
+        split2h(value(r, v, sca), p0, p1);
+        if (v < 16) {
+            const int e = v >> 2, q = v & 3;
+            lo4[q] = p0; hi4[q] = p1;
+            if (q == 3) {
+                unsigned short* d = np + 2 * TL::A_PLANE + (e * (BN / 4) + brg) * HKP + 4 * w;
+                *reinterpret_cast<f16x4*>(d) = lo4;
+                *reinterpret_cast<f16x4*>(d + TL::B_PLANE) = hi4;
+            }
+        } else {
+            const int e = (v - 16) >> 1, q = (v - 16) & 1;
+            lo2[q] = p0; hi2[q] = p1;
+            if (q == 1) {
+                unsigned short* d = np + (e * (HM / 4) + arg) * HKP + 2 * akp;
+                *reinterpret_cast<f16x2*>(d) = lo2;
+                *reinterpret_cast<f16x2*>(d + TL::A_PLANE) = hi2;
+            }
+        }
+    };
+
+    f32x4 acc0[4][NTW], acc1[4][NTW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            acc0[i][j] = acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(acc0[i][j]), "+a"(acc1[i][j]));
+        }
+#define TN_MFMA(ACC, FA, FB) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(FA), "v"(FB))
+
+    // one slab: 4 column tiles x 12 MFMAs; a value of slab sl + 1 is split after each of the first six MFMAs of a tile (B's 16
+    // values, then A's 8); B's four loads of slab sl + 3 follow in tile 2 once its rows are committed, A's two in tile 3
+    auto slab_body = [&](Tn8Regs& r, int buf, int sl) {
+        const unsigned short* bp = sm16 + buf * TL::BUF;
+        unsigned short* np = sm16 + (buf ^ 1) * TL::BUF;
+        const float sca = (sl + 1) < nslab ? sa : 0.f;
+        const unsigned short* a0p = bp + (wm * 64 + fi) * HKP + 8 * kq;
+        const unsigned short* b0p = bp + 2 * TL::A_PLANE + (wn * 64 + fi) * HKP + 8 * kq;
+        f16x8 a0[4], a1[4], bq[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = *reinterpret_cast<const f16x8*>(a0p + i * 16 * HKP);
+            a1[i] = *reinterpret_cast<const f16x8*>(a0p + TL::A_PLANE + i * 16 * HKP);
+        }
+        bq[0][0] = *reinterpret_cast<const f16x8*>(b0p);
+        bq[0][1] = *reinterpret_cast<const f16x8*>(b0p + TL::B_PLANE);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            if (j + 1 < NTW) {
+                bq[(j + 1) & 1][0] = *reinterpret_cast<const f16x8*>(b0p + (j + 1) * 16 * HKP);
+                bq[(j + 1) & 1][1] = *reinterpret_cast<const f16x8*>(b0p + TL::B_PLANE + (j + 1) * 16 * HKP);
+            }
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                const int i = m & 3;
+                if (m < 4) TN_MFMA(acc0[i][j], a0[i], bq[j & 1][0]);
+                else if (m < 8) TN_MFMA(acc1[i][j], a0[i], bq[j & 1][1]);
+                else TN_MFMA(acc1[i][j], a1[i], bq[j & 1][0]);
+                if (m < 6) commit_value(r, np, 6 * j + m, sca);
+                // B's values are 0..15: the last one is committed in tile 2 at m = 3; A's (16..23) in tile 3 at m = 5
+                if (j == 2 && m >= 4 && (m & 1) == 0) load_one(r, sl + 3, 1, (m - 4) >> 1);          // m = 4, 6, 8, 10
+                if (j == 2 && m == 11) load_one(r, sl + 3, 1, 3) ;
+                if (j == 3 && (m == 8 || m == 10)) load_one(r, sl + 3, 0, (m - 8) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    Tn8Regs r0, r1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { load_one(r0, 0, 1, q); load_one(r1, 1, 1, q); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { load_one(r0, 0, 0, q); load_one(r1, 1, 0, q); }
+#pragma unroll
+    for (int v = 0; v < 24; ++v) commit_value(r0, sm16, v, sa);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_one(r0, 2, 1, q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) load_one(r0, 2, 0, q);
+    __syncthreads();
+    // iteration s: slab s out of buffer s & 1, slab s + 1 into the other (from the register set that then takes slab s + 3);
+    // one rolled loop of two bodies, padded to an even count with zero slabs
+    for (int s = 0; s < nslab; s += 2) {
+        slab_body(r1, 0, s);
+        __syncthreads();
+        slab_body(r0, 1, s + 1);
+        __syncthreads();
+    }
+#undef TN_MFMA
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const float inv = 1.0f / sa;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const int pc = wn * 64 + j * 16 + fi;
+            const int64_t col = n0 + 4 * (pc & (BN / 4 - 1)) + pc / (BN / 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pr = wm * 64 + i * 16 + 4 * kq + r;
+                const int64_t row = m0 + 4 * (pr & (HM / 4 - 1)) + pr / (HM / 4);
+                const float val = (acc0[i][j][r] + H3_LO * acc1[i][j][r]) * inv;
+                if (slabs) {
+                    slabs[((int64_t)z * M + row) * N + col] = val;
+                } else {
+                    float* cp = C + row * ldc + col;
+                    *cp = (accumulate ? *cp : 0.f) + val;
+                }
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void h3_splitk_reduce_kernel(const float* __restrict__ slabs, int S, int64_t MN, int64_t N,
                                                                float* __restrict__ C, int64_t ldc,
                                                                const float* __restrict__ bias, int accumulate) {
@@ -280,13 +468,9 @@ __global__ __launch_bounds__(256) void h3_splitk_reduce_kernel(const float* __re
     for (int j = 0; j < 4; ++j) c[j] = (accumulate ? c[j] : 0.f) + o[j] + (bias ? bias[col + j] : 0.f);
 }
 
-template <int BN, bool AKC, bool BKC>
-int launch_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
-              int64_t ldc, const float* bias, int accumulate, const unsigned* a_absmax, hipStream_t st) {
-    const int tm = (int)(M / HM), tn = (int)(N / BN);
-    const int64_t tiles = (int64_t)tm * tn;
-    // split K when the tile grid cannot fill the chip: whole groups of 8 splits (one per XCD), <= workspace
-    int64_t S = 1;
+// split-K plan shared by the two kernels: whole groups of 8 splits (one per XCD) when the tile grid cannot fill the chip
+static void h3_plan(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, int64_t tiles, int64_t& S, int64_t& kps) {
+    S = 1;
     if (tiles < ctx->num_cu && K >= 64 * HK) {
         S = (ctx->num_cu + tiles - 1) / tiles;
         S = (S + 7) / 8 * 8;
@@ -295,8 +479,42 @@ int launch_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int
         if (S > max_ws) S = max_ws;
         if (S < 1) S = 1;
     }
-    int64_t kps = ((K + S - 1) / S + HK - 1) / HK * HK;
+    kps = ((K + S - 1) / S + HK - 1) / HK * HK;
     S = (K + kps - 1) / kps;
+}
+
+// dW-shaped products (see gemm_h3_tn8_kernel): A [K][M] and B [K][N] contiguous along their rows
+int launch_h3_tn(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, int accumulate, const unsigned* a_absmax, hipStream_t st) {
+    constexpr int BN = 256;
+    const int tm = (int)(M / HM), tn = (int)(N / BN);
+    const int64_t tiles = (int64_t)tm * tn;
+    int64_t S, kps;
+    h3_plan(ctx, M, N, K, tiles, S, kps);
+    float* slabs = (S > 1) ? (float*)ctx->ws : nullptr;
+    const int64_t G = (S > 1) ? tiles : tn, ngroups = (S > 1) ? S : tm;
+    const int64_t grid = 8 * G * ((ngroups + 7) / 8);
+    UAV_REQUIRE(grid < (1ll << 31), "gemm_h3: grid too large");
+    auto kern = gemm_h3_tn8_kernel;
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(kern), (int)H3Tile<BN>::LDS));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), H3Tile<BN>::LDS, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate, kps,
+                       slabs, a_absmax, tm, tn, (int)S);
+    if (S > 1) {
+        const int64_t MN = M * N, nb = (MN / 4 + 255) / 256;
+        hipLaunchKernelGGL(h3_splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, slabs, (int)S, MN, N, C, ldc,
+                           (const float*)nullptr, accumulate);
+    }
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BN, bool AKC, bool BKC>
+int launch_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+              int64_t ldc, const float* bias, int accumulate, const unsigned* a_absmax, hipStream_t st) {
+    const int tm = (int)(M / HM), tn = (int)(N / BN);
+    const int64_t tiles = (int64_t)tm * tn;
+    int64_t S, kps;
+    h3_plan(ctx, M, N, K, tiles, S, kps);
     float* slabs = (S > 1) ? (float*)ctx->ws : nullptr;
     const int64_t G = (S > 1) ? tiles : tn, ngroups = (S > 1) ? S : tm;
     const int64_t grid = 8 * G * ((ngroups + 7) / 8);
@@ -329,6 +547,17 @@ bool gemm_h3_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, i
     return true;
 }
 
+// The dW shape (both operands contiguous along their row index, whole 32-row slabs, 256-column tiles, dwordx4 loads) goes to
+// gemm_h3_tn8_kernel unless UAV_DEBUG_GEMM_TN_OFF asks for the older kernel (same results bit for bit: an A/B switch).
+bool gemm_h3_tn_ok(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B, int64_t sb_k,
+                   int64_t sb_n) {
+    if (uav_debug(UAV_DEBUG_GEMM_TN_OFF)) return false;
+    if (sa_m != 1 || sb_n != 1 || sa_k == 1 || sb_k == 1) return false;
+    if (M < HM || M % HM || N < 256 || N % 256 || K < HK || K % HK) return false;
+    if ((sa_k & 3) || (sb_k & 3) || sa_k >= (1 << 23) || sb_k >= (1 << 23)) return false;
+    return ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+}
+
 int gemm_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
             int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias, int accumulate, const unsigned* a_absmax,
             hipStream_t st) {
@@ -338,6 +567,8 @@ int gemm_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64
     const bool akc = sa_k == 1, bkc = sb_k == 1;
     const int64_t lda = akc ? sa_m : sa_k, ldb = bkc ? sb_n : sb_k;
     const bool wide = N % 256 == 0;
+    if (!bias && gemm_h3_tn_ok(M, N, K, A, sa_m, sa_k, B, sb_k, sb_n))
+        return launch_h3_tn(ctx, M, N, K, A, lda, B, ldb, C, ldc, accumulate, a_absmax, st);
 #define H3_GO(BN, AK, BK_) return launch_h3<BN, AK, BK_>(ctx, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, a_absmax, st)
     if (wide) {
         if (akc && bkc) H3_GO(256, true, true);
@@ -355,6 +586,8 @@ int gemm_h3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64
 extern "C" int uav_gemm_f16x3(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
                               const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
                               int accumulate, const float* a_absmax, uav_stream stream) {
+    UAV_REQUIRE(ctx, "uav_gemm_f16x3: NULL handle");
+    uav_enter(ctx);
     return gemm_h3(ctx, M, N, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, bias, accumulate,
                    reinterpret_cast<const unsigned*>(a_absmax), as_stream(stream));
 }

@@ -316,7 +316,7 @@ class lstm_arith:
         set_lstm_arith(self.prev, self.device)
 
 
-DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "cluster": 4, "cluster_fwd_only": 8, "abl_wait": 0x100, "abl_stash": 0x200, "abl_fetch": 0x400, "abl_mfma": 0x800, "cluster_sc1": 0x1000}
+DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "cluster": 4, "cluster_fwd_only": 8, "gemm_tn_off": 0x10, "abl_wait": 0x100, "abl_stash": 0x200, "abl_fetch": 0x400, "abl_mfma": 0x800, "cluster_sc1": 0x1000}
 
 
 def set_debug_flags(*names, device=None):
