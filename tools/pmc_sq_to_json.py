@@ -39,7 +39,8 @@ def fold(dirs):
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").strip()
+    # "void (anonymous namespace)::kernel<..>(args)" -> "kernel<..>": the namespace prefix must go BEFORE the cut at the argument list
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
 def main():

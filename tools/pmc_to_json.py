@@ -27,8 +27,8 @@ def fold(d, counter):
 
 
 def short(name):
-    name = name.split("(")[0].replace("void ", "").strip()
-    return name
+    # "void (anonymous namespace)::kernel<..>(args)" -> "kernel<..>": the namespace prefix must go BEFORE the cut at the argument list
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
 
 
 def main():
