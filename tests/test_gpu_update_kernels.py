@@ -408,6 +408,22 @@ def test_device_curriculum_matches_the_reference_traces(golden):
         d2 = ops.curriculum_read(st2.cpu().numpy())
         assert np.allclose([d2["radius"], d2["bonus"]], trace[len(seq) - 1][:2], rtol=1e-12, atol=0), name
         assert d2["episodes"] == len(seq) and d2["successes"] == int(np.sum(seq)) and not d2["overflow"]
+    # messages as long as a 4096-env rollout's (windows of 120 inside one message, several 4096-byte staging chunks, windows that
+    # straddle chunk and rank boundaries): the device state after each call equals the host class fed episode by episode
+    big = 16384
+    st4, host4 = ops.curriculum_state(DEV), Curriculum()
+    for call in range(4):
+        rows = np.zeros((3, 4 + big + 1), np.uint8)
+        for r, n in enumerate((int(rng.randint(4000, 9000)), int(rng.randint(0, 300)), int(rng.randint(9000, big + 1)))):
+            bits = (rng.rand(n) < (0.15 + 0.2 * call)).astype(np.uint8)
+            rows[r, :4] = np.frombuffer(np.int32(n).tobytes(), np.uint8)
+            rows[r, 4:4 + n] = bits
+            for b in bits:
+                host4.update(bool(b))
+        ops.curriculum_update(st4, torch.from_numpy(rows).to(DEV), big)
+        d4 = ops.curriculum_read(st4.cpu().numpy())
+        assert np.allclose([d4["radius"], d4["bonus"]], [host4.current_radius, float(host4.explore_bonus)], rtol=1e-12, atol=0), call
+        assert d4["hist_len"] == len(host4.success_history) and not d4["overflow"]
     # more episodes in a message than it holds: flagged
     st3 = ops.curriculum_state(DEV)
     m = message([1] * cap)
