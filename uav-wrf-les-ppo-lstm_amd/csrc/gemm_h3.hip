@@ -281,9 +281,12 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(int64_t M, int64_t N, int6
 //   * EIGHT waves, two per SIMD, 64 x 64 wave tiles: 128 accumulator registers + two slabs of staging (2 x 24) + one column
 //     tile of B fragments ahead fit the 256 registers a wave has at this occupancy.  What binds now is LDS: per slab 128 KB
 //     of fragment reads + 48 KB of piece writes per CU at 128 B per clock take as long as the MFMAs.
+#ifndef TN8_GROUP
+#define TN8_GROUP 3        // MFMAs (with the pair split behind them) per scheduling region; 1 .. 12 measure the same (r04_gemm_tn_ablation.log)
+#endif
 struct Tn8Regs {
     f32x4 a[2];            // A item: rows 4 arg .. + 3 in the components, k = 2 akp + q
-    f32x4 b[4];            // B item: rows 4 brg .. + 3, k = 4 w + q
+    f32x4 b[4];            // B item: rows 4 brg .. + 3, k = 4 bkg + q
 };
 
 __global__ __launch_bounds__(512) void gemm_h3_tn8_kernel(int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
@@ -312,50 +315,66 @@ __global__ __launch_bounds__(512) void gemm_h3_tn8_kernel(int64_t M, int64_t N, 
     const int fi = lane & 15, kq = lane >> 4;
     const float sa = block_scale(a_absmax);
 
-    const int arg = t & 31, akp = t >> 5;                 // A item: rows 4 arg .., k 2 akp, 2 akp + 1
-    const int brg = lane;                                 // B item: rows 4 brg .., k 4 w ..
+    // Which thread stages which (row group, k group) decides the LDS bank pattern of the piece writes (plane rows are 80 bytes =
+    // 20 banks apart: eight consecutive rows start on eight different multiples of 4 banks and then repeat).  A b32 write is
+    // conflict-free when 32 consecutive lanes are 8 row groups x 4 k pairs, a b64 write when 16 consecutive lanes are 8 row
+    // groups x 2 k groups; a load instruction then reads 128-byte segments (8 lanes x 16 bytes) of several k rows.
+    const int arg = (lane & 7) | ((lane >> 5) & 1) << 3 | (w & 1) << 4;       // A item: rows 4 arg .. (32 groups)
+    const int akl = (lane >> 3) & 3, akp = akl | (w >> 1) << 2;              //         k 2 akp, 2 akp + 1 (16 pairs)
+    const int brg = (lane & 7) | ((lane >> 4) & 3) << 3 | (w & 1) << 5;       // B item: rows 4 brg .. (64 groups)
+    const int bkl = (lane >> 3) & 1, bkg = bkl | (w >> 1) << 1;              //         k 4 bkg .. (8 groups)
     const float* Bp = B + n0;
     const float* Ap = A + m0;
     const unsigned ldbu = (unsigned)ldb, ldau = (unsigned)lda;
-    const unsigned oab = ((unsigned)(2 * akp) * ldau + 4u * (unsigned)arg) * 4u;
-    const unsigned obb = 16u * (unsigned)brg;
+    const unsigned oab = ((unsigned)(2 * akl) * ldau + 4u * (unsigned)arg) * 4u;          // lane part; the wave part is uniform
+    const unsigned obb = ((unsigned)(4 * bkl) * ldbu + 4u * (unsigned)brg) * 4u;
     auto load_one = [&](Tn8Regs& r, int slab, int item, int q) {
         slab = slab < nslab ? slab : nslab - 1;
         const int64_t k0 = kb + (int64_t)slab * HK;
         if (item == 0) {
-            const char* ua = reinterpret_cast<const char*>(Ap + (k0 + q) * lda);
+            const char* ua = reinterpret_cast<const char*>(Ap + (k0 + 8 * (w >> 1) + q) * lda);
             r.a[q] = *reinterpret_cast<const f32x4*>(ua + oab);
         } else {
-            const char* ub = reinterpret_cast<const char*>(Bp + (k0 + 4 * w + q) * (int64_t)ldbu);
+            const char* ub = reinterpret_cast<const char*>(Bp + (k0 + 8 * (w >> 1) + q) * (int64_t)ldbu);
             r.b[q] = *reinterpret_cast<const f32x4*>(ub + obb);
         }
     };
-    // values in commit order: B rows first (16 values: unit e = v >> 2, k q = v & 3), then the A rows (8 values: e = v >> 1, q = v & 1)
-    auto value = [&](const Tn8Regs& r, int v, float sca) -> float {
-        return v < 16 ? r.b[v & 3][v >> 2] : r.a[(v - 16) & 1][(v - 16) >> 1] * sca;
+    // The split of TWO values in six mixed-precision FMAs, the halves landing packed in place (common.h's split2h to the bit:
+    // every step is exact or the same single rounding): p0 = f16(x s) into the low / high half of P, r = x s - p0 (the fp16
+    // operand read from P), p1 = f16(2048 r) into Q.  Against cvt_pk / cvt / pk_add / pk_mul / cvt_pk + register moves: 3
+    // instructions per value instead of 4.5, none of them packed-f32 (two passes).
+    auto split_pair = [&](float x, float y, float s, unsigned& P, unsigned& Q) {
+        float rx, ry;
+        const float c2048 = 2048.0f;
+        asm("v_fma_mixlo_f16 %0, %4, %6, 0\n\t"
+            "v_fma_mixhi_f16 %0, %5, %6, 0\n\t"
+            "v_fma_mix_f32 %2, %4, %6, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %1, %2, %7, 0\n\t"
+            "v_fma_mixhi_f16 %1, %3, %7, 0"
+            : "=&v"(P), "=&v"(Q), "=&v"(rx), "=&v"(ry) : "v"(x), "v"(y), "s"(s), "s"(c2048));
     };
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    f16x4 lo4, hi4;
-    f16x2 lo2, hi2;
-    auto commit_value = [&](const Tn8Regs& r, unsigned short* np, int v, float sca) {
-        _Float16 p0, p1;
-        split2h(value(r, v, sca), p0, p1);
-        if (v < 16) {
-            const int e = v >> 2, q = v & 3;
-            lo4[q] = p0; hi4[q] = p1;
-            if (q == 3) {
-                unsigned short* d = np + 2 * TL::A_PLANE + (e * (BN / 4) + brg) * HKP + 4 * w;
-                *reinterpret_cast<f16x4*>(d) = lo4;
-                *reinterpret_cast<f16x4*>(d + TL::B_PLANE) = hi4;
+    // pairs in commit order: B rows first (8 pairs: row e = pp >> 1, k 2 (pp & 1), + 1), then the A rows (4 pairs: row e = pp - 8)
+    uint2 blo, bhi;
+    auto commit_pair = [&](const Tn8Regs& r, unsigned short* np, int pp, float sca) {
+        if (pp < 8) {
+            const int e = pp >> 1, h = pp & 1;
+            unsigned P, Q;
+            split_pair(r.b[2 * h][e], r.b[2 * h + 1][e], 1.0f, P, Q);
+            if (h == 0) { blo.x = P; bhi.x = Q; }
+            else {
+                blo.y = P; bhi.y = Q;
+                unsigned short* d = np + 2 * TL::A_PLANE + (e * (BN / 4) + brg) * HKP + 4 * bkg;
+                *reinterpret_cast<uint2*>(d) = blo;
+                *reinterpret_cast<uint2*>(d + TL::B_PLANE) = bhi;
             }
         } else {
-            const int e = (v - 16) >> 1, q = (v - 16) & 1;
-            lo2[q] = p0; hi2[q] = p1;
-            if (q == 1) {
-                unsigned short* d = np + (e * (HM / 4) + arg) * HKP + 2 * akp;
-                *reinterpret_cast<f16x2*>(d) = lo2;
-                *reinterpret_cast<f16x2*>(d + TL::A_PLANE) = hi2;
-            }
+            const int e = pp - 8;
+            unsigned P, Q;
+            split_pair(r.a[0][e], r.a[1][e], sca, P, Q);
+            unsigned short* d = np + (e * (HM / 4) + arg) * HKP + 2 * akp;
+            *reinterpret_cast<unsigned*>(d) = P;
+            *reinterpret_cast<unsigned*>(d + TL::A_PLANE) = Q;
         }
     };
 
@@ -397,12 +416,12 @@ __global__ __launch_bounds__(512) void gemm_h3_tn8_kernel(int64_t M, int64_t N, 
                 if (m < 4) TN_MFMA(acc0[i][j], a0[i], bq[j & 1][0]);
                 else if (m < 8) TN_MFMA(acc1[i][j], a0[i], bq[j & 1][1]);
                 else TN_MFMA(acc1[i][j], a1[i], bq[j & 1][0]);
-                if (m < 6) commit_value(r, np, 6 * j + m, sca);
-                // B's values are 0..15: the last one is committed in tile 2 at m = 3; A's (16..23) in tile 3 at m = 5
+                if (m < 6 && (m & 1)) commit_pair(r, np, 3 * j + (m >> 1), sca);
+                // B's pairs are 0..7: the last one is committed in tile 2 at m = 3; A's (8..11) in tile 3 at m = 5
                 if (j == 2 && m >= 4 && (m & 1) == 0) load_one(r, sl + 3, 1, (m - 4) >> 1);          // m = 4, 6, 8, 10
                 if (j == 2 && m == 11) load_one(r, sl + 3, 1, 3) ;
                 if (j == 3 && (m == 8 || m == 10)) load_one(r, sl + 3, 0, (m - 8) >> 1);
-                __builtin_amdgcn_sched_barrier(0);
+                if (m % TN8_GROUP == TN8_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -413,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_h3_tn8_kernel(int64_t M, int64_t N, 
 #pragma unroll
     for (int q = 0; q < 2; ++q) { load_one(r0, 0, 0, q); load_one(r1, 1, 0, q); }
 #pragma unroll
-    for (int v = 0; v < 24; ++v) commit_value(r0, sm16, v, sa);
+    for (int pp = 0; pp < 12; ++pp) commit_pair(r0, sm16, pp, sa);
 #pragma unroll
     for (int q = 0; q < 4; ++q) load_one(r0, 2, 1, q);
 #pragma unroll
