@@ -502,30 +502,31 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
 
     // ---- A operand: raw dG values of this lane, [tile mi][row 8 kq + e]; tile 2p+m <-> gate rows 64w + 32p + 2i + m
     float raw[4][8];
-    auto load_a = [&](int slab, int pair) {
+    auto load_a_one = [&](int slab, int pair, int e) {
         slab = slab < nslab ? slab : nslab - 1;                       // clamped: the tail issues harmless reloads
         // 32-bit element offsets from the (scalar) base pointer: the launch checks N*T*4H < 2^30
         const unsigned off = (unsigned)(r_begin + slab * KS6 + 8 * kq) * (4 * H) + 64 * w + 32 * pair + 2 * j;
+        const float2 t2 = *reinterpret_cast<const float2*>(dgates + (off + (unsigned)e * (4 * H)));
+        raw[2 * pair][e] = t2.x;
+        raw[2 * pair + 1][e] = t2.y;
+    };
+    auto load_a = [&](int slab, int pair) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float2 t2 = *reinterpret_cast<const float2*>(dgates + (off + (unsigned)e * (4 * H)));
-            raw[2 * pair][e] = t2.x;
-            raw[2 * pair + 1][e] = t2.y;
-        }
+        for (int e = 0; e < 8; ++e) load_a_one(slab, pair, e);
     };
     // ---- B / Y / x / dheads staging registers (one slab ahead)
     constexpr int NV = HEADS ? 9 : 8;                                // Y = the same rows of y, shifted by one
     float v[NV], hz = 0.f, xv[XV], dv[DV];
     float kv = 1.f;                                                  // keep[q0 + (lane & 7)]: read back by v_readlane
     int i_start = -1;                                                // row of this thread's group with t == 0
-    auto load_b = [&](int slab) {
+    auto load_b_y = [&](int slab, int i) {
+        slab = slab < nslab ? slab : nslab - 1;
+        const int rr = r_begin + slab * KS6 + 8 * rg - 1 + i;
+        v[i] = y[(unsigned)(rr < 0 ? 0 : rr) * H + c];
+    };
+    auto load_b_rest = [&](int slab) {
         slab = slab < nslab ? slab : nslab - 1;
         const int q0 = r_begin + slab * KS6 + 8 * rg;                 // first row of this thread's group (uniform)
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int rr = q0 - 1 + i;
-            v[i] = y[(unsigned)(rr < 0 ? 0 : rr) * H + c];
-        }
         const int tq = q0 % T;                                        // T >= 8: at most one sequence start in 8 rows
         i_start = (tq == 0) ? 0 : (tq + 7 >= T ? T - tq : -1);
         if (i_start >= 0) hz = h0[(unsigned)((q0 + i_start) / T) * H + c];
@@ -544,6 +545,11 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
             const unsigned r = (unsigned)(r_begin + slab * KS6 + (q < KS6 ? q : 0));
             dv[k] = (HEADS && a < NH && q < KS6) ? dheads[r * NH + a] : 0.f;
         }
+    };
+    auto load_b = [&](int slab) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) load_b_y(slab, i);
+        load_b_rest(slab);
     };
     auto commit_b = [&](int buf) {
         unsigned short* bp = sm16 + buf * BUF;
@@ -654,9 +660,13 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
             for (int e = 0; e < 8; ++e) sc[e] = __builtin_amdgcn_ldexpf(raw[mi][e], ne);
             split8u(sc, ap[m][0], ap[m][1]);
         }
-        load_a(sl + 1, pair);
     };
-    auto mfma_pair = [&](int buf, int pair) {
+    // The loads ride BETWEEN the column tiles of the MFMA blocks, one or two per tile, instead of in bursts of 8 / 8 / 13 behind
+    // the splits: while the memory pipe is taking a burst a wave's issue stalls for ~95 cycles per load instruction (a lone
+    // load issues in ~15: tools/vmem_issue_probe.hip, profiles/r04_wgrad_phases.log) and the pipe then idles through the
+    // matrix phases.  Pair 0's block carries the dG rows of slab sl + 1 / pair 0 (their registers were split just before it),
+    // pair 1's block those of pair 1 and the B-side rows of slab sl + 2 (their registers were committed before it).
+    auto mfma_pair = [&](int buf, int pair, int sl) {
         const unsigned short* bp = sm16 + buf * BUF;
 #pragma unroll
         for (int ni = 0; ni < NT_; ++ni) {
@@ -666,7 +676,14 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
             bb[1] = *reinterpret_cast<const f16x8*>(src + BPL);
             mac3(acc[2 * pair][ni], ap[0], bb);
             mac3(acc[2 * pair + 1][ni], ap[1], bb);
-            if (HEADS) asm volatile("" ::: "memory");              // one tile of B fragments in flight: room for the head tile and the row scales
+#pragma unroll
+            for (int e = ni; e < 8; e += NT_) load_a_one(sl + 1, pair, e);          // (H = 64 has five column tiles for eight rows)
+            if (pair == 1) {
+#pragma unroll
+                for (int i = ni; i < NV; i += NT_) load_b_y(sl + 2, i);
+                if (ni == NT_ - 1) load_b_rest(sl + 2);
+            }
+            asm volatile("" ::: "memory");                         // one tile of B fragments in flight; the loads stay where they are
         }
         if (HEADS && pair == 1) {                         // dW_head tile of this wave: dheads^T Y[:, 16w .. 16w+16)
             const unsigned short* yp = bp + 2 * BPL;
@@ -697,14 +714,13 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
     for (int sl = 0; sl < nslab; ++sl) {
         const int buf = sl & 1;
         WX_PROF_MARK(0);
-        mfma_pair(buf, 0);
+        mfma_pair(buf, 0, sl);
         WX_PROF_DEP(acc[0][NT_ - 1]); WX_PROF_DEP(acc[1][NT_ - 1]); WX_PROF_MARK(2);
         commit_b(buf ^ 1);                                // planes of slab sl + 1 (a clamped copy on the last slab)
-        load_b(sl + 2);
         WX_PROF_MARK(5);
         split_pair(sl, 1);
         WX_PROF_DEP(ap[0][0]); WX_PROF_DEP(ap[1][1]); WX_PROF_MARK(3);
-        mfma_pair(buf, 1);
+        mfma_pair(buf, 1, sl);
         WX_PROF_DEP(acc[2][NT_ - 1]); WX_PROF_DEP(acc[3][NT_ - 1]); WX_PROF_MARK(4);
         if (!late) { lds_barrier(); WX_PROF_MARK(7); }
         split_pair(sl + 1, 0);                            // pair 0 of the NEXT slab (raw loaded one slab ago)
