@@ -146,7 +146,8 @@ def launch(args, argv):
     if args.scaling == "weak" and not args.no_strong_phase and CONFIGS[args.config]["num_envs"] % args.gpus == 0:
         wall = time.time() - t0
         k2, w2 = max(3, args.steps // 2), min(args.warmup, 2)
-        argv2 = ["--gpus", str(args.gpus), "--config", args.config, "--backend", args.backend, "--scaling", "strong",
+        argv2 = ["--gpus", str(args.gpus), "--config", args.config, "--backend", args.backend, "--collectives", args.collectives,
+                 "--pg-timeout", str(args.pg_timeout), "--scaling", "strong",
                  "--steps", str(k2), "--warmup", str(w2), "--no-cpu-baseline"]
         rc2, text2 = spawn_ranks(args.gpus, me + argv2, capture_rank0=True, timeout=max(180.0, 4.0 * wall), shared_gpu=shared)
         o2 = last_json_line(text2)
@@ -324,6 +325,7 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
         ops.KERNEL_TIMER.enable(timers)
     # (the first 48 iterations only: timing events beyond HIP's pool cost a ~30 ms allocation stall inside the timed region)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 48))]
+    tr.time_rollouts(ev)           # an event pair around each of those iterations' rollouts, recorded inside train_iteration()
     barrier()
     t0 = time.perf_counter()
     verbose = os.environ.get("UAV_BENCH_VERBOSE")
@@ -332,14 +334,7 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
         faulthandler.dump_traceback_later(2.0, repeat=True, file=sys.stderr)
     for k in range(steps):
         tk = time.perf_counter()
-        if k < len(ev):
-            ev[k][0].record()
-        tr.collect()
-        if k < len(ev):
-            ev[k][1].record()
-        tr.update()
-        tr.update_curriculum()      # the iteration's one host sync (success bits; the range guard's max |param| rides along)
-        tr.iteration += 1
+        tr.train_iteration()        # the function users call: rollout, update, curriculum, the range guard's poll
         if verbose:
             print(f"[bench] step {k}: host {1e3 * (time.perf_counter() - tk):.1f} ms", file=sys.stderr, flush=True)
     barrier()
@@ -421,12 +416,12 @@ def binding_roof(bytes_moved, executed_flops, sec, flop_peak_tflops):
 
 
 def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arith="fp16x3"):
-    """Dominant kernel + whole iteration.  Top level (`bound`, `achieved`, `peak`, `unit`, `frac`) = the roof that binds:
-    HBM on the bytes the kernel actually moves (rocprofv3 counters when the committed profile matches today's kernel
-    sources, otherwise the implementation's byte formula -- `bytes_basis` says which) or the matrix pipe on the flops it
-    actually EXECUTES (three fp16 products per f32 product on the 2.5 PF pipe), whichever fraction is larger.  SURVEY
-    8(d)'s algorithmic figures (f32-equivalent flops against the f32 MFMA peak, 44 B per unit) ride along as sub-fields;
-    the f32 MFMA peak is not a roof for this implementation any more (its f32-equivalent rate exceeds it)."""
+    """Dominant kernel + whole iteration.  Top level (`bound`, `achieved`, `peak`, `unit`, `frac`) of the dominant kernel =
+    SURVEY 8(d)'s algorithmic figure (f32-equivalent flops per launch / live duration / the dense f32 MFMA peak), `traffic` =
+    HBM bytes per launch by the rocprofv3 counters (when the committed profile matches today's kernel sources, else null).
+    What the implementation really moves and executes rides along: `hbm.frac_pmc` (counter bytes against 8 TB/s),
+    `mfma.frac_executed_pipe` (three fp16 products per f32 product on the 2.5 PF pipe), `binding` (the larger of the two:
+    the roof that actually binds the launch), and the same for the whole iteration under `iteration`."""
     L = max(cfg["layers"], 1)
     units = N * T
     traffic, src = load_traffic()
@@ -445,13 +440,21 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
         fl = units * 2 * 4 * H * H                                     # dh_{t-1} = dG W_hh: one forward-equivalent product
         pmc = traffic.get(kname, {}).get("hbm_total_bytes") if fresh else None
         moved = pmc if pmc else impl_b
-        out = {"kernel": kname}
-        out.update(binding_roof(moved, mult * fl, sec, pipe_peak))
+        # Top level = SURVEY 8(d)'s figure for this kernel, as the bench contract words it: ALGORITHMIC flops per launch (2 * 4H * H
+        # per env-step, f32-equivalent: one forward-equivalent product) / the live launch duration, against the roof 8(d) names
+        # for the LSTM GEMMs, the dense f32 MFMA peak.  `traffic` = HBM bytes per launch by the counters.  What the launch
+        # actually moves / executes -- counter bytes against 8 TB/s (`hbm.frac_pmc`), three fp16 piece products per f32 product
+        # against the 2.5 PF pipe (`mfma.frac_executed_pipe`) -- rides along, as does `binding` (the larger of those two).
+        out = {"kernel": kname, "bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+               "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS}
         out.update({"traffic": pmc, "traffic_source": src, "bytes_basis": "pmc" if pmc else "formula (stash 5H read + dgates 4H written + dheads + keep)",
                     "bytes_per_launch": moved, "avg_ms": bwd["avg_ms"], "launches": bwd["n"],
-                    "note": "frac = the LARGER of (bytes the launch moves / 8 TB/s) and (executed matrix flops / the peak of the pipe "
-                            "they run on: " + pipe + "), duration live from HIP events on the launch stream.  SURVEY 8(d)'s "
-                            "algorithmic figures are under mfma.algorithmic_* and hbm.algorithmic_*",
+                    "algorithmic_flops_per_launch": fl, "algorithmic_flops_per_unit": 2 * 4 * H * H, "units_per_launch": units,
+                    "note": "frac = SURVEY 8(d) algorithmic f32-equivalent flops per launch / live HIP-event duration on the launch stream / the dense "
+                            "f32 MFMA peak (MI355X_MICROARCH.md).  The kernel EXECUTES those products as three fp16 piece products on the 2.5 PF "
+                            "pipe (mfma.frac_executed_pipe) and streams its BPTT stash (hbm.frac_pmc = counter bytes / duration / 8 TB/s; "
+                            "hbm.pmc_over_algorithmic = counter bytes over 8(d)'s 44 B per unit)",
+                    "binding": binding_roof(moved, mult * fl, sec, pipe_peak),
                     "mfma": {"algorithmic_f32_tflops": fl / sec / 1e12, "f32_peak_tflops": PEAK_F32_MFMA_TFLOPS,
                              "frac_f32_peak": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS,
                              "executed_tflops": mult * fl / sec / 1e12, "executed_pipe": pipe, "executed_pipe_peak_tflops": pipe_peak,
@@ -460,6 +463,7 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
                             "achieved_GBps_algorithmic": alg_b / sec / 1e9, "achieved_GBps_implementation": impl_b / sec / 1e9,
                             "peak_GBps": PEAK_HBM_GBPS, "frac_algorithmic": alg_b / sec / 1e9 / PEAK_HBM_GBPS,
                             "frac_implementation": impl_b / sec / 1e9 / PEAK_HBM_GBPS,
+                            "frac_pmc": (pmc / sec / 1e9 / PEAK_HBM_GBPS) if pmc else None,
                             "pmc_over_algorithmic": (pmc / alg_b) if pmc else None}})
         # north_star: "evidenced by rocprof ... MFMA utilisation": the matrix pipe's busy fraction from the SQ counters, next to
         # the analytic one (executed flops / duration / peak).  Measured under the profiler, so at the profiler's clock.
@@ -615,6 +619,40 @@ def predicted_8gpu(cfg_name, cfg, N, T, ms_iter, n_params, measured=None):
     return out
 
 
+def distributed_block(world, rank, local, dev, args, dist):
+    """What the communicator saw, for the first multi-GPU record: world size, backend, RCCL's version as torch reports it (and as
+    the C ABI's dlopen'ed copy does), and every rank's (rank, local rank, device index, device name, PCI bus id) gathered to
+    rank 0 -- N distinct devices = N ranks each on its own GPU.  Every rank calls this (the gather is a collective)."""
+    import torch
+    me = {"rank": rank, "local_rank": local, "device_index": dev.index, "pid": os.getpid()}
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        me["device_name"] = pr.name
+        me["pci_bus_id"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+        me["uuid"] = str(getattr(pr, "uuid", ""))
+    except Exception as e:
+        me["device_error"] = repr(e)[:120]
+    ranks = [me]
+    if dist.is_initialized() and world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, me)
+        ranks = got
+    out = {"world_size": world, "initialized": bool(dist.is_initialized()),
+           "backend": dist.get_backend() if dist.is_initialized() else None, "collectives": args.collectives,
+           "pg_timeout_s": args.pg_timeout, "ranks": ranks,
+           "distinct_devices": len({(r.get("pci_bus_id"), r.get("uuid"), r.get("device_index")) for r in ranks})}
+    try:
+        out["rccl_version_torch"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:
+        out["rccl_version_torch"] = repr(e)[:120]
+    try:
+        from uavppo import ops
+        out["rccl_version_abi"] = ops.rccl_version()
+    except Exception as e:
+        out["rccl_version_abi"] = repr(e)[:120]
+    return out
+
+
 def build_trainer(cfg, N, rank, world, dev, ops):
     import torch
     from uavppo.trainer import VecPPOTrainer
@@ -644,6 +682,9 @@ def main():
     ap.add_argument("--no-strong-phase", action="store_true", help="launcher mode: skip the second (strong-scaling) set of ranks")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip timing the iteration's collectives after the timed region")
+    ap.add_argument("--collectives", default="torch", choices=("torch", "abi"),
+                    help="carrier of the iteration's exchanges: torch.distributed (default) or the C ABI's own RCCL communicator (uav_allreduce)")
+    ap.add_argument("--pg-timeout", type=float, default=300.0, help="seconds before a stuck collective aborts the rank (process-group timeout)")
     ap.add_argument("--headline-timeout", type=float, default=0.0, help="launcher mode: seconds before the headline rank set is terminated (0 = config-dependent default)")
     args = ap.parse_args()
 
@@ -675,10 +716,20 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             os.environ.setdefault("MASTER_PORT", str(free_port()))
+        # a collective that never completes (a dead or missing peer) must end the run with a non-zero exit code instead of
+        # sitting in the launcher: the process group's watchdog aborts the process after `--pg-timeout` seconds
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=args.pg_timeout)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=pg_timeout)
+        if args.collectives == "abi":
+            # the three exchanges on the C ABI's own RCCL communicator (uav_allreduce & co, include/uavppo.h K9); the torch
+            # group above then only carries the 128-byte id, the barriers and the max-over-ranks time
+            from uavppo import dist_utils
+            dist_utils.use_abi_collectives(rank, world, dev)
 
     from uavppo import ops
     cfg = CONFIGS[args.config]
@@ -733,6 +784,7 @@ def main():
         out["measured_exchange_us"] = measure_exchanges(dev, tr.policy.num_params(), own_group=False)
     if rehearsal:
         out["rehearsal"] = f"one-rank {args.backend} communicator, all exchanges issued (UAVPPO_FORCE_COLLECTIVES=1)"
+    out["distributed"] = distributed_block(world, rank, local, dev, args, dist)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["cpu_baseline_vectorised"] = cpu_baseline_vectorised(T=128, H=128, n_full=4096)

@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 7   /* 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 8   /* 8: uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -72,19 +72,11 @@ int uav_get_lstm_arith(const uav_ctx* ctx);
 /* A/B switches of the h = 256 step path (tests / measurements only; results are bit-identical or within f32 tolerance):
  *   STEP_F32  uav_lstm_fwd / _bwd at h = 256 take the generic exact-f32 step path instead of the fp16-split step kernels
  *   X_F32     a wide layer input is read as f32 rows by every workgroup instead of pre-split piece planes
- *   CLUSTER   uav_lstm_fwd at h = 256 runs the persistent cluster kernel (csrc/lstm_cluster.hip: weights resident in registers,
- *             h_t exchanged between 8 workgroups through L2; bit-identical results) instead of one launch per time step */
+ * Every flag leaves results bit-identical or within f32 tolerance; nothing here can make an entry point return garbage. */
 #define UAV_DEBUG_STEP_F32 1u
 #define UAV_DEBUG_X_F32    2u
-#define UAV_DEBUG_CLUSTER 4u
 #define UAV_DEBUG_GEMM_TN_OFF 0x10u   /* the dW-shaped split-fp16 products on the older one-slab-in-flight kernel (same results; an A/B switch) */
-#define UAV_DEBUG_CLUSTER_FWD_ONLY 8u   /* with CLUSTER: only uav_lstm_fwd takes the cluster kernel, the BPTT keeps the per-step kernels */
-#define UAV_DEBUG_CLUSTER_ABL 0x1f00u  /* measurement only: cluster kernel without 0x100 peer waits, 0x200 stash stores, 0x400 peer fetch, 0x800 products (garbage results);
-                                          0x1000: hand-off payload by write-through stores even when a cluster sits on one XCD (same results) */
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags);
-/* The cluster kernels bound every wait on a peer workgroup; a wait that ran out is counted here (the launch then finishes with
- * garbage instead of hanging).  out[0] = the count since uav_create (host pointer; synchronises `stream`).  0 on a healthy run. */
-int uav_lstm_cluster_errors(uav_ctx* ctx, unsigned* out, uav_stream stream);
 /* out[0] (f32, device) = max |x[i]| over n floats, a NaN counting as +inf: the range probe for the modes above. */
 int uav_absmax(uav_ctx* ctx, const float* x, int64_t n, float* out, uav_stream stream);
 
@@ -425,6 +417,31 @@ int uav_rollout_tail(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg
                      int32_t* act_out, float* cur_obs, float* obs_seq, float* keep, int32_t* act_buf, float* val_buf,
                      float* logp_buf, float* keep_buf, float* rew_buf, float* done_buf, uint8_t* flags_buf, int32_t* nan_count,
                      uav_stream stream);
+
+/* ---- K9: the iteration's exchanges over RCCL / xGMI (SURVEY 8b `uav_allreduce`, 8e).  One process per GPU, one communicator per
+ * handle; RCCL is bound at run time (dlopen librccl.so.1 -- inside a PyTorch process the copy torch already loaded; $UAV_RCCL_LIB
+ * overrides), so the library itself has no link-time dependency on it.  A host that is not PyTorch uses these instead of
+ * torch.distributed (INTEGRATION.md "Collectives"); the Python trainer takes them with UAVPPO_COLLECTIVES=abi.
+ *   uav_comm_unique_id  rank 0 draws the 128-byte id (host memory) and hands it to the other ranks by any host channel
+ *   uav_comm_init       every rank, with the handle's device current: blocks until all `world` ranks have joined
+ *   uav_allreduce       in-place SUM of `count` f32 over the ranks on `stream`: the flat gradient before uav_clip_adam.  The loss
+ *                       kernels take inv_n = 1 / GLOBAL sample count, so the sum is the mean of train_ppo2.0.py:85 and the
+ *                       global-norm clip of :87 that follows it is identical on every rank
+ *   uav_allreduce_f64   in-place SUM of f64: uav_adv_stats' (sum, sumsq, count) before uav_adv_normalise (train_ppo2.0.py:35-39)
+ *   uav_allgather_bytes recv [world][bytes_per_rank] <- every rank's send [bytes_per_rank]: uav_pack_success_bits' message,
+ *                       consumed in rank order by uav_curriculum_update (model.py:131-164 replicated)
+ * All are asynchronous on `stream` and ordered with the kernels around them; errors (no RCCL, no communicator, RCCL's own)
+ * return non-zero with uav_last_error(). */
+#define UAV_COMM_ID_BYTES 128
+int uav_rccl_version(int* out /*host*/);
+int uav_comm_unique_id(void* id_out /*host, UAV_COMM_ID_BYTES*/);
+int uav_comm_init(uav_ctx* ctx, const void* id /*host, UAV_COMM_ID_BYTES*/, int rank, int world);
+int uav_comm_world(const uav_ctx* ctx);   /* 0: no communicator */
+int uav_comm_rank(const uav_ctx* ctx);    /* -1: no communicator */
+int uav_comm_destroy(uav_ctx* ctx);       /* also done by uav_destroy */
+int uav_allreduce(uav_ctx* ctx, float* flat_grad, int64_t count, uav_stream stream);
+int uav_allreduce_f64(uav_ctx* ctx, double* buf, int64_t count, uav_stream stream);
+int uav_allgather_bytes(uav_ctx* ctx, const void* send, void* recv, int64_t bytes_per_rank, uav_stream stream);
 
 #ifdef __cplusplus
 }

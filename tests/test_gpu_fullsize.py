@@ -1,6 +1,9 @@
-"""BASELINE.json's full C3 size (4096 envs x 128 steps, LSTM h=128) through size-independent properties:
-the oracle cannot run there in seconds, so the checks are tile independence, linearity of the gradient
-in the batch, subset agreement with the oracle, determinism and conservation of the statistics.  -m gpu."""
+"""BASELINE.json's full C3 size (4096 envs x 128 steps, LSTM h=128): the benchmarked iteration itself against the
+oracle -- rollout rows replayed (test_c3_procedural_rollout_rows_equal_oracle), then GAE, normalisation and the five
+optimiser steps of the update on the whole 524,288-sample buffer against the oracle's torch-CPU autograd update
+(test_c3_whole_iteration_matches_oracle; the oracle side takes ~10 s of host time) -- plus size-independent properties:
+tile independence, linearity of the gradient in the batch, determinism, conservation of the statistics.
+Reference: PPOV2.0/train_ppo2.0.py:15-88 (update), :157-198 (rollout).  -m gpu."""
 import numpy as np
 import pytest
 import torch
@@ -215,3 +218,18 @@ def test_c3_procedural_rollout_rows_equal_oracle(radius):
     if radius > 100:
         assert n_end >= 6
     print(f"C3 procedural replay: rows {rows}, episode ends replayed {n_end}, rows with ends in the launch {len(ended)}")
+
+
+def test_c3_whole_iteration_matches_oracle():
+    """The iteration bench.py times, at its exact shape and seed (4096 x 128, h = 128, procedural field, radius 50, own
+    actions, own noise): after the fused rollout, the update on the rollout's own buffers -- epoch 0 adopting the rollout
+    kernel's forward pass, epochs 1-4 through lstm_fwd_h3_kernel, five lstm_bwd_h3k_kernel / lstm_wgrad_h3_kernel launches,
+    clip + Adam -- against the oracle update (PPOV2.0/train_ppo2.0.py:15-88 semantics, torch-CPU autograd) of the same
+    buffers: advantages / returns, per-epoch losses, per-epoch UNclipped gradients, gradient norms, final parameters."""
+    from _iteration_check import update_vs_oracle
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=1234, use_curriculum=False)
+    tr.collect()
+    assert tr._rollout_forward_valid                    # epoch 0 will adopt the rollout's stash, as in the bench
+    m = update_vs_oracle(tr, "c3")
+    assert m["samples"] == 524288 and len(m["steps"]) == 5

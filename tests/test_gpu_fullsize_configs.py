@@ -2,9 +2,10 @@
 
   C2  256 envs x 64 steps, LSTM h=64                      whole iteration against the oracle (16,384 samples: CPU seconds)
   C4  1024 envs x 128 steps per GPU, h=128, PPOV2.1 (sigma 15), materialised bank of F=64 fields built by
-      uav_env_materialise, through rollout_lstm_kernel    oracle rows + invariants
+      uav_env_materialise, through rollout_lstm_kernel    oracle rows + invariants + whole iteration against the oracle
   C5  4096 envs x 256 steps per GPU, h=256 x 2, obs 6+2   tile independence, determinism, fp16-split vs exact-f32
-      gradient, pipelined vs per-layer backward bit-equality -- properties, the oracle cannot run 1 M samples
+      gradient, pipelined vs per-layer backward bit-equality -- properties at 1 M samples; ONE step-kernel tile of it
+      (64 envs x 256 steps, the same kernels) whole iteration against the oracle
 
 Reference shapes: PPOV2.1/environment.py:52-69 (sigma = 15 field), nn.LSTM stack PPOV2.0/model.py:206-212,
 update loop PPOV2.0/train_ppo2.0.py:15-88.  -m gpu."""
@@ -164,8 +165,50 @@ def test_c4_iteration_is_deterministic(c4):
     assert torch.equal(outs[0][2], tr.buf["obs"])           # and the same rollout as the fixture's
 
 
+def test_c4_whole_iteration_matches_oracle(c4):
+    """C4's per-GPU iteration (1024 x 128, h = 128, sigma = 15 bank, radius 90 so that episodes end inside the rollout):
+    update on the rollout's own buffers against the oracle update -- losses, gradients, norms, parameters."""
+    from _iteration_check import update_vs_oracle
+    from uavppo.trainer import VecPPOTrainer
+    tr, _, _, _ = c4
+    t2 = VecPPOTrainer(tr.N, tr.T, "lstm", hidden=128, variant="v2.1", device=DEV, seed=1234, bank=tr.bank,
+                       bank_sources=tr.bank_sources, use_curriculum=False)
+    t2.radius = 90.0
+    t2.reset()
+    t2.collect()
+    assert torch.equal(t2.buf["obs"], tr.buf["obs"])         # the rollout the row-replay test pinned to the oracle
+    m = update_vs_oracle(t2, "c4")
+    assert m["samples"] == 131072 and m["episode_ends"] >= 8
+
+
 # ------------------------------------------------------------------------------------------------------------ C5
 C5 = dict(N=4096, T=256, H=256, L=2, K=2)
+
+
+def test_c5_tile_whole_iteration_matches_oracle():
+    """One tile of C5 -- 64 envs x 256 steps, h = 256 x 2, TREND_K = 2, radius 150 (restarts inside the sequence) -- through the
+    SAME kernels as the full shape (stepper rollout whose stash epoch 0 adopts, step_fwd_h3 / cell_bwd_h3 / step_bwd_h3 with
+    the pipelined two-layer backward, split-fp16 weight-gradient GEMMs, colsum_xw): rollout replayed by the procedural oracle,
+    then the whole update against the oracle's two-layer torch-CPU LSTM (nn.LSTM stack semantics, PPOV2.0/model.py:206-212)."""
+    from _iteration_check import update_vs_oracle
+    from uavppo import ops
+    from uavppo.trainer import VecPPOTrainer
+    N, T = 64, C5["T"]
+    tr = VecPPOTrainer(N, T, "lstm", hidden=C5["H"], layers=C5["L"], variant="v2.1", device=DEV, seed=1234,
+                       use_curriculum=False, trend_k=C5["K"])
+    tr.radius = 150.0
+    tr.reset()
+    ora = pr.ProceduralVecEnv(N, 1234, "v2.1", radius=150.0, trend_k=C5["K"])
+    obs = ora.reset()
+    tr.collect()
+    assert tr._rollout_forward_valid and ops.lstm_bwd_caps(DEV, 6 + C5["K"], 256) != 0      # the fp16-split step path
+    b = {k: tr.buf[k].cpu().numpy() for k in ("obs", "act", "rew", "done")}
+    for t in range(T):
+        assert np.array_equal(b["obs"][:, t], obs), t
+        obs, rew, done, _, _, _ = ora.step(b["act"][:, t])
+        assert np.allclose(b["rew"][:, t], rew.astype(np.float32), atol=1e-6, rtol=0) and np.array_equal(b["done"][:, t] > 0, done)
+    m = update_vs_oracle(tr, "c5_tile")
+    assert m["samples"] == 16384 and m["episode_ends"] >= 4
 
 
 @pytest.fixture(scope="module")

@@ -24,6 +24,10 @@ torch.cuda.set_device(0)
 backend = os.environ.get("BACKEND", "gloo")
 if world > 1 or backend == "nccl":
     dist.init_process_group(backend, rank=rank, world_size=world)
+if os.environ.get("COLLECTIVES") == "abi":      # the three exchanges on the C ABI's own RCCL communicator (uav_allreduce & co)
+    from uavppo import dist_utils, ops
+    dist_utils.use_abi_collectives(rank, world, "cuda:0")
+    assert ops.comm_world("cuda:0") == world and ops.rccl_version() > 20000
 N = 64 // world
 kind = os.environ["POLICY"]
 if kind == "lstm64":          # fused persistent rollout + sequence kernels
@@ -91,6 +95,30 @@ def test_rccl_single_rank_path(tmp_path, policy):
     for k in ("flat", "adv", "obs"):
         assert torch.equal(a[k], b[k]), k
     assert a["gn"] == b["gn"] and a["radius"] == b["radius"] and a["hist"] == b["hist"] and a["losses"] == b["losses"]
+
+
+@pytest.mark.parametrize("policy", ["lstm64", "lstm256x2"])
+def test_abi_collectives_single_rank_path(tmp_path, policy):
+    """The same rehearsal on the C ABI's own communicator (include/uavppo.h K9: uav_comm_init, uav_allreduce, uav_allreduce_f64,
+    uav_allgather_bytes -- RCCL bound by dlopen inside libuavppo.so, no torch.distributed group at all): one rank,
+    UAVPPO_FORCE_COLLECTIVES=1, every exchange issued on the trainer's streams; BIT-identical to the job without collectives."""
+    port = 29800 + os.getpid() % 1000
+    _run(1, str(tmp_path / "plain"), port, policy)
+    _run(1, str(tmp_path / "abi"), port + 1, policy, COLLECTIVES="abi", UAVPPO_FORCE_COLLECTIVES="1")
+    a, b = torch.load(tmp_path / "plain.0"), torch.load(tmp_path / "abi.0")
+    for k in ("flat", "adv", "obs"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["gn"] == b["gn"] and a["radius"] == b["radius"] and a["hist"] == b["hist"] and a["losses"] == b["losses"]
+
+
+def test_abi_collectives_refuse_without_a_communicator():
+    from uavppo import ops
+    t = torch.zeros(8, device="cuda:0")
+    with pytest.raises(RuntimeError, match="no communicator"):
+        ops.comm_allreduce(t)
+    with pytest.raises(RuntimeError, match="no communicator"):
+        ops.comm_allgather_bytes(torch.zeros(8, dtype=torch.uint8, device="cuda:0"))
+    assert ops.comm_world("cuda:0") == 0
 
 
 @pytest.mark.parametrize("mode", ["plain", "rccl-one-rank", "two-ranks-gloo"])

@@ -27,21 +27,25 @@ for k, v in over.items():
 spec = importlib.util.spec_from_file_location("train_ppo2_0", os.path.join(PKG, "train_ppo2.0.py"))
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 out = os.environ["OUT"]
-tr, rows = m.train_ppo_vectorised(iterations=int(os.environ.get("ITERS", "2")), csv_path=out + ".csv", model_path=out + ".pth", log_every=1)
+eps = os.environ.get("EPISODES")
+if eps:       # stop at an episode count (every rank must leave the loop after the same iteration)
+    tr, rows = m.train_ppo_vectorised(episodes=int(eps), csv_path=out + ".csv", model_path=out + ".pth", log_every=3)
+else:
+    tr, rows = m.train_ppo_vectorised(iterations=int(os.environ.get("ITERS", "2")), csv_path=out + ".csv", model_path=out + ".pth", log_every=1)
 torch.save({"flat": tr.policy.flat.cpu(), "rows": rows, "radius": tr.radius, "episodes": tr.episodes_done, "obs": tr.buf["obs"].cpu(),
-            "info": tr.info.cpu()}, out + f".{tr.rank}")
+            "info": tr.info.cpu(), "iteration": tr.iteration}, out + f".{tr.rank}")
 import torch.distributed as dist
 if dist.is_initialized():
     dist.destroy_process_group()
 '''
 
 
-def _run(world, out, port, cfg, iters=2):
+def _run(world, out, port, cfg, iters=2, **extra):
     import json
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OUT=out, CFG=json.dumps(cfg), ITERS=str(iters), UAVPPO_DIST_BACKEND="gloo", GPU_MAX_HW_QUEUES="2")
+                   OUT=out, CFG=json.dumps(cfg), ITERS=str(iters), UAVPPO_DIST_BACKEND="gloo", GPU_MAX_HW_QUEUES="2", **extra)
         procs.append(subprocess.Popen([sys.executable, "-c", f"ROOT={ROOT!r}; PKG={PKG!r}\n" + WORKER], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -120,3 +124,17 @@ def test_train_script_stops_at_an_episode_count(tmp_path):
     tr, rows = m.train_ppo_vectorised(episodes=40, csv_path=str(tmp_path / "e.csv"), model_path=None, log_every=0)
     assert len(rows) == 40 and [r[0] for r in rows] == list(range(1, 41)) and tr.episodes_done >= 40
     assert all(1 <= r[8] <= 1000 for r in rows)
+
+
+def test_two_ranks_stop_together_at_an_episode_count(tmp_path):
+    """`episodes=` with WORLD_SIZE = 2: the stop decision is taken from replicated device state (a fixed curriculum-mirror slot,
+    trainer.episodes_before_rollout), not from each process's polled mirror -- so both ranks leave the loop after the SAME
+    iteration (a rank stopping alone would strand the other in the next gradient all-reduce: this test would time out) and rank 0
+    writes exactly `episodes` rows."""
+    cfg = dict(NUM_ENVS=128, HORIZON=64, POLICY="lstm", HIDDEN=64, NUM_LAYERS=1, ENV_VARIANT="v2.0", EPOCHS=1)
+    port = 29900 + os.getpid() % 1000
+    _run(2, str(tmp_path / "e2"), port, cfg, EPISODES="60")
+    a, b = torch.load(tmp_path / "e2.0", weights_only=False), torch.load(tmp_path / "e2.1", weights_only=False)
+    assert a["iteration"] == b["iteration"] and a["iteration"] >= 3
+    assert torch.equal(a["flat"], b["flat"]) and a["episodes"] == b["episodes"] >= 60
+    assert len(a["rows"]) == 60 and [r[0] for r in a["rows"]] == list(range(1, 61))

@@ -102,10 +102,12 @@ def test_rollout_sampling_statistics_and_determinism():
 
 
 # --------------------------------------------------------------------------------------------- update
-def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, epochs, gae_mode, last_val, num_minibatches=1):
+def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, epochs, gae_mode, last_val, num_minibatches=1,
+                       grads_out=None):
     """_update_model semantics (train_ppo2.0.py:15-88) with the LSTM policy, torch-CPU autograd.
     num_minibatches > 1: train_ppo2.0.py:43-53's minibatch loop with minibatch m = the whole sequences of envs
-    [m*N/M, (m+1)*N/M) (an LSTM minibatch cannot cut a sequence), one optimiser step per minibatch."""
+    [m*N/M, (m+1)*N/M) (an LSTM minibatch cannot cut a sequence), one optimiser step per minibatch.
+    grads_out: a list that receives every optimiser step's UNclipped gradient as a {name: tensor} dict."""
     if gae_mode == "reference_exact":
         adv = po.gae_reference_exact(rew, val, done)
     else:
@@ -130,6 +132,8 @@ def oracle_lstm_update(p, adam, obs, act, rew, val, logp, done, keep, h0, c0, ep
                                                ret2[sl].reshape(-1), torch.from_numpy(val[sl]).reshape(-1))
             total.backward()
             grads = {n: leaf[n].grad for n in p}
+            if grads_out is not None:
+                grads_out.append({n: g.detach().clone() for n, g in grads.items()})
             gn = po.clip_grads(grads)
             adam.step(p, grads)
             log.append([float(pl), float(vl), float(ent), gn])

@@ -17,9 +17,10 @@ struct uav_ctx {
     double* ftab;      // device tables of the table-driven f64 log / cos-sin / exp (env_core.h ft_*)
     int lstm_arith;    // UAV_ARITH_*: how the LSTM sequence kernels evaluate their f32 matrix products (uav_set_lstm_arith)
     unsigned debug;    // UAV_DEBUG_*: A/B switches of the h = 256 step path (uav_set_debug_flags)
-    unsigned* cluster_err;    // device counter: bounded waits of the cluster kernels that ran out (lstm_cluster.hip)
     hipStream_t side[3];      // uav_lstm_bwd_stack: one stream per layer below the top (created on first use)
     hipEvent_t side_ev[8];    // fork / join + a small ring of per-step hand-off events per side stream
+    void* comm;               // ncclComm_t of this process's rank (comm.hip: uav_comm_init), or NULL
+    int comm_rank, comm_world;
 };
 
 // arithmetic / debug switches of the call in flight on this thread (set from the handle by the LSTM entry points; the

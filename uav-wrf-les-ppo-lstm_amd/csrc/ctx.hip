@@ -50,12 +50,13 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->pow075 = nullptr;
     c->wave = nullptr;
     c->ftab = nullptr;
+    c->comm = nullptr;
+    c->comm_rank = -1;
+    c->comm_world = 0;
     // process-level override of the default arithmetic, read here once (never on a call path)
     c->lstm_arith = getenv("UAV_LSTM_F32_MFMA") ? UAV_ARITH_F32_MFMA : (getenv("UAV_LSTM_BF16X6") ? UAV_ARITH_BF16X6 : UAV_ARITH_FP16X3);
-    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u) |
-               (getenv("UAV_LSTM_CLUSTER") ? UAV_DEBUG_CLUSTER : 0u);
-    c->cluster_err = nullptr;
-    if (hipMalloc(&c->ws, ws_bytes) != hipSuccess || hipMalloc(&c->cluster_err, 256) != hipSuccess || hipMemset(c->cluster_err, 0, 256) != hipSuccess) {
+    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u);
+    if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
         (void)hipFree(c->ws);
         delete c;
         uav_set_error("uav_create: hipMalloc(%zu) failed", ws_bytes);
@@ -63,7 +64,6 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     }
     if (env_init_tables(c) != 0) {
         (void)hipFree(c->ws);
-        (void)hipFree(c->cluster_err);
         (void)hipFree(c->pow075);
         (void)hipFree(c->wave);
         (void)hipFree(c->ftab);
@@ -82,26 +82,19 @@ int uav_set_lstm_arith(uav_ctx* ctx, int mode) {
 int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; }
 
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags) {
-    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_CLUSTER | UAV_DEBUG_CLUSTER_FWD_ONLY | UAV_DEBUG_CLUSTER_ABL | UAV_DEBUG_GEMM_TN_OFF)) == 0, "uav_set_debug_flags: bad argument");
+    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_GEMM_TN_OFF)) == 0, "uav_set_debug_flags: bad argument");
     ctx->debug = flags;
-    return 0;
-}
-
-int uav_lstm_cluster_errors(uav_ctx* ctx, unsigned* out, uav_stream stream) {
-    UAV_REQUIRE(ctx && out, "uav_lstm_cluster_errors: NULL argument");
-    UAV_CHECK_HIP(hipMemcpyAsync(out, ctx->cluster_err, 4, hipMemcpyDeviceToHost, as_stream(stream)));
-    UAV_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
     return 0;
 }
 
 void uav_destroy(uav_ctx* ctx) {
     if (!ctx) return;
+    (void)uav_comm_destroy(ctx);
     for (auto& e : ctx->side_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& s : ctx->side)
         if (s) (void)hipStreamDestroy(s);
     (void)hipFree(ctx->ws);
-    (void)hipFree(ctx->cluster_err);
     (void)hipFree(ctx->pow075);
     (void)hipFree(ctx->wave);
     (void)hipFree(ctx->ftab);

@@ -668,18 +668,10 @@ static bool h3_step_ok(int H) {
 }
 
 // fp16-split step path of uav_lstm_fwd for h = 256 (input projection included: the caller does NOT pre-fill the stash)
-bool lstm_c8_ok(const uav_ctx* ctx, int I, int H);
-bool lstm_c8_fits(int I, int T);
-int lstm_c8_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh, const float* keep,
-                const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn, float* cn, float* stash,
-                hipStream_t st);
-
 int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
                 const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn,
                 float* cn, float* stash, hipStream_t st) {
     constexpr int H = 256;
-    // the whole time loop as ONE persistent cluster launch (lstm_cluster.hip), bit-identical to the per-step launches below
-    if (lstm_c8_ok(ctx, I, H) && lstm_c8_fits(I, T)) return lstm_c8_fwd(ctx, x, I, w_ih, b_ih, b_hh, keep, h0, c0, w_hh, N, T, y, hn, cn, stash, st);
     const int64_t NH = (int64_t)N * H;
     int IP = (I + 31) / 32 * 32;
     IP = IP <= 32 ? 32 : (IP <= 64 ? 64 : (IP <= 128 ? 128 : 256));        // instantiated slab counts: 1, 2, 4, 8
@@ -884,18 +876,10 @@ static int h3_bwd_attr() {
     return 0;
 }
 
-bool lstm_c8_bwd_fits(int T);
-int lstm_c8_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy, const float* dheads,
-                const float* w_head, int n_heads, const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0,
-                float* dc0, const float* w_ih, float* dx, hipStream_t st);
-static bool c8_bwd_ok(const uav_ctx* ctx, int T) { return lstm_c8_ok(ctx, 8, 256) && lstm_c8_bwd_fits(T) && !uav_debug(UAV_DEBUG_CLUSTER_FWD_ONLY); }
-
 static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh, const float* dy,
                        const float* dheads, const float* w_head, int n_heads,
                        const float* dhn, const float* dcn, int N, int T, float* dgates, float* dh0, float* dc0,
                        const float* w_ih, float* dx, hipStream_t st) {
-    // the whole BPTT as ONE persistent cluster launch (lstm_cluster.hip)
-    if (c8_bwd_ok(ctx, T)) return lstm_c8_bwd(ctx, keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, dgates, dh0, dc0, w_ih, dx, st);
     const size_t need = H3Bwd::need(N);
     UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
     int rc;
@@ -916,23 +900,6 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
 int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
                       const float* w_head, int n_heads, int N, int T, hipStream_t st) {
     UAV_REQUIRE(nl >= 1 && nl <= 4, "uav_lstm_bwd_stack: 1..4 layers, got %d", nl);
-    if (c8_bwd_ok(ctx, T)) {
-        // cluster kernels: one launch per layer, top down on the caller's stream (a cluster launch takes every CU: layers are not
-        // overlapped, and never with another cluster launch)
-        for (int l = 0; l < nl; ++l) {
-            const uav_lstm_bwd_layer& a = layers[l];
-            UAV_REQUIRE(a.stash && a.w_hh && a.dgates, "uav_lstm_bwd_stack: layer %d: NULL stash / w_hh / dgates", l);
-            UAV_REQUIRE(l + 1 == nl || (a.w_ih && a.dx), "uav_lstm_bwd_stack: layer %d feeds the layer below: w_ih and dx are required", l);
-        }
-        for (int l = 0; l < nl; ++l) {
-            const uav_lstm_bwd_layer& a = layers[l];
-            const int rc = lstm_c8_bwd(ctx, a.keep, a.stash, a.w_hh, l == 0 ? dy : layers[l - 1].dx, l == 0 ? dheads : nullptr,
-                                       l == 0 ? w_head : nullptr, l == 0 ? n_heads : 0, a.dhn, a.dcn, N, T, a.dgates, a.dh0, a.dc0,
-                                       l + 1 < nl ? a.w_ih : nullptr, l + 1 < nl ? a.dx : nullptr, st);
-            if (rc) return rc;
-        }
-        return 0;
-    }
     const size_t need = H3Bwd::need(N);
     UAV_REQUIRE((size_t)nl * need + (64u << 20) <= ctx->ws_bytes, "uav_lstm_bwd_stack: workspace too small for %d layers", nl);
     int rc;

@@ -79,10 +79,16 @@ def _update_model(buffer, model, optimizer):
         raise RuntimeError("NaN in probs")                                     # :58-62
 
 
-def train_ppo(episodes=2000, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth"):
-    """Reference-shaped single-environment loop (train_ppo2.0.py:110-261) on the HIP kernels."""
+def train_ppo(episodes=None, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth"):
+    """Reference-shaped single-environment loop (train_ppo2.0.py:110-261) on the HIP kernels; `episodes` = the reference's 2000
+    (train_ppo2.0.py:128) when not given.  With NUM_ENVS > 1, another POLICY or WORLD_SIZE > 1 the vectorised loop runs instead;
+    what ends it, in this order: an `episodes` argument given HERE by the caller; else config.EPISODES when set; else
+    config.ITERATIONS when set; else the reference's 2000 episodes."""
     if NUM_ENVS > 1 or POLICY != "mlp" or WORLD_SIZE > 1:
-        return train_ppo_vectorised(csv_path=csv_path, model_path=model_path)
+        if episodes is None and ITERATIONS is None and EPISODES is None:
+            episodes = 2000
+        return train_ppo_vectorised(csv_path=csv_path, model_path=model_path, episodes=episodes)
+    episodes = 2000 if episodes is None else episodes
     env = MethaneEnv()
     model = PPOActorCritic(6, 5)
     optimizer = ClipAdam(model.parameters(), lr=LEARNING_RATE)
@@ -224,7 +230,18 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
     # The loop never waits for the device except for copies that landed an iteration ago: the curriculum lives on the device
     # (uavppo/trainer.py, device_curriculum), the per-iteration logs are read from pinned mirrors one iteration late, the episode
     # count that ends the run is the lagged one (the run may collect one or two rollouts more than it needs; rows are cut).
-    while (iterations is None or it < iterations) and (episodes is None or tr.episodes_lagged < episodes):
+    # With several ranks the episode count that ends the run must be one every rank reads identically: the polled mirror
+    # (`episodes_lagged`) depends on when each process's copy happened to land, so a rank could leave the loop an iteration before
+    # its peers and strand them in the next all-reduce.  There the count comes from a FIXED mirror slot -- the state before the
+    # rollout two iterations back, waited for -- which is replicated device state, hence equal on all ranks at this point.
+    slots = []                       # mirror slot of every rollout so far (device curriculum)
+
+    def episodes_for_stop():
+        if world == 1 or not tr.device_curriculum:
+            return tr.episodes_lagged
+        return tr.episodes_before_rollout(slots[-2]) if len(slots) >= 2 else 0
+
+    while (iterations is None or it < iterations) and (episodes is None or episodes_for_stop() < episodes):
         mirror.fence()
         tr.collect()
         slot = mirror.start()
@@ -235,6 +252,9 @@ def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", mo
         if pending is not None:
             log_rollout(pending)
         pending = (slot, tr.last_mirror_slot, None) if tr.device_curriculum else (slot, None, tr.rollout_radius())
+        if tr.device_curriculum:
+            slots.append(tr.last_mirror_slot)
+            del slots[:-3]
         it += 1
         if log_every and it % log_every == 0:
             pl, vl, ent = tr.losses()              # (also where NaN probabilities raise, on every rank together)

@@ -40,7 +40,6 @@ SIGNATURES = {
     "uav_set_lstm_arith": (I32, [P, I32]),
     "uav_get_lstm_arith": (I32, [P]),
     "uav_set_debug_flags": (I32, [P, C.c_uint]),
-    "uav_lstm_cluster_errors": (I32, [P, P, P]),
     "uav_absmax": (I32, [P, P, I64, P, P]),
     "uav_gae": (I32, [P, P, P, P, P, I32, I32, F32, F32, I32, P, P]),
     "uav_adv_stats": (I32, [P, P, I64, P, P]),
@@ -85,6 +84,15 @@ SIGNATURES = {
     "uav_env_materialise": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, P]),
     "uav_rollout": (I32, [P, P, I32, C.POINTER(EnvCfg), I32, P, I32, I32, U64, P, P, P, P, P, P, P, P, P, P,
                           P, P, P, P, P, P, P, P, P, P]),
+    "uav_rccl_version": (I32, [C.POINTER(C.c_int)]),
+    "uav_comm_unique_id": (I32, [P]),
+    "uav_comm_init": (I32, [P, P, I32, I32]),
+    "uav_comm_world": (I32, [P]),
+    "uav_comm_rank": (I32, [P]),
+    "uav_comm_destroy": (I32, [P]),
+    "uav_allreduce": (I32, [P, P, I64, P]),
+    "uav_allreduce_f64": (I32, [P, P, I64, P]),
+    "uav_allgather_bytes": (I32, [P, P, P, I64, P]),
 }
 
 _lib = None

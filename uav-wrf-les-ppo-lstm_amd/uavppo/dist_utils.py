@@ -1,6 +1,12 @@
 """Data-parallel plumbing: env shards per rank, and the three exchanges of one iteration
-(SURVEY 8e).  Backend-agnostic torch.distributed calls ('nccl' == RCCL over xGMI on the GPU box;
-'gloo' in the CPU tests).  No data-path collective exists: rollout buffers never leave a rank."""
+(SURVEY 8e).  Two carriers, the same three calls:
+
+  torch.distributed (default)   backend-agnostic ('nccl' == RCCL over xGMI on the GPU box; 'gloo' in the CPU tests)
+  the C ABI (UAVPPO_COLLECTIVES=abi, or use_abi_collectives())   uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes of
+                                include/uavppo.h on the handle's own RCCL communicator, issued on the caller's stream -- what
+                                a host that is not PyTorch would call (INTEGRATION.md "Collectives")
+
+No data-path collective exists: rollout buffers never leave a rank."""
 from __future__ import annotations
 
 import os
@@ -8,18 +14,57 @@ import os
 import torch
 import torch.distributed as dist
 
+_ABI = {"on": False, "world": 1, "rank": 0}
+
+
+def use_abi_collectives(rank, world_size, device=None, uid=None):
+    """Carry the iteration's exchanges on the C ABI's own RCCL communicator.  Rank 0 draws the 128-byte id; with an initialised
+    torch.distributed group (any backend: it is only the host channel for those bytes) it is broadcast through it, otherwise
+    the caller passes `uid` itself (a file, MPI, a socket ...).  Call before the trainer is built, like init_process_group."""
+    from . import ops
+    if uid is None:
+        box = [ops.comm_unique_id() if rank == 0 else None]
+        if world_size > 1:
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("use_abi_collectives: pass `uid` (rank 0's ops.comm_unique_id()) or initialise torch.distributed "
+                                   "as the host channel for it")
+            dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    ops.comm_init(uid, rank, world_size, device)
+    _ABI.update(on=True, world=int(world_size), rank=int(rank))
+
+
+def abi_collectives():
+    return _ABI["on"]
+
 
 def world():
+    if _ABI["on"]:
+        return _ABI["world"]
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 def collectives_on():
     """True when the iteration's exchanges must be issued: more than one rank, or UAVPPO_FORCE_COLLECTIVES=1 with an
-    initialised process group (a one-rank RCCL communicator then carries every exchange unchanged: how the RCCL code
-    path is exercised on a one-GPU box, tests/test_gpu_multirank.py::test_rccl_single_rank_path)."""
+    initialised process group / ABI communicator (a one-rank RCCL communicator then carries every exchange unchanged: how the
+    RCCL code path is exercised on a one-GPU box, tests/test_gpu_multirank.py::test_rccl_single_rank_path)."""
+    forced = os.environ.get("UAVPPO_FORCE_COLLECTIVES") == "1"
+    if _ABI["on"]:
+        return _ABI["world"] > 1 or forced
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size() > 1 or os.environ.get("UAVPPO_FORCE_COLLECTIVES") == "1"
+    return dist.get_world_size() > 1 or forced
+
+
+def allreduce_sum(t):
+    """In-place sum of a small f32 / f64 tensor over the ranks on whichever carrier is up (no-op without collectives)."""
+    if collectives_on():
+        if _ABI["on"] and t.is_cuda:
+            from . import ops
+            ops.comm_allreduce(t)
+        else:
+            dist.all_reduce(t)
+    return t
 
 
 def env_shard(rank, envs_per_rank):
@@ -31,18 +76,14 @@ def env_shard(rank, envs_per_rank):
 def allreduce_adv_stats(stats3):
     """(sum, sum of squares, count) of the advantages over ALL ranks: the reference normalises over
     the whole buffer (train_ppo2.0.py:35-39)."""
-    if collectives_on():
-        dist.all_reduce(stats3)
-    return stats3
+    return allreduce_sum(stats3)
 
 
 def allreduce_grad(flat_grad):
     """ONE all-reduce (sum) of the flat gradient per optimiser step.  Every rank's loss is already
     scaled by 1/(global sample count), so the sum IS the global-mean gradient; the clip norm is
     computed after it, identically on all ranks."""
-    if collectives_on():
-        dist.all_reduce(flat_grad)
-    return flat_grad
+    return allreduce_sum(flat_grad)
 
 
 SUCC_CAP = 16384          # per-rank capacity of the fixed-size success message (episodes ended in one rollout)
@@ -71,6 +112,9 @@ def exchange_successes(msg):
     """The messages of all ranks, stacked [world, 4 + SUCC_CAP + 1], after ONE all-gather (a view of `msg` at world 1)."""
     if not collectives_on():
         return msg[None]
+    if _ABI["on"] and msg.is_cuda:
+        from . import ops
+        return ops.comm_allgather_bytes(msg)
     parts = [torch.empty_like(msg) for _ in range(world())]
     dist.all_gather(parts, msg)
     return torch.stack(parts)
@@ -106,6 +150,9 @@ def gather_episode_flags(flags):
     feed the SAME episode sequence to their replicated curriculum."""
     if not collectives_on():
         return flags
+    if _ABI["on"] and flags.is_cuda:
+        from . import ops
+        return ops.comm_allgather_bytes(flags.reshape(-1)).reshape(world() * flags.shape[0], *flags.shape[1:])
     parts = [torch.empty_like(flags) for _ in range(world())]
     dist.all_gather(parts, flags)
     return torch.cat(parts, 0)

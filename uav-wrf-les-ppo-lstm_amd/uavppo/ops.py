@@ -316,7 +316,7 @@ class lstm_arith:
         set_lstm_arith(self.prev, self.device)
 
 
-DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "cluster": 4, "cluster_fwd_only": 8, "gemm_tn_off": 0x10, "abl_wait": 0x100, "abl_stash": 0x200, "abl_fetch": 0x400, "abl_mfma": 0x800, "cluster_sc1": 0x1000}
+DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "gemm_tn_off": 0x10}
 
 
 def set_debug_flags(*names, device=None):
@@ -324,11 +324,56 @@ def set_debug_flags(*names, device=None):
     check(lib().uav_set_debug_flags(Context.get(device).handle, sum(DEBUG_FLAGS[n] for n in names)), "uav_set_debug_flags")
 
 
-def lstm_cluster_errors(device=None):
-    """Bounded waits of the h = 256 cluster kernels that ran out since the handle was created (0 on a healthy run); host sync."""
-    out = C.c_uint(0)
-    check(lib().uav_lstm_cluster_errors(Context.get(device).handle, C.byref(out), _stream()), "uav_lstm_cluster_errors")
+# ---- K9: RCCL behind the ABI (csrc/comm.hip; include/uavppo.h "K9")
+def rccl_version():
+    """RCCL's version code (e.g. 22706) as the library the ABI binds reports it."""
+    out = C.c_int(0)
+    check(lib().uav_rccl_version(C.byref(out)), "uav_rccl_version")
     return int(out.value)
+
+
+def comm_unique_id():
+    """128 opaque bytes drawn by rank 0 (ncclGetUniqueId); hand them to every rank's comm_init over any host channel."""
+    buf = C.create_string_buffer(128)
+    check(lib().uav_comm_unique_id(buf), "uav_comm_unique_id")
+    return bytes(buf.raw)
+
+
+def comm_init(uid, rank, world, device=None):
+    """Join the job's communicator with this device's handle (blocks until all `world` ranks have called it)."""
+    if len(uid) != 128:
+        raise RuntimeError("comm_init: the unique id is 128 bytes")
+    check(lib().uav_comm_init(Context.get(device).handle, C.c_char_p(uid), int(rank), int(world)), "uav_comm_init")
+
+
+def comm_world(device=None):
+    return int(lib().uav_comm_world(Context.get(device).handle))
+
+
+def comm_destroy(device=None):
+    check(lib().uav_comm_destroy(Context.get(device).handle), "uav_comm_destroy")
+
+
+def comm_allreduce(t):
+    """In-place sum over the ranks on the current stream: f32 (the flat gradient) or f64 (advantage statistics, loss sums)."""
+    if t.dtype == torch.float32:
+        check(lib().uav_allreduce(_h(t), _p(t, F32, name="t"), t.numel(), _stream()), "uav_allreduce")
+    elif t.dtype == torch.float64:
+        check(lib().uav_allreduce_f64(_h(t), _p(t, torch.float64, name="t"), t.numel(), _stream()), "uav_allreduce_f64")
+    else:
+        raise RuntimeError(f"comm_allreduce: f32 or f64, got {t.dtype}")
+    return t
+
+
+def comm_allgather_bytes(msg):
+    """[world, len(msg)] u8: every rank's message, in rank order."""
+    w = comm_world(msg.device)
+    if w < 1:
+        raise RuntimeError("comm_allgather_bytes: no communicator on this device's handle")
+    out = torch.empty(w, msg.numel(), dtype=torch.uint8, device=msg.device)
+    check(lib().uav_allgather_bytes(_h(msg), _p(msg, torch.uint8, name="msg"), _p(out, torch.uint8, name="out"), msg.numel(), _stream()),
+          "uav_allgather_bytes")
+    return out
 
 
 def get_lstm_arith(device=None):

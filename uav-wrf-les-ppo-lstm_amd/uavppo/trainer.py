@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, collectives_on, env_shard, exchange_successes, pack_local_successes,
+from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, allreduce_sum, collectives_on, env_shard, exchange_successes, pack_local_successes,
                          unpack_episode_successes)
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
@@ -122,7 +122,9 @@ class VecPPOTrainer:
         self.use_fused_tail = True           # ... and heads + sample + env step + store of a step as ONE launch (A/B switch)
         self._rollout_forward_valid = False
         self.record = False          # tests: keep (loss_sums, grad norm) of every optimiser step
+        self.record_grads = False    # tests: ... and the (all-reduced, unclipped) flat gradient of every optimiser step + its parameters
         self.log = []
+        self.grad_log = []
         # range guard of the fp16-split kernels: device maxima [|param|, |obs|, |h0|], mirrored to pinned host memory
         self.ranges = torch.zeros(3, **f32)
         self._ranges_host = torch.zeros(4, 3, dtype=torch.float32).pin_memory()      # ring: the host may run iterations ahead
@@ -233,6 +235,8 @@ class VecPPOTrainer:
             latest = self._curr_queue.pop(0)
         if latest is not None:
             d = ops.curriculum_read(self._curr_host[latest].numpy())
+            if d["overflow"]:          # surfaced one or two rollouts late, never at the end of a long run only
+                raise RuntimeError(f"device curriculum: a rank ended more than {SUCC_CAP} episodes in one rollout (message capacity)")
             self._radius = d["radius"]
             self._bonus = np.float64(d["bonus"]) if d["bonus_is_f64"] else d["bonus"]
             self._episodes_done, self._successes_done, self._hist_len = d["episodes"], d["successes"], d["hist_len"]
@@ -245,6 +249,19 @@ class VecPPOTrainer:
         k = self.last_mirror_slot if k is None else k
         self._curr_evs[k].synchronize()
         return ops.curriculum_read(self._curr_host[k].numpy())["radius"]
+
+    def episodes_before_rollout(self, k):
+        """Episodes the whole job had finished BEFORE the rollout whose mirror went to slot k (its `last_mirror_slot`): waits for
+        that 64-byte copy only.  The mirror is taken on the device between two curriculum updates, from state every rank holds
+        identically -- so this value, unlike the polled `episodes_lagged`, is the same on every rank at the same program point:
+        what a multi-rank loop must base its stop decision on (a rank that stops alone leaves the others in the next all-reduce)."""
+        if not self.device_curriculum:
+            return self._episodes_done
+        self._curr_evs[k].synchronize()
+        d = ops.curriculum_read(self._curr_host[k].numpy())
+        if d["overflow"]:
+            raise RuntimeError(f"device curriculum: a rank ended more than {SUCC_CAP} episodes in one rollout (message capacity)")
+        return d["episodes"]
 
     @property
     def radius(self):
@@ -620,6 +637,8 @@ class VecPPOTrainer:
                 elif not self.fused_mlp:
                     grad = self.policy.backward(self.dheads)
                 allreduce_grad(grad)              # RCCL sum over ranks; inv_n already holds 1/global count
+                if self.record_grads:            # (gradient, parameters it was taken at)
+                    self.grad_log.append((grad.clone(), self.policy.flat.clone()))
                 self.opt_step += 1
                 ops.clip_adam(self.policy.flat, grad, self.exp_avg, self.exp_avg_sq, self.opt_step, hp["lr"],
                               max_norm=hp["max_grad_norm"], gnorm_out=self.gnorm, pmax_out=self.ranges[0:1])
@@ -675,8 +694,18 @@ class VecPPOTrainer:
         self.curriculum.update_many(bits)
         self._radius, self._bonus = self.curriculum.current_radius, self.curriculum.explore_bonus
 
+    def time_rollouts(self, event_pairs):
+        """Measurement hook (bench.py): the next len(event_pairs) calls of train_iteration() record a (start, end) pair of
+        torch.cuda.Event around their rollout on the current stream -- the loop that is timed stays train_iteration() itself."""
+        self._iter_events = list(event_pairs)[::-1]
+
     def train_iteration(self):
+        ev = self._iter_events.pop() if getattr(self, "_iter_events", None) else None
+        if ev is not None:
+            ev[0].record()
         self.collect()
+        if ev is not None:
+            ev[1].record()
         sums = self.update()
         self.update_curriculum()
         self.poll_param_range()
@@ -690,8 +719,7 @@ class VecPPOTrainer:
         # raise together (a rank raising alone would leave the others waiting in the next all-reduce)
         t = torch.cat([self.loss_sums, self.nan_count.to(torch.float64)])
         if self._coll:
-            import torch.distributed as dist
-            dist.all_reduce(t)
+            allreduce_sum(t)
         s = t.cpu().numpy()
         if s[3] > 0 or s[4] > 0:
             raise RuntimeError("NaN in probs")
