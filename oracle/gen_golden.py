@@ -397,6 +397,26 @@ def gen_train_lstm():
         losses.append(float(loss))
     out.update({f"post/{k}": v for k, v in sd_to_np(net.state_dict()).items()})
     out.update(losses=np.asarray(losses), gnorms=np.asarray(gnorms))
+    # the same loop body on RAGGED sequences: forward(x, lengths) packs them (model.py:229-240: pack_padded_sequence with
+    # enforce_sorted=False, the output at step lengths[i] - 1 of sequence i goes to the head); zero padding behind each length
+    net.load_state_dict({k[5:]: torch.from_numpy(v) for k, v in out.items() if k.startswith("init/")})
+    opt = torch.optim.AdamW(net.parameters(), lr=3e-4)
+    lens = [int(v) for v in rng.randint(1, xb.size(1) + 1, size=len(xb))]
+    lens[0], lens[1] = xb.size(1), 1                                   # a full-length and a one-step sequence among them
+    xr = xb.clone()
+    for i, L in enumerate(lens):
+        xr[i, L:] = 0.0
+    rl, rg = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        o = net(xr.unsqueeze(-1), lengths=lens)
+        loss = crit(o, yb)
+        loss.backward()
+        rg.append(float(torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)))
+        opt.step()
+        rl.append(float(loss))
+    out.update({f"ragged_post/{k}": v for k, v in sd_to_np(net.state_dict()).items()})
+    out.update(ragged_lengths=np.asarray(lens), ragged_x=xr.numpy(), ragged_losses=np.asarray(rl), ragged_gnorms=np.asarray(rg))
     # scheduler trace (torch itself)
     dummy = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-4)
     sch = torch.optim.lr_scheduler.ReduceLROnPlateau(dummy, mode="min", factor=0.5, patience=5)

@@ -20,7 +20,8 @@ Pinning (tests/golden/train_lstm_v21.npz, gen_golden.py train_lstm_v21): the ref
 random.seed(5); three optimiser steps on the torch modules its (function-local) PeakAndStopPredictor is built from.
 Pinning (tests/golden/train_lstm_v20.npz, oracle/gen_golden.py train_lstm): the reference's own SequenceDataset on synthetic
 sequences, and three optimiser steps of its model / criterion / AdamW / clipping run in eval mode (dropout cannot be given
-masks in the reference: with dropout on, the restatement is pinned by its structure only).
+masks in the reference: with dropout on, the restatement is pinned by its structure only), on full-length windows AND on
+ragged sequences through the reference's forward(x, lengths) (pack_padded_sequence, model.py:229-240).
 """
 import numpy as np
 import torch
@@ -41,9 +42,11 @@ def sequence_dataset(sequences, source_concs, training_size):
     return X, np.asarray(labels, np.float32), lo, hi
 
 
-def predictor_forward(p, x, masks=None):
+def predictor_forward(p, x, masks=None, lengths=None):
     """p: dict of tensors with the reference's state_dict keys; x [B, T, 1]; masks: None (eval) or dict with
-    'l0','l1' [B, T, H] and 'head' [B, 64], already scaled by 1/(1-p)."""
+    'l0','l1' [B, T, H] and 'head' [B, 64], already scaled by 1/(1-p).  lengths (list / array of B ints, or None = all T):
+    model.py:229-240 packs the sequences, so sequence i ends at step lengths[i] - 1 and THAT output feeds the head; an LSTM is
+    causal, so running the padded steps too and picking the output at lengths[i] - 1 is the same function."""
     B = x.shape[0]
     seq = x.transpose(0, 1)
     for l in range(3):
@@ -53,7 +56,10 @@ def predictor_forward(p, x, masks=None):
                                             p[f"lstm.bias_ih_l{l}"], p[f"lstm.bias_hh_l{l}"], None)
         if masks is not None and l < 2:
             seq = seq * masks[f"l{l}"].transpose(0, 1)
-    h = seq[-1]
+    if lengths is None:
+        h = seq[-1]
+    else:
+        h = seq[torch.as_tensor(np.asarray(lengths), dtype=torch.long) - 1, torch.arange(B)]
     z = F.linear(h, p["fc.0.weight"], p["fc.0.bias"])
     a = torch.relu(F.layer_norm(z, (z.shape[1],), p["fc.1.weight"], p["fc.1.bias"], 1e-5))
     if masks is not None:
@@ -79,10 +85,10 @@ class AdamWState:
             params[k].addcdiv_(self.m[k], denom, value=-self.lr / bc1)
 
 
-def train_step(params, opt, x, y, masks=None, beta=2.0, max_norm=1.0):
+def train_step(params, opt, x, y, masks=None, beta=2.0, max_norm=1.0, lengths=None):
     """One optimiser step in place on `params` (dict of leaf-less tensors).  Returns (loss, grad_norm)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    out = predictor_forward(leaf, x, masks)
+    out = predictor_forward(leaf, x, masks, lengths)
     loss = F.smooth_l1_loss(out, y, beta=beta)
     loss.backward()
     grads = {k: leaf[k].grad for k in params}

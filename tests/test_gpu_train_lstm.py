@@ -58,6 +58,42 @@ def test_three_eval_mode_steps_match_the_reference_golden(tl):
         assert np.allclose(v.cpu().numpy(), want, rtol=2e-3, atol=3e-6), k      # Adam turns 1e-6 gradient noise into ~1e-6 steps
 
 
+def test_three_steps_on_ragged_sequences_match_the_reference_golden(tl):
+    """model.py:229-240's forward(x, lengths) in the training loop: three optimiser steps on zero-padded ragged sequences
+    (lengths 1..10) against the reference's own packed-sequence run; and, with dropout masks, against the oracle."""
+    from evaluate_with_lstm import ConcentrationThresholdPredictor
+    g = np.load(GOLD, allow_pickle=False)
+    model = ConcentrationThresholdPredictor(hidden_size=32, device=DEV)
+    model.load_state_dict({k[5:]: g[k] for k in g.files if k.startswith("init/")})
+    tr = tl.PredictorTrainer(model, lr=3e-4)
+    x = torch.from_numpy(g["ragged_x"]).to(DEV)[:, :, None].contiguous()
+    y = torch.from_numpy(g["Y"][:24]).to(DEV)
+    lens = g["ragged_lengths"]
+    for k in range(3):
+        loss = tr.train_step(x, y, masks=None, lengths=lens)
+        assert np.isclose(float(loss.item()), g["ragged_losses"][k], rtol=2e-5), (k, float(loss.item()), g["ragged_losses"][k])
+        assert np.isclose(float(tr.gnorm.item()), g["ragged_gnorms"][k], rtol=2e-4)
+    for k, v in model.state_dict().items():
+        assert np.allclose(v.cpu().numpy(), g["ragged_post/" + k], rtol=2e-3, atol=3e-6), k
+    with pytest.raises(ValueError):
+        tr.train_step(x, y, lengths=[0] * 24)
+    # dropout masks + ragged lengths against the oracle
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    opt = lt.AdamWState(params, lr=3e-4)
+    opt.t, opt.m, opt.v = 3, {}, {}
+    o = 0
+    names = [(f"lstm.{k}", v) for k, v in model.lstm.p.items()] + list(model.fc.items())
+    for name, v in names:                                      # the trainer's Adam state, cut into the oracle's tensors
+        n = v.numel()
+        opt.m[name] = tr.exp_avg[o:o + n].view(v.shape).cpu().clone()
+        opt.v[name] = tr.exp_avg_sq[o:o + n].view(v.shape).cpu().clone()
+        o += n
+    masks = tr.draw_masks(24, x.shape[1])
+    want_loss, want_gn = lt.train_step(params, opt, x.cpu(), y.cpu(), masks={k: v.cpu() for k, v in masks.items()}, lengths=lens)
+    loss = tr.train_step(x, y, masks, lengths=lens)
+    assert np.isclose(float(loss.item()), want_loss, rtol=2e-5) and np.isclose(float(tr.gnorm.item()), want_gn, rtol=3e-4)
+
+
 @pytest.mark.parametrize("H", [128, 64])
 def test_train_step_with_dropout_masks_matches_oracle(tl, H):
     from evaluate_with_lstm import ConcentrationThresholdPredictor

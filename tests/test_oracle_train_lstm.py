@@ -44,6 +44,28 @@ def test_three_optimiser_steps_match_reference(gold):
         assert np.allclose(v.numpy(), want, rtol=1e-4, atol=2e-7), k
 
 
+def test_three_optimiser_steps_on_ragged_sequences_match_reference(gold):
+    """The reference's forward(x, lengths) -- pack_padded_sequence, the output at step lengths[i] - 1 of sequence i
+    (PPOV2.0/model.py:229-240) -- for three optimiser steps on zero-padded sequences of lengths 1..10."""
+    params = {k[5:]: torch.from_numpy(gold[k].copy()) for k in gold.files if k.startswith("init/")}
+    opt = lt.AdamWState(params, lr=3e-4)
+    x, y = torch.from_numpy(gold["ragged_x"])[:, :, None], torch.from_numpy(gold["Y"][:24])
+    lens = gold["ragged_lengths"]
+    assert lens.min() == 1 and lens.max() == x.shape[1] and len(set(lens.tolist())) >= 6
+    for k in range(3):
+        loss, gn = lt.train_step(params, opt, x, y, masks=None, lengths=lens)
+        assert np.isclose(loss, gold["ragged_losses"][k], rtol=2e-6), (k, loss, gold["ragged_losses"][k])
+        assert np.isclose(gn, gold["ragged_gnorms"][k], rtol=2e-5)
+    for k, v in params.items():
+        assert np.allclose(v.numpy(), gold["ragged_post/" + k], rtol=1e-4, atol=2e-7), k
+    # what lies behind a sequence's end cannot matter
+    x2 = x.clone()
+    for i, L in enumerate(lens):
+        x2[i, L:] = 7.0
+    with torch.no_grad():
+        assert torch.equal(lt.predictor_forward(params, x, None, lens), lt.predictor_forward(params, x2, None, lens))
+
+
 def test_reduce_lr_on_plateau_matches_torch(gold):
     sch = lt.ReduceLROnPlateauOracle(3e-4)
     lrs = [sch.step(float(m)) for m in gold["sched_metrics"]]

@@ -104,11 +104,22 @@ class PredictorTrainer:
         m = lambda shape, p: (torch.rand(shape, generator=self.gen, device=dev) >= p).to(F32) / (1.0 - p)
         return {"l0": m((B, T, H), self.P_LSTM), "l1": m((B, T, H), self.P_LSTM), "head": m((B, 64), self.P_HEAD)}
 
-    def train_step(self, x, y, masks=None, beta=2.0, max_norm=1.0):
-        """x [B, T, 1], y [B] on the device; masks from draw_masks() or None (eval-mode step).  Returns the loss (f64[1] tensor)."""
+    def train_step(self, x, y, masks=None, beta=2.0, max_norm=1.0, lengths=None):
+        """x [B, T, 1], y [B] on the device; masks from draw_masks() or None (eval-mode step).  lengths: None (every sequence
+        has T steps -- all SequenceDataset produces) or B ints in 1..T for zero-padded ragged sequences, the
+        ConcentrationThresholdPredictor.forward(x, lengths) of model.py:229-240: sequence i ends at step lengths[i] - 1, that
+        output feeds the head and only that step receives the head's gradient (the padded steps run and are ignored: an LSTM is
+        causal, so this equals pack_padded_sequence).  Returns the loss (f64[1] tensor)."""
         m, p, fc, g = self.model, self.model.lstm.p, self.model.fc, self.g
         B, T, _ = x.shape
         H = m.lstm.hidden_size
+        rows = torch.arange(B, device=x.device)
+        if lengths is None:
+            last = torch.full((B,), T - 1, dtype=torch.long, device=x.device)
+        else:
+            last = torch.as_tensor(np.asarray(lengths), dtype=torch.long, device=x.device) - 1
+            if last.numel() != B or int(last.min()) < 0 or int(last.max()) >= T:
+                raise ValueError(f"lengths: {B} values in 1..{T} expected")
         z0 = torch.zeros(B, H, dtype=F32, device=x.device)
         # ---- forward, keeping what BPTT needs
         xs, ys, stashes = [x.contiguous()], [], []
@@ -119,7 +130,7 @@ class PredictorTrainer:
             stashes.append(st)
             if l < 2:
                 xs.append(yl * masks[f"l{l}"] if masks is not None else yl)
-        h = ys[2][:, T - 1].contiguous()
+        h = ys[2][rows, last].contiguous()
         z = ops.gemm(h, fc["fc.0.weight"], trans_b=True, bias=fc["fc.0.bias"])
         a, rstd = ops.ln_relu(z, fc["fc.1.weight"], fc["fc.1.bias"], want_stats=True)      # z now holds xhat
         ad = a * masks["head"] if masks is not None else a
@@ -138,9 +149,9 @@ class PredictorTrainer:
         ops.gemm(dz, h, trans_a=True, out=g["fc.0.weight"])
         ops.colsum(dz, out=g["fc.0.bias"])
         dh = ops.gemm(dz, fc["fc.0.weight"])
-        # ---- backward: LSTM stack, top layer first; only the last step of the top layer receives a gradient
+        # ---- backward: LSTM stack, top layer first; only the last step of each sequence receives the head's gradient
         dy = torch.zeros(B, T, H, dtype=F32, device=x.device)
-        dy[:, T - 1] = dh
+        dy[rows, last] = dh
         for l in (2, 1, 0):
             r = ops.lstm_bwd(xs[l], None, stashes[l], p[f"weight_ih_l{l}"], p[f"weight_hh_l{l}"], ys[l], z0, dy=dy,
                              need_dx=(l > 0), dw_ih=g[f"lstm.weight_ih_l{l}"], dw_hh=g[f"lstm.weight_hh_l{l}"],
