@@ -309,9 +309,14 @@ def cpu_baseline_vectorised(T=128, H=128, n_sample=4096, n_full=4096, epochs=5, 
 
 
 # ------------------------------------------------------------------------------------------------ measurement
-def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
+def measure(tr, steps, warmup, world, dev, ops, dist, timers=(), dominant=("lstm_bwd",), breakdown_iters=3):
     """`warmup` untimed iterations, then exactly `steps` timed ones between barrier + synchronize pairs;
-    returns (max-over-ranks seconds, rollout ms per iteration, kernel timers)."""
+    returns (max-over-ranks seconds, rollout ms per iteration, kernel timers).
+
+    Inside the timed region only the DOMINANT kernel's launches are bracketed with HIP events on the launch stream (what
+    `roofline` needs, live): an event pair costs ~5 us of device idle per bracketed launch (rocprofv3 trace of round 5:
+    profiles/r05_trace_gaps_*.txt -- 20 brackets were 0.11 ms of a 7 ms C3 iteration, 7 % of a C2 iteration).  The other kernels
+    of `timers` and the rollout are timed the same way over `breakdown_iters` EXTRA iterations after the timed region."""
     import torch
 
     def barrier():
@@ -321,11 +326,9 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
 
     for _ in range(warmup):
         tr.train_iteration()
-    if timers:
-        ops.KERNEL_TIMER.enable(timers)
-    # (the first 48 iterations only: timing events beyond HIP's pool cost a ~30 ms allocation stall inside the timed region)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 48))]
-    tr.time_rollouts(ev)           # an event pair around each of those iterations' rollouts, recorded inside train_iteration()
+    live = tuple(t for t in timers if t in dominant)
+    if live:
+        ops.KERNEL_TIMER.enable(live)
     barrier()
     t0 = time.perf_counter()
     verbose = os.environ.get("UAV_BENCH_VERBOSE")
@@ -345,8 +348,20 @@ def measure(tr, steps, warmup, world, dev, ops, dist, timers=()):
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    summary = ops.KERNEL_TIMER.summary() if timers else {}
+    summary = ops.KERNEL_TIMER.summary() if live else {}
     ops.KERNEL_TIMER.disable()
+    # per-kernel breakdown + rollout time: a few more iterations of the same loop, outside the timed region
+    rest = tuple(t for t in timers if t not in live)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(breakdown_iters)]
+    if rest:
+        ops.KERNEL_TIMER.enable(rest)
+    tr.time_rollouts(ev)           # an event pair around each of those iterations' rollouts, recorded inside train_iteration()
+    for _ in range(breakdown_iters):
+        tr.train_iteration()
+    barrier()
+    if rest:
+        summary.update(ops.KERNEL_TIMER.summary())
+        ops.KERNEL_TIMER.disable()
     tr.losses()     # raises (on every rank) if any NaN probability was seen (reference convention)
     roll_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     return dt, roll_ms, summary
@@ -480,9 +495,11 @@ def roofline_block(cfg, N, T, H, timers, dt_iter, epochs, reused_fwd, kind, arit
     I = 6 + cfg.get("trend_k", 0)
     if kind == "lstm":
         fwd_fl = 2 * 4 * H * (I + H) + (L - 1) * 2 * 4 * H * (H + H) + 2 * H * NHEADS
-        # implementation bytes: rollout stash (6H + H + heads + 44 B) once, then per epoch fwd 7H written (minus the reused one),
-        # bwd 5H + 4H, wgrad 4H + H (+x), all f32
-        impl_it = units * 4 * L * ((6 * H + H) + (epochs - (1 if reused_fwd else 0)) * 7 * H + epochs * (9 * H + 5 * H)) \
+        # implementation bytes: per forward pass (the rollout's included) gates 4H + c_prev H + y H written -- with I <= 6 the
+        # stash's h_prev slot is not written at all (the weight gradients take h_prev from y); wider inputs (C5) write it and
+        # the fp16 piece planes of y as well: 8H -- then per epoch bwd 5H read + 4H written, wgrad 4H + H read, all f32
+        fw = 6 * H if I <= 6 else 8 * H
+        impl_it = units * 4 * L * (fw + (epochs - (1 if reused_fwd else 0)) * fw + epochs * (9 * H + 5 * H)) \
             + units * (ALG_ROLLOUT_B + ALG_GAE_B + epochs * ALG_UPDATE_B)
         it_mult, it_peak = mult, pipe_peak
     else:
@@ -770,6 +787,8 @@ def main():
         "rollout_env_steps_per_s": N * T * world / (roll_ms * 1e-3),
         "ppo_iterations_per_s": args.steps / dt, "optimizer_steps_per_s": args.steps * opt_steps / dt,
         "rollout_ms": roll_ms, "kernel_ms": {k: v["avg_ms"] for k, v in timers.items()},
+        "kernel_ms_note": "lstm_bwd (the roofline's kernel): HIP events around its launches INSIDE the timed region; the other kernels "
+                          "and rollout_ms: the same brackets over 3 extra iterations after it (an event pair costs ~5 us of device idle)",
         "roofline": roofline,
     }
     # (the strong-scaling shape is NOT timed in these processes: launch() runs it in a second set of fresh ranks; under

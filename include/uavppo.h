@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 8   /* 8: uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 8   /* 8: uav_lstm_wgrad db_hh; uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -307,7 +307,8 @@ int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* lay
                        const float* w_head, int n_heads, int N, int T, int H, uav_stream stream);
 /* Time-batched weight gradients from dgates in ONE fused pass (csrc/wgrad.hip):
  * dw_ih [4H][I] = dG^T X, dw_hh [4H][H] = dG^T Hprev with Hprev[n][t] = y[n][t-1]*keep[n][t]
- * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh) and -- when dheads != NULL (top layer) --
+ * (h0[n]*keep[n][0] at t = 0), db [4H] (= db_ih = db_hh; db_hh, when non-NULL, receives the same values: nn.LSTM's second
+ * bias gradient, so the caller needs no copy launch) and -- when dheads != NULL (top layer) --
  * dw_head [n_heads][H] = dheads^T y.  dx [N][T][I] = dG W_ih when non-NULL.  y [N][T][H] is this
  * layer's forward output.  I > 6 (stacked layers) takes generic split-K GEMMs and needs `stash`.
  * Range note: the default kernels of uav_lstm_fwd / _bwd / _wgrad / uav_rollout evaluate their matrix products as fp16
@@ -317,7 +318,7 @@ int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* lay
  * generic exact-f32 step path (the fp16-split step kernels have no wide-range twin). */
 int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* y,
                    const float* stash, const float* dgates, const float* w_ih, const float* dheads,
-                   int n_heads, int N, int T, int I, int H, float* dw_ih, float* dw_hh, float* db,
+                   int n_heads, int N, int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* db_hh,
                    float* dw_head, float* dx, uav_stream stream);
 
 /* ---- E1-E5: vectorised plume environment (environment.py:19-169).  State lives in one

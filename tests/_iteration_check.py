@@ -105,9 +105,9 @@ def update_vs_oracle(tr, label, grad_rel_tol=2e-5, lr_steps_tol=0.1, far_frac=3e
             rel_at = _rel_l2(g_hip, g_at)
             # tensor by tensor: largest deviation over the tensor's largest entry -- or, for a tensor whose gradient cancels
             # to rounding noise (the critic bias at epoch 0 is sum(V - ret) = -sum(adv_n) = 0 by the normalisation itself),
-            # over 1e-3 of the whole gradient's largest entry
+            # over 1e-2 of the whole gradient's largest entry
             gmax = max(float(g.abs().max()) for g in g_at.values())
-            per_tensor = {n: float((g_hip[n] - g_at[n]).abs().max()) / max(float(g_at[n].abs().max()), 1e-3 * gmax) for n in g_at}
+            per_tensor = {n: float((g_hip[n] - g_at[n]).abs().max()) / max(float(g_at[n].abs().max()), 1e-2 * gmax) for n in g_at}
             gn_at = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g_at.values())))
             # (b) same gradients: the oracle's clip + Adam on the trainer's gradient, from parameters that followed the same rule
             p_same_before = max(float((p_same[n] - p_hip[n]).abs().max()) for n in p_same)

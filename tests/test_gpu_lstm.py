@@ -318,9 +318,10 @@ def test_split_fp16_weight_gradients_over_a_wide_dynamic_range(ops, H):
 
 
 def test_gate_activation_error_bounds(ops):
-    """csrc/common.h: fast_sigmoid / fast_tanh are v_exp_f32 + v_rcp_f32 (no IEEE division sequence).  tanh is evaluated as
-    1 - 2/(exp(2x)+1): ABSOLUTE error <= 2.5e-7 everywhere (what the recurrence needs: c and h are sums of O(1) terms), but
-    the form cancels for small |x|, so the RELATIVE error grows like 2.5e-7/|x| below |x| = 1 -- stated in DESIGN.md 3 and pinned here.
+    """csrc/common.h: fast_sigmoid / fast_tanh are v_exp_f32 + v_rcp_f32 (no IEEE division sequence).  tanh is 1 - 2/(exp(2x)+1)
+    for |x| >= 1/4 (absolute error <= 2.5e-7) and, since round 5, the odd Taylor polynomial to x^9 below (the exp form cancels
+    there: its relative error was 2.5e-7 / |x|, 1e-3 at |x| = 1e-4): RELATIVE error <= 1.5e-6 over the whole range, down to
+    |x| = 1e-6, stated in DESIGN.md 3 and pinned here.
     The activations are read straight from the BPTT stash (gates after activation) of a one-step layer with W = 0."""
     H, N = 128, 64
     xs = torch.cat([torch.linspace(-12, 12, 4096), torch.logspace(-6, 0, 2048), -torch.logspace(-6, 0, 2048)]).double()
@@ -330,7 +331,7 @@ def test_gate_activation_error_bounds(ops):
     w_ih[:, 0] = 1.0                                                      # gate pre-activation = x[0] (+ bias 0)
     w_hh = torch.zeros(4 * H, H, device=DEV)
     b = torch.zeros(4 * H, device=DEV)
-    worst_abs_t = worst_abs_s = worst_rel_t = 0.0
+    worst_abs_t = worst_abs_s = worst_rel_t = worst_relx_t = 0.0
     for r in range(rows):
         # every unit of env n sees the same scalar; put value xs[r, u] on env u (N = H envs)
         x = torch.zeros(H, 1, 6, device=DEV)
@@ -343,10 +344,12 @@ def test_gate_activation_error_bounds(ops):
         worst_abs_s = max(worst_abs_s, (sig - torch.sigmoid(pre)).abs().max().item())
         et = (tnh - torch.tanh(pre)).abs()
         worst_abs_t = max(worst_abs_t, et.max().item())
-        worst_rel_t = max(worst_rel_t, (et * pre.abs().clamp_max(1.0) / torch.tanh(pre).abs().clamp_min(1e-300)).max().item())
-    print("sigmoid abs", worst_abs_s, "tanh abs", worst_abs_t, "tanh rel*|x|", worst_rel_t)
+        nz = pre.abs() > 0
+        worst_rel_t = max(worst_rel_t, (et[nz] / torch.tanh(pre[nz]).abs()).max().item())
+        worst_relx_t = max(worst_relx_t, (et * pre.abs().clamp_max(1.0) / torch.tanh(pre).abs().clamp_min(1e-300)).max().item())
+    print("sigmoid abs", worst_abs_s, "tanh abs", worst_abs_t, "tanh rel", worst_rel_t, "tanh rel*min(|x|,1)", worst_relx_t)
     assert worst_abs_s < 1.5e-7 and worst_abs_t < 2.5e-7
-    assert worst_rel_t < 2.5e-7            # relative error of tanh <= 2.5e-7 / min(|x|, 1)
+    assert worst_rel_t < 1.5e-6            # relative error of tanh over [1e-6, 12]: largest just above the 1/4 switch (2.5e-7 / 0.245); the exp form alone: 1e-3 at 1e-4
 
 
 @pytest.mark.parametrize("N,T,I", [(64, 6, 8), (100, 5, 256), (37, 3, 40)])

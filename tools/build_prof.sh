@@ -3,8 +3,8 @@
 set -e
 cd "$(dirname "$0")/../uav-wrf-les-ppo-lstm_amd/csrc"
 mkdir -p build_prof
-for f in adam ctx env gae gemm gemm_h3 loss lstm lstm_cluster lstm_generic mlp mlp_fused rollout wgrad; do
-  fl=""; case $f in lstm|wgrad) fl="-ffp-contract=fast";; lstm_cluster) fl="-mllvm -amdgpu-mfma-vgpr-form=1 -DUAV_C8_PROFILE";; esac
+for f in adam comm ctx env gae gemm gemm_h3 loss lstm lstm_generic mlp mlp_fused rollout wgrad; do
+  fl=""; case $f in lstm|wgrad) fl="-ffp-contract=fast";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $fl -DUAV_X6_PROFILE -Wno-unused-function -c $f.hip -o build_prof/$f.o &
 done
 wait

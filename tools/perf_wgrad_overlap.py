@@ -23,7 +23,7 @@ def main():
 
     def run(h, d, stream):
         check(lib().uav_lstm_wgrad(h, ops._p(d["x"]), None, ops._p(d["h0"]), ops._p(d["y"]), ops._p(d["st"]), ops._p(d["dg"]), ops._p(d["wi"]),
-                                   None, 0, N, T, d["I"], H, ops._p(d["dwi"]), ops._p(d["dwh"]), ops._p(d["db"]), None, None,
+                                   None, 0, N, T, d["I"], H, ops._p(d["dwi"]), ops._p(d["dwh"]), ops._p(d["db"]), None, None, None,
                                    C.c_void_p(stream.cuda_stream)), "uav_lstm_wgrad")
 
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()

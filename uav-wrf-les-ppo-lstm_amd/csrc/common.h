@@ -80,8 +80,22 @@ __device__ __forceinline__ void lds_barrier() {
 // not the MFMAs, paced the persistent kernels (tools/mfma_probe.hip).
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = 1 - 2/(exp(2x)+1): exact limits at +-inf, abs error ~1e-7
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+    // |x| >= 1/4: tanh(x) = 1 - 2 / (exp(2x) + 1): exact limits at +-inf, absolute error <= 1.9e-7, i.e. relative <= 8e-7 there.
+    // |x| <  1/4: that form cancels (its RELATIVE error is 1.9e-7 / |x|: 1e-3 at |x| = 1e-4), so the odd Taylor polynomial
+    // x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315 + 62 x^8/2835) takes over: truncation 8.9e-3 x^10 <= 8.5e-9 relative, rounding
+    // ~2e-7 relative.  Both are evaluated and one selected (no branch): +8 VALU per call.  UAV_TANH_LEGACY: the exp form alone
+    // (A/B builds only: tools/ab_tanh.sh).
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+#ifdef UAV_TANH_LEGACY
+    return big;
+#else
+    const float x2 = x * x;
+    float p = __builtin_fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f);
+    p = __builtin_fmaf(p, x2, 2.0f / 15.0f);
+    p = __builtin_fmaf(p, x2, -1.0f / 3.0f);
+    p = __builtin_fmaf(p, x2, 1.0f);
+    return __builtin_fabsf(x) < 0.25f ? x * p : big;
+#endif
 }
 
 // ---- split-bf16 ("x6") arithmetic: an f32 value as three bf16 pieces a = p0 + p1 + p2 (8 significand bits each, so

@@ -58,7 +58,7 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
                       const float* w_head, int n_heads, int N, int T, hipStream_t st);
 int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
                      const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
-                     float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st);
+                     float* dw_ih, float* dw_hh, float* db, float* db_hh, float* dw_head, hipStream_t st);
 
 constexpr int MT = 16;      // env rows per workgroup (MFMA M)
 // UAV_LSTM_F32_MFMA=1 selects the exact v_mfma_f32_16x16x4_f32 kernels (the A/B reference of the split ones)
@@ -1597,7 +1597,7 @@ int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const floa
 
 int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float* h0, const float* y,
                    const float* stash, const float* dgates, const float* w_ih, const float* dheads, int n_heads, int N,
-                   int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* dw_head, float* dx,
+                   int T, int I, int H, float* dw_ih, float* dw_hh, float* db, float* db_hh, float* dw_head, float* dx,
                    uav_stream stream) {
     UAV_REQUIRE(ctx && x && h0 && y && dgates && w_ih && dw_ih && dw_hh && db, "uav_lstm_wgrad: NULL argument");
     uav_enter(ctx);
@@ -1608,7 +1608,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
     int rc;
     if (I <= 6 && (H == 64 || H == 128)) {
         if ((rc = lstm_wgrad_fused(ctx, dgates, y, keep, h0, x, I, dheads ? y : nullptr, dheads, n_heads, N, T, H, dw_ih,
-                                   dw_hh, db, dw_head, st))) return rc;
+                                   dw_hh, db, db_hh, dw_head, st))) return rc;
     } else {
         // generic path: column sums use the tail of the workspace, the split-K slabs everything in front of it
         UAV_REQUIRE(stash, "uav_lstm_wgrad: stash is required when I > 6");
@@ -1628,6 +1628,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         if (narrow) rc = colsum_xw(&sub, dgates, NT, 4 * H, x, I, db, dw_ih, red, amax, st);
         else rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st);
         if (rc) return rc;
+        if (db_hh) UAV_CHECK_HIP(hipMemcpyAsync(db_hh, db, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
         auto product = [&](int64_t M, int64_t Nn, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
                            int64_t sb_k, int64_t sb_n, float* C, int64_t ldc) {
             if (h3 && gemm_h3_ok(M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n))

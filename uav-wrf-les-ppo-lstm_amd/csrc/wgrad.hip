@@ -748,7 +748,8 @@ __global__ __launch_bounds__(H * 4) void lstm_wgrad_h3_kernel(
 template <int H>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int nb, int I, int NH,
                                                            float* __restrict__ dw_ih, float* __restrict__ dw_hh,
-                                                           float* __restrict__ db, float* __restrict__ dw_head) {
+                                                           float* __restrict__ db, float* __restrict__ db_hh,
+                                                           float* __restrict__ dw_head) {
     using G = WG<H>;
     const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (o >= G::SLAB) return;
@@ -764,7 +765,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int m = (int)(o / G::NC), c = (int)(o % G::NC);
         if (c < H) dw_hh[(size_t)m * H + c] = s;
         else if (c - H < I) dw_ih[(size_t)m * I + (c - H)] = s;
-        else if (c - H == 6) db[m] = s;
+        else if (c - H == 6) {
+            db[m] = s;
+            if (db_hh) db_hh[m] = s;          // nn.LSTM's two bias vectors always enter as a sum: the same gradient
+        }
     } else if (dw_head) {
         const int a = (int)((o - gsz) / H), uu = (int)((o - gsz) % H);
         if (a < NH) dw_head[(size_t)a * H + uu] = s;
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <int H>
 static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
                         const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T,
-                        float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st) {
+                        float* dw_ih, float* dw_hh, float* db, float* db_hh, float* dw_head, hipStream_t st) {
     using G = WG<H>;
     const int64_t NTr = (int64_t)N * T;
     int nb = ctx->num_cu;
@@ -815,7 +819,7 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
                 hipLaunchKernelGGL((lstm_wgrad_x6_kernel<H, false>), dim3(nbx), dim3(H * 4), GX::LDS, st, dgates, y_prev_src,
                                    keep, h0, x, I, dheads, NH, N, T, (int)rpx, slabs);
             hipLaunchKernelGGL((wgrad_reduce_kernel<H>), dim3((unsigned)((G::SLAB + 255) / 256)), dim3(256), 0, st, slabs,
-                               nbx, I, NH, dw_ih, dw_hh, db, dw_head);
+                               nbx, I, NH, dw_ih, dw_hh, db, db_hh, dw_head);
             UAV_LAUNCH_CHECK();
             return 0;
         }
@@ -824,7 +828,7 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
     hipLaunchKernelGGL((lstm_wgrad_kernel<H>), dim3(nb), dim3(H * 4), G::LDS, st, dgates, y_prev_src, keep, h0, x, I, ytop,
                        dheads, NH, N, T, rpb, slabs);
     hipLaunchKernelGGL((wgrad_reduce_kernel<H>), dim3((unsigned)((G::SLAB + 255) / 256)), dim3(256), 0, st, slabs, nb, I,
-                       NH, dw_ih, dw_hh, db, dw_head);
+                       NH, dw_ih, dw_hh, db, db_hh, dw_head);
     UAV_LAUNCH_CHECK();
     return 0;
 }
@@ -832,10 +836,10 @@ static int launch_wgrad(uav_ctx* ctx, const float* dgates, const float* y_prev_s
 // fast path entry used by uav_lstm_wgrad (lstm.hip) when I <= 6 and H in {64,128}
 int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
                      const float* x, int I, const float* ytop, const float* dheads, int NH, int N, int T, int H,
-                     float* dw_ih, float* dw_hh, float* db, float* dw_head, hipStream_t st) {
+                     float* dw_ih, float* dw_hh, float* db, float* db_hh, float* dw_head, hipStream_t st) {
     switch (H) {
-        case 64: return launch_wgrad<64>(ctx, dgates, y_prev_src, keep, h0, x, I, ytop, dheads, NH, N, T, dw_ih, dw_hh, db, dw_head, st);
-        case 128: return launch_wgrad<128>(ctx, dgates, y_prev_src, keep, h0, x, I, ytop, dheads, NH, N, T, dw_ih, dw_hh, db, dw_head, st);
+        case 64: return launch_wgrad<64>(ctx, dgates, y_prev_src, keep, h0, x, I, ytop, dheads, NH, N, T, dw_ih, dw_hh, db, db_hh, dw_head, st);
+        case 128: return launch_wgrad<128>(ctx, dgates, y_prev_src, keep, h0, x, I, ytop, dheads, NH, N, T, dw_ih, dw_hh, db, db_hh, dw_head, st);
     }
     uav_set_error("lstm_wgrad_fused: H=%d unsupported", H);
     return 2;

@@ -155,8 +155,7 @@ class PredictorTrainer:
         for l in (2, 1, 0):
             r = ops.lstm_bwd(xs[l], None, stashes[l], p[f"weight_ih_l{l}"], p[f"weight_hh_l{l}"], ys[l], z0, dy=dy,
                              need_dx=(l > 0), dw_ih=g[f"lstm.weight_ih_l{l}"], dw_hh=g[f"lstm.weight_hh_l{l}"],
-                             db=g[f"lstm.bias_ih_l{l}"], want_dstate=False)
-            g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
+                             db=g[f"lstm.bias_ih_l{l}"], want_dstate=False, db_hh=g[f"lstm.bias_hh_l{l}"])
             if l > 0:
                 dy = r["dx"] * masks[f"l{l - 1}"] if masks is not None else r["dx"]
                 dy = dy.contiguous()
@@ -279,8 +278,8 @@ class PeakStopTrainer:
         dy = torch.zeros(B, T, H, dtype=F32, device=x.device)
         dy[:, T - 1] = ops.gemm(dout, m.heads_w)
         ops.lstm_bwd(x, None, st, p["weight_ih_l0"], p["weight_hh_l0"], yl, z0, dy=dy, need_dx=False,
-                     dw_ih=g["lstm.weight_ih_l0"], dw_hh=g["lstm.weight_hh_l0"], db=g["lstm.bias_ih_l0"], want_dstate=False)
-        g["lstm.bias_hh_l0"].copy_(g["lstm.bias_ih_l0"])
+                     dw_ih=g["lstm.weight_ih_l0"], dw_hh=g["lstm.weight_hh_l0"], db=g["lstm.bias_ih_l0"], want_dstate=False,
+                     db_hh=g["lstm.bias_hh_l0"])
         self.step_count += 1
         ops.clip_adamw(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, weight_decay=self.wd,
                        max_norm=max_norm, gnorm_out=self.gnorm)

@@ -147,9 +147,14 @@ def _init_distributed():
             dist.init_process_group("nccl", rank=RANK, world_size=WORLD_SIZE, device_id=dev)
         else:
             dist.init_process_group(DIST_BACKEND, rank=RANK, world_size=WORLD_SIZE)
-    if dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size(), dev
-    return 0, 1, dev
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    if os.environ.get("UAVPPO_COLLECTIVES") == "abi" and world > 1:
+        # the iteration's exchanges on the C ABI's own RCCL communicator (include/uavppo.h K9) instead of torch.distributed,
+        # which then only carries the communicator's 128-byte id, the CSV gather and the final barrier
+        from uavppo import dist_utils
+        if not dist_utils.abi_collectives():
+            dist_utils.use_abi_collectives(rank, world, dev)
+    return rank, world, dev
 
 
 def train_ppo_vectorised(iterations=None, csv_path="training_results2_0.csv", model_path="model/ppo_successful_models.pth",

@@ -76,7 +76,7 @@ SIGNATURES = {
     "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd_caps": (I32, [P, I32, I32]),
     "uav_lstm_bwd_stack": (I32, [P, I32, P, P, P, P, I32, I32, I32, I32, P]),
-    "uav_lstm_wgrad": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P, P]),
+    "uav_lstm_wgrad": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),
     "uav_env_reset": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P]),
     "uav_env_step": (I32, [P, P, I32, C.POINTER(EnvCfg), P, P, P, P, P, P, P, P, P, P]),

@@ -620,7 +620,7 @@ def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):
                                _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
                                _p(dheads, F32, (N, T, nh), "dheads"), nh, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
-                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nh, H), "dw_head"), _p(None), _stream()),
+                               _p(db, F32, (4 * H,), "db"), None, _p(dw_head, F32, (nh, H), "dw_head"), _p(None), _stream()),
           "uav_lstm_wgrad")
     return {"dw_ih": dw_ih, "dw_hh": dw_hh, "db": db, "dw_head": dw_head}
 
@@ -655,9 +655,11 @@ def lstm_bwd_stack(layers, keep, dy=None, dheads=None, w_head=None):
 
 
 def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=None, dhn=None, dcn=None, need_dx=False,
-             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None, bwd_done=False):
+             dgates=None, dw_ih=None, dw_hh=None, db=None, dw_head=None, want_dstate=True, wgrad_dheads=None, bwd_done=False,
+             db_hh=None):
     """BPTT sequence kernel + fused weight-gradient pass of one layer.  y, h0: the layer's forward
     output and initial hidden state (h_prev of the weight gradient is y shifted by one step).
+    db_hh: a second [4H] tensor that receives the bias gradient too (nn.LSTM's bias_hh; saves the caller a copy launch).
     bwd_done: dgates (and the dx a layer above needs) were already produced by lstm_bwd_stack: only the weight gradients."""
     N, T, I = x.shape
     H = w_hh.shape[1]
@@ -694,7 +696,7 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
                                _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
                                _p(wgrad_dheads, F32, (N, T, nhw), "dheads"), nhw, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
-                               _p(db, F32, (4 * H,), "db"), _p(dw_head, F32, (nhw, H), "dw_head"),
+                               _p(db, F32, (4 * H,), "db"), _p(db_hh, F32, (4 * H,), "db_hh"), _p(dw_head, F32, (nhw, H), "dw_head"),
                                None if dx_in_bwd else _p(dx), _stream()),
           "uav_lstm_wgrad")
     if _t is not None:

@@ -323,8 +323,8 @@ class LSTMActorCritic(_FlatPolicy):
                 ops.lstm_bwd(x, keep, stash, v[f"lstm.weight_ih_l{l}"], v[f"lstm.weight_hh_l{l}"], y, h0,
                              wgrad_dheads=dheads.view(N, T, -1) if top else None, dgates=work[f"dgates{l}"],
                              dw_ih=g[f"lstm.weight_ih_l{l}"], dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"],
-                             dw_head=g["head.weight"] if top else None, want_dstate=False, bwd_done=True)
-                g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
+                             dw_head=g["head.weight"] if top else None, want_dstate=False, bwd_done=True,
+                             db_hh=g[f"lstm.bias_hh_l{l}"])
             self._saved = None
             return self.grad
         if not fused_heads:
@@ -342,8 +342,7 @@ class LSTMActorCritic(_FlatPolicy):
                              wgrad_dheads=dheads.view(N, T, -1) if top else None,
                              need_dx=(l > 0), dgates=work.get("dgates"), dw_ih=g[f"lstm.weight_ih_l{l}"],
                              dw_hh=g[f"lstm.weight_hh_l{l}"], db=g[f"lstm.bias_ih_l{l}"],
-                             dw_head=g["head.weight"] if top else None, want_dstate=False)
-            g[f"lstm.bias_hh_l{l}"].copy_(g[f"lstm.bias_ih_l{l}"])
+                             dw_head=g["head.weight"] if top else None, want_dstate=False, db_hh=g[f"lstm.bias_hh_l{l}"])
             dy = r["dx"]
         self._saved = None
         return self.grad

@@ -180,10 +180,12 @@ class VecPPOTrainer:
         self.side_stream_curriculum = True     # False: pack + copy on the main stream inside update_curriculum (A/B, tools/ab_loop.py)
         if policy == "lstm":
             L, H = layers, hidden
-            self.h = torch.zeros(L, N, H, **f32)
-            self.c = torch.zeros(L, N, H, **f32)
-            self.h0 = torch.zeros(L, N, H, **f32)     # state at the start of the current rollout (for BPTT)
-            self.c0 = torch.zeros(L, N, H, **f32)
+            # recurrent state (h | c) and its snapshot at the start of the current rollout (what BPTT starts from): each pair is
+            # ONE allocation, so the snapshot before a rollout is one copy launch instead of two
+            self._state = torch.zeros(2, L, N, H, **f32)
+            self._state0 = torch.zeros(2, L, N, H, **f32)
+            self.h, self.c = self._state[0], self._state[1]
+            self.h0, self.c0 = self._state0[0], self._state0[1]
             nb = N // self.num_minibatches
             self.work = {"dgates": torch.empty(nb, T, 4 * H, **f32), "heads": torch.empty(nb, T, 6, **f32)}   # heads: logits | value, written by the sequence kernels
             for l in range(L):
@@ -402,12 +404,10 @@ class VecPPOTrainer:
             self._buffers_own = True
         wide = self._guarded() and self.arith != "fp16x3"      # uav_rollout exists in the fp16-split form only
         if self.kind == "lstm" and (self.policy.num_layers != 1 or self.policy.hidden not in (64, 128) or self.trend_k or wide):
-            self.h0.copy_(self.h)
-            self.c0.copy_(self.c)
+            self._state0.copy_(self._state)
             self._collect_stepwise_lstm(forced_act, noise)
         elif self.kind == "lstm":
-            self.h0.copy_(self.h)
-            self.c0.copy_(self.c)
+            self._state0.copy_(self._state)
             reuse = self.reuse_rollout_forward and self.num_minibatches == 1
             ops.rollout_lstm(self.env_state, self.N, self.env_cfg(), self.policy.flat, self.policy.hidden, self.T,
                              self.iteration, self.cur_obs, self.h[0], self.c[0], self.buf, last_val=self.last_val,
