@@ -45,7 +45,7 @@ def _oracle_step(p, x, k, h0, c0, act, logp, adv, ret, val, sl, nbT):
     total, pl, vl, ent = po.ppo_losses(probs, value, act[sl].reshape(-1), logp[sl].reshape(-1), adv[sl].reshape(-1),
                                        ret[sl].reshape(-1), val[sl].reshape(-1))
     total.backward()
-    return {n: leaf[n].grad.detach() for n in p}, [float(pl), float(vl), float(ent)]
+    return {n: leaf[n].grad.detach() for n in p}, [float(pl.detach()), float(vl.detach()), float(ent.detach())]
 
 
 def _rel_l2(got, want):

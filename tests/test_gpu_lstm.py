@@ -344,8 +344,7 @@ def test_gate_activation_error_bounds(ops):
         worst_abs_s = max(worst_abs_s, (sig - torch.sigmoid(pre)).abs().max().item())
         et = (tnh - torch.tanh(pre)).abs()
         worst_abs_t = max(worst_abs_t, et.max().item())
-        nz = pre.abs() > 0
-        worst_rel_t = max(worst_rel_t, (et[nz] / torch.tanh(pre[nz]).abs()).max().item())
+        worst_rel_t = max(worst_rel_t, (et / torch.tanh(pre).abs().clamp_min(1e-300)).max().item())     # (x = 0: 0 / tiny = 0)
         worst_relx_t = max(worst_relx_t, (et * pre.abs().clamp_max(1.0) / torch.tanh(pre).abs().clamp_min(1e-300)).max().item())
     print("sigmoid abs", worst_abs_s, "tanh abs", worst_abs_t, "tanh rel", worst_rel_t, "tanh rel*min(|x|,1)", worst_relx_t)
     assert worst_abs_s < 1.5e-7 and worst_abs_t < 2.5e-7

@@ -2,7 +2,7 @@
 # The round's evidence in one call on the GPU box (from the repo root): bash tools/final_round.sh <tag>
 # bench lines of every config, the 8-rank gloo rehearsal, kernel stats + HBM byte counters + SQ counters at the CURRENT kernel sources.
 set -e
-TAG=${1:-r04_z}
+TAG=${1:-r05_z}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 if [ "$2" != "skip-bench" ]; then
