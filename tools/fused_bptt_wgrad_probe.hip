@@ -1,0 +1,471 @@
+// fused_bptt_wgrad_probe.hip -- VERDICT r04 item 2(a): "fuse the weight gradients into the BPTT kernel so dgates never reaches HBM ...
+// price a 2-CU pair per 32-env tile".  This is that schedule as a stand-alone probe at h = 128 (budget and design:
+// profiles/r05_c3_fused_wgrad_budget.md): it does the REAL work of one epoch's BPTT + weight gradients -- stash rows from HBM by
+// LDS-DMA, the gate pointwise, the split-fp16 dh product, the inter-CU hand-off of the partial dh tiles, dW accumulated in
+// registers over all T steps -- on synthetic data, checks itself against a plain f64 reference on the host, and prints
+// microseconds per time step to set against today's lstm_bwd_h3k_kernel + lstm_wgrad_h3_kernel (0.52 + 0.335 ms per 128 steps at
+// 4096 envs = 6.7 us per step).  Simplifications, all cost-neutral or pessimistic: no episode masks, no dy from the heads (dh enters
+// at the last step only), the weight-gradient operands under ONE fixed power-of-two scale instead of the per-row running scale
+// (same instruction count: a second split of every gate gradient), h_prev of step 0 taken as zero.
+//
+// Pair p = workgroups (p, half 0 / 1) -- blocks b and b + 8, one XCD -- 32 envs; half h owns units [64 h, 64 h + 64) = 256 gate
+// rows.  Wave w does the pointwise of tile (m = w & 3, c = w >> 2): units 16 m .. + 15 of its half x envs 16 c .. + 15, lane
+// (j, kq) = env j, units 4 kq .. + 3.  dh product: wave w multiplies the dG planes of BOTH env tiles (K = the 256 own rows) against
+// W_hh^T[own rows][unit tile w]: unit tiles 0-3 are the own half's (result stays here), 4-7 the partner's (result crosses).
+// dW: wave w accumulates local gate rows 32 w .. 32 w + 31 x [h_prev(128) | x(6) | 1 | 0 ...](144) over all steps.
+//
+//   hipcc -O3 --offload-arch=gfx950 tools/fused_bptt_wgrad_probe.hip -o tools/bin/fused_probe && tools/bin/fused_probe [pairs=128] [T=128]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int H = 128, HU = 64, E = 32, R = 256, XC = 8, NCOL = 144;
+constexpr int RSA = R + 8;          // dG planes: [env 32][local row 256 + pad] halves
+constexpr int RSH = NCOL + 8;       // [h_prev | x | 1] planes: [env 32][144 + pad] halves
+constexpr int PLA = E * RSA, PLH = E * RSH;
+constexpr float LO = 1.0f / 2048.0f;
+constexpr float HSCALE = 1024.0f;   // weight-gradient operand scales (stand-ins for the product kernel's running scales)
+
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+__device__ __forceinline__ void split2h(float a, _Float16& p0, _Float16& p1) {      // a = p0 + 2^-11 p1
+    p0 = (_Float16)a;
+    p1 = (_Float16)((a - (float)p0) * 2048.0f);
+}
+__device__ __forceinline__ void split2u(float a, _Float16& p0, _Float16& p1) {      // a = p0 + p1 (unscaled residual)
+    p0 = (_Float16)a;
+    p1 = (_Float16)(a - (float)p0);
+}
+__device__ __forceinline__ unsigned short hb(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ f16x8 tr_frag(const unsigned short* plane, int rs, int lane) {     // csrc/mlp_fused.hip: tr_frag
+    typedef short v4s __attribute__((__vector_size__(4 * sizeof(short))));
+    typedef __attribute__((address_space(3))) v4s lds_v4s;
+    const int li = lane & 15, kq = lane >> 4;
+    const unsigned short* a = plane + (8 * kq + (li >> 2)) * rs + 4 * (li & 3);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)a);
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(a + 4 * rs));
+    typedef short v8s __attribute__((__vector_size__(8 * sizeof(short))));
+    const v8s r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, r);
+}
+
+struct Args {
+    const float* stash;   // [N][T][6H]  gates i f g o | c_prev | (unused)
+    const float* y;       // [N][T][H]   layer output (h_prev of step t = y[t - 1])
+    const float* x;       // [N][T][8]   obs 6 | 1 | 0
+    const float* w_hh;    // [4H][H]
+    const float* dhn;     // [N][H]
+    const float* dcn;     // [N][H]
+    float* dh0;           // [N][H]
+    float* dc0;           // [N][H]
+    float* slab;          // [2 pairs][256][144]: this workgroup's dW partial
+    float* xbuf;          // [pairs][2 parity][2 half][8 tiles][64 lanes][4]
+    unsigned* flags;      // [pairs][2]
+    unsigned* err;
+    int N, T;
+    float gscale;         // fixed power-of-two scale of dG for the weight-gradient operand
+};
+
+__global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short* pA = reinterpret_cast<unsigned short*>(smem_raw);      // [2 pieces][32][RSA]  per-env scale (dh product)
+    unsigned short* pB = pA + 2 * PLA;                                     // [2 pieces][32][RSA]  fixed scale (dW product)
+    unsigned short* pH = pB + 2 * PLA;                                     // [2 pieces][32][RSH]
+    float* ring = reinterpret_cast<float*>(pH + 2 * PLH);                  // [8 waves][5][256]
+    f32x4* hop = reinterpret_cast<f32x4*>(ring + 8 * 5 * 256);             // [4][64]: own tile (m, c = 1) from wave m to wave m + 4
+    float* unsc = reinterpret_cast<float*>(hop + 4 * 64);                  // [32] per-env unscale of the dh product
+
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, kq = lane >> 4;
+    const int pair = (blockIdx.x / 16) * 8 + (blockIdx.x % 8), half = (blockIdx.x / 8) & 1;     // blocks b, b + 8: one XCD
+    const int m = w & 3, c = w >> 2;
+    const int T = a.T;
+    const int n = pair * E + 16 * c + j;                  // this lane's env
+    const int ul = 16 * m + 4 * kq;                       // first of its four local units
+    const int ug = HU * half + ul;
+
+    // ---- weights of the dh product: unit tile w (0-3 own, 4-7 partner's), K = the 256 own rows, two fp16 pieces: 64 VGPRs
+    const int ut_g = (w < 4) ? HU * half + 16 * w : HU * (1 - half) + 16 * (w - 4);
+    f16x8 wa[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const int lr = 32 * s + 8 * kq + e8, q = lr >> 6, u = lr & 63;
+            _Float16 p0, p1;
+            split2h(a.w_hh[(size_t)(q * H + HU * half + u) * H + ut_g + j], p0, p1);
+            wa[s][0][e8] = p0; wa[s][1][e8] = p1;
+        }
+    }
+    // ---- dW accumulators: local rows 32 w .. + 31 (row tiles 2 w, 2 w + 1) x 9 column tiles: 72 VGPRs
+    f32x4 dw[2][9];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 9; ++ct) dw[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float dh_rec[4], dc_next[4];
+    {
+        const float4 d4 = *reinterpret_cast<const float4*>(a.dhn + (size_t)n * H + ug);
+        const float4 c4 = *reinterpret_cast<const float4*>(a.dcn + (size_t)n * H + ug);
+        dh_rec[0] = d4.x; dh_rec[1] = d4.y; dh_rec[2] = d4.z; dh_rec[3] = d4.w;
+        dc_next[0] = c4.x; dc_next[1] = c4.y; dc_next[2] = c4.z; dc_next[3] = c4.w;
+    }
+    // ---- stash by LDS-DMA: per wave and step 5 x [16 envs][16 units] f32, lane l -> env l / 4, units 4 (l % 4) ..
+    typedef __attribute__((address_space(3))) float lds_f;
+    const int e_d = lane >> 2, g4 = lane & 3;
+    const size_t drow = (size_t)(pair * E + 16 * c + e_d) * T;
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((lds_f*)(ring + w * 5 * 256)));
+    auto issue = [&](int t) {
+        const float* src = a.stash + (drow + t) * (6 * H) + HU * half + 16 * m + 4 * g4;
+        unsigned m0save;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+            "s_add_u32 m0, m0, 1024\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(m0save)
+            : "v"(src), "v"(src + H), "v"(src + 2 * H), "v"(src + 3 * H), "v"(src + 4 * H), "s"(ring_base)
+            : "memory", "scc");
+    };
+    // ---- [h_prev | x | 1] of a step: 32 envs x 34 float4 (32 of y[t - 1], 2 of x[t]); thread i takes items i, i + 512, i + 1024
+    float4 hx[3];
+    auto hx_load = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int it = threadIdx.x + 512 * k;
+            hx[k] = float4{0.f, 0.f, 0.f, 0.f};
+            if (it < E * 34) {
+                const int e = it / 34, f4 = it % 34;
+                const size_t row = (size_t)(pair * E + e) * T + t;
+                if (f4 < 32) { if (t > 0) hx[k] = *reinterpret_cast<const float4*>(a.y + (row - 1) * H + 4 * f4); }
+                else hx[k] = *reinterpret_cast<const float4*>(a.x + row * XC + 4 * (f4 - 32));
+            }
+        }
+    };
+    auto hx_commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int it = threadIdx.x + 512 * k;
+            if (it < E * 34) {
+                const int e = it / 34, f4 = it % 34;
+                const float v[4] = {hx[k].x, hx[k].y, hx[k].z, hx[k].w};
+                unsigned short b[2][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 p0, p1;
+                    split2u(v[r] * HSCALE, p0, p1);
+                    b[0][r] = hb(p0); b[1][r] = hb(p1);
+                }
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+                    *reinterpret_cast<uint2*>(pH + pc * PLH + e * RSH + 4 * f4) =
+                        make_uint2(b[pc][0] | (unsigned)b[pc][1] << 16, b[pc][2] | (unsigned)b[pc][3] << 16);
+            }
+        }
+    };
+    // zero the pad columns 136..143 of the h planes once (column tile 8 reads them)
+    for (int i = threadIdx.x; i < 2 * E * 8; i += 512) pH[(i / (E * 8)) * PLH + ((i / 8) % E) * RSH + 136 + (i % 8)] = 0;
+
+    float* my_x = a.xbuf + (size_t)pair * 2 * 2 * 8 * 64 * 4;                // [parity][half][tile 8][lane][4]
+    unsigned* fl = a.flags + pair * 2;
+    bool dead = false;
+
+    issue(T - 1);
+    hx_load(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+        const int par = t & 1;
+        // ---- the partner's contribution to dh of this tile, produced by its step t + 1
+        f32x4 theirs = {0.f, 0.f, 0.f, 0.f};
+        if (t < T - 1) {
+            if (!dead) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(fl + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)(t + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) { if (lane == 0) atomicAdd(a.err, 1u); dead = true; break; }
+                }
+            }
+            const float* src = my_x + ((size_t)(((t + 1) & 1) * 2 + (1 - half)) * 8 + (4 * c + m)) * 64 * 4 + lane * 4;
+            const unsigned long long* s8 = reinterpret_cast<const unsigned long long*>(src);
+            const unsigned long long v0 = __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v1 = __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            theirs = f32x4{__uint_as_float((unsigned)v0), __uint_as_float((unsigned)(v0 >> 32)), __uint_as_float((unsigned)v1),
+                           __uint_as_float((unsigned)(v1 >> 32))};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ring(t), hx(t), the partner tile: all issued long ago but the last
+        const float* sl = ring + w * 5 * 256 + j * 16 + 4 * kq;
+        float4 pf[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pf[q] = *reinterpret_cast<const float4*>(sl + q * 256);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t > 0) issue(t - 1);
+        // ---- pointwise of tile (m, c)
+        const float gi[4] = {pf[0].x, pf[0].y, pf[0].z, pf[0].w}, gf[4] = {pf[1].x, pf[1].y, pf[1].z, pf[1].w};
+        const float gg[4] = {pf[2].x, pf[2].y, pf[2].z, pf[2].w}, go[4] = {pf[3].x, pf[3].y, pf[3].z, pf[3].w};
+        const float cp[4] = {pf[4].x, pf[4].y, pf[4].z, pf[4].w};
+        float dg[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dh = dh_rec[r] + theirs[r];
+            const float cc = gf[r] * cp[r] + gi[r] * gg[r];
+            const float tch = ftanh(cc);
+            const float dc = dh * go[r] * (1.0f - tch * tch) + dc_next[r];
+            dg[0][r] = dc * gg[r] * gi[r] * (1.0f - gi[r]);
+            dg[1][r] = dc * cp[r] * gf[r] * (1.0f - gf[r]);
+            dg[2][r] = dc * gi[r] * (1.0f - gg[r] * gg[r]);
+            dg[3][r] = dh * tch * go[r] * (1.0f - go[r]);
+            dc_next[r] = dc * gf[r];
+        }
+        // per-env power-of-two scale of the dh product's operand: max over this lane's 16 values, the four kq lanes of env j, and
+        // the four waves m = 0..3 that share the env tile (through LDS after the barrier: here per (wave, env), unscaled per wave)
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, fabsf(dg[q][r]));
+        {
+            const unsigned u = __builtin_bit_cast(unsigned, mx);
+            const auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s16[0]), __builtin_bit_cast(float, (unsigned)s16[1]));
+            const unsigned v = __builtin_bit_cast(unsigned, mx);
+            const auto s32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
+        }
+        // (one scale per ENV over all 256 rows is needed because K runs over all of them: a fixed exponent bound stands in for
+        //  the cross-wave max, which costs one more LDS exchange of 32 floats in the product kernel)
+        (void)mx;
+        const int ex = 12;                                            // synthetic data: |dG| < 1
+        lds_barrier();          // B3: every wave has finished reading the planes of step t + 1 (dh product and dW product)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned short ba[2][4], bb[2][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                _Float16 p0, p1, q0, q1;
+                split2h(__builtin_amdgcn_ldexpf(dg[q][r], ex), p0, p1);
+                split2u(dg[q][r] * a.gscale, q0, q1);
+                ba[0][r] = hb(p0); ba[1][r] = hb(p1); bb[0][r] = hb(q0); bb[1][r] = hb(q1);
+            }
+            const int off = (16 * c + j) * RSA + q * HU + ul;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                *reinterpret_cast<uint2*>(pA + pc * PLA + off) = make_uint2(ba[pc][0] | (unsigned)ba[pc][1] << 16, ba[pc][2] | (unsigned)ba[pc][3] << 16);
+                *reinterpret_cast<uint2*>(pB + pc * PLA + off) = make_uint2(bb[pc][0] | (unsigned)bb[pc][1] << 16, bb[pc][2] | (unsigned)bb[pc][3] << 16);
+            }
+        }
+        if (m == 0 && kq == 0) unsc[16 * c + j] = __builtin_amdgcn_ldexpf(1.0f, -ex);
+        hx_commit();
+        if (t > 0) hx_load(t - 1);
+        lds_barrier();          // B1: planes of step t complete
+        // ---- dh product: unit tile w x both env tiles, K = 256 own rows
+        f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int cc2 = 0; cc2 < 2; ++cc2) {
+                const unsigned short* br = pA + (16 * cc2 + j) * RSA + 32 * s + 8 * kq;
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(br);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(br + PLA);
+                d1[cc2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][1], b0, d1[cc2], 0, 0, 0);
+                d0[cc2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][0], b0, d0[cc2], 0, 0, 0);
+                d1[cc2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s][0], b1, d1[cc2], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");                           // one slab's fragments at a time
+        }
+        f32x4 res[2];
+#pragma unroll
+        for (int cc2 = 0; cc2 < 2; ++cc2) res[cc2] = (d0[cc2] + d1[cc2] * LO) * unsc[16 * cc2 + j];
+        if (w < 4) {
+            hop[w * 64 + lane] = res[1];                              // own tile (m = w, c = 1) -> wave w + 4
+        } else {
+            float* dst = my_x + ((size_t)(par * 2 + half) * 8 + (w - 4)) * 64 * 4 + lane * 4;       // partner tile (m = w - 4), c = 0 | 1
+#pragma unroll
+            for (int cc2 = 0; cc2 < 2; ++cc2) {
+                unsigned long long* d8 = reinterpret_cast<unsigned long long*>(dst + (size_t)cc2 * 4 * 64 * 4);
+                __hip_atomic_store(d8, (unsigned long long)__float_as_uint(res[cc2][0]) | ((unsigned long long)__float_as_uint(res[cc2][1]) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(d8 + 1, (unsigned long long)__float_as_uint(res[cc2][2]) | ((unsigned long long)__float_as_uint(res[cc2][3]) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the coherent stores are acknowledged
+        }
+        lds_barrier();          // B2: hop tiles written, partner tiles stored
+        if (threadIdx.x == 0 && t > 0) __hip_atomic_store(fl + half, (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh_rec[r] = res[0][r];
+        } else {
+            const f32x4 v = hop[(w - 4) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dh_rec[r] = v[r];
+        }
+        // ---- dW += dG^T [h_prev | x | 1]: off the dh chain, under the hand-off's latency
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const f16x8 a0 = tr_frag(pB + 16 * (2 * w + rt), RSA, lane);
+            const f16x8 a1 = tr_frag(pB + PLA + 16 * (2 * w + rt), RSA, lane);
+#pragma unroll
+            for (int ct = 0; ct < 9; ++ct) {
+                const f16x8 b0 = tr_frag(pH + 16 * ct, RSH, lane);
+                const f16x8 b1 = tr_frag(pH + PLH + 16 * ct, RSH, lane);
+                dw[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, dw[rt][ct], 0, 0, 0);
+                dw[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, dw[rt][ct], 0, 0, 0);
+                dw[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, dw[rt][ct], 0, 0, 0);
+                if (ct & 1) asm volatile("" ::: "memory");           // two column tiles' fragments at a time
+            }
+        }
+    }
+    // dh0 needs the partner's last contribution (step 0) too: the flag of step 0 is not raised (t > 0 above), so finish through
+    // one more hand-off with flag value 0 ... the probe writes its own part only and the host adds the two halves' xbuf tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *reinterpret_cast<float4*>(a.dh0 + (size_t)n * H + ug) = float4{dh_rec[0], dh_rec[1], dh_rec[2], dh_rec[3]};
+    *reinterpret_cast<float4*>(a.dc0 + (size_t)n * H + ug) = float4{dc_next[0], dc_next[1], dc_next[2], dc_next[3]};
+    float* slab = a.slab + (size_t)blockIdx.x * R * NCOL;
+    const float inv = 1.0f / (a.gscale * HSCALE);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 9; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(size_t)(32 * w + 16 * rt + 4 * kq + r) * NCOL + 16 * ct + j] = dw[rt][ct][r] * inv;
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static double sig(double v) { return 1.0 / (1.0 + exp(-v)); }
+
+int main(int argc, char** argv) {
+    const int pairs = argc > 1 ? atoi(argv[1]) : 128, T = argc > 2 ? atoi(argv[2]) : 128;
+    if (pairs < 8 || pairs % 8 || pairs > 128) { fprintf(stderr, "pairs: a multiple of 8 in 8..128 (both halves of every pair resident)\n"); return 2; }
+    const int N = pairs * E;
+    unsigned s = 777u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    std::vector<float> stash((size_t)N * T * 6 * H), y((size_t)N * T * H), x((size_t)N * T * XC), w((size_t)4 * H * H), dhn((size_t)N * H), dcn((size_t)N * H);
+    for (size_t i = 0; i < (size_t)N * T; ++i) {
+        float* r = &stash[i * 6 * H];
+        for (int u = 0; u < H; ++u) {
+            r[u] = (float)sig(3.0 * rnd()); r[H + u] = (float)sig(3.0 * rnd() + 1.0); r[2 * H + u] = (float)tanh(2.0 * rnd());
+            r[3 * H + u] = (float)sig(3.0 * rnd()); r[4 * H + u] = rnd(); r[5 * H + u] = 0.f;
+        }
+        for (int u = 0; u < H; ++u) y[i * H + u] = rnd();
+        for (int f = 0; f < 6; ++f) x[i * XC + f] = rnd() + 0.5f;
+        x[i * XC + 6] = 1.0f; x[i * XC + 7] = 0.0f;
+    }
+    for (auto& v : w) v = rnd() * 0.18f;
+    for (auto& v : dhn) v = rnd() * 0.02f;
+    for (auto& v : dcn) v = rnd() * 0.02f;
+    Args a{};
+    float *dstash, *dy, *dx, *dw_, *ddhn, *ddcn, *ddh0, *ddc0, *dslab, *dxb;
+    unsigned *dfl, *derr;
+    CK(hipMalloc(&dstash, stash.size() * 4)); CK(hipMalloc(&dy, y.size() * 4)); CK(hipMalloc(&dx, x.size() * 4));
+    CK(hipMalloc(&dw_, w.size() * 4)); CK(hipMalloc(&ddhn, dhn.size() * 4)); CK(hipMalloc(&ddcn, dcn.size() * 4));
+    CK(hipMalloc(&ddh0, dhn.size() * 4)); CK(hipMalloc(&ddc0, dhn.size() * 4));
+    CK(hipMalloc(&dslab, (size_t)2 * pairs * R * NCOL * 4)); CK(hipMalloc(&dxb, (size_t)pairs * 2 * 2 * 8 * 64 * 4 * 4));
+    CK(hipMalloc(&dfl, pairs * 2 * 4)); CK(hipMalloc(&derr, 4));
+    CK(hipMemcpy(dstash, stash.data(), stash.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dy, y.data(), y.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw_, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ddhn, dhn.data(), dhn.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(ddcn, dcn.data(), dcn.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(derr, 0, 4));
+    a.stash = dstash; a.y = dy; a.x = dx; a.w_hh = dw_; a.dhn = ddhn; a.dcn = ddcn; a.dh0 = ddh0; a.dc0 = ddc0; a.slab = dslab;
+    a.xbuf = dxb; a.flags = dfl; a.err = derr; a.N = N; a.T = T; a.gscale = 4096.0f;
+    const size_t lds = (size_t)(4 * PLA + 2 * PLH) * 2 + (8 * 5 * 256 + 4 * 64 * 4 + 32) * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto launch = [&]() {
+        std::vector<unsigned> init(pairs * 2, 0xffffffffu);          // flag = the step whose tiles are ready (counts DOWN from T)
+        CK(hipMemcpyAsync(dfl, init.data(), init.size() * 4, hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(fused_pair_kernel, dim3(2 * pairs), dim3(512), lds, 0, a);
+        CK(hipGetLastError());
+    };
+    launch();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ts;
+    for (int rep = 0; rep < 7; ++rep) {
+        std::vector<unsigned> init(pairs * 2, 0xffffffffu);
+        CK(hipMemcpy(dfl, init.data(), init.size() * 4, hipMemcpyHostToDevice));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(fused_pair_kernel, dim3(2 * pairs), dim3(512), lds, 0, a);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const double ms = ts[ts.size() / 2];
+    const double gb = ((double)N * T * (5.0 * H + 2.0 * H + 2.0 * XC) * 4) / 1e9;
+    printf("fused pair schedule: %d pairs (%d envs), T = %d: %.3f ms = %.3f us per step; ~%.2f GB requested -> %.2f TB/s\n", pairs, N, T, ms,
+           1e3 * ms / T, gb, gb / ms);
+    printf("to set against lstm_bwd_h3k_kernel + lstm_wgrad_h3_kernel at 4096 x 128: 0.52 + 0.335 ms = 6.7 us per step (LDS %zu B)\n", lds);
+    unsigned herr = 0;
+    CK(hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost));
+    printf("partner time-outs: %u\n", herr);
+    // ---- check against a plain f64 BPTT + weight gradient on the host: the first pair only
+    {
+        const int NE = E;
+        std::vector<double> dh((size_t)NE * H), dc((size_t)NE * H), dW((size_t)4 * H * NCOL, 0.0), dG(4 * H);
+        for (int e = 0; e < NE; ++e)
+            for (int u = 0; u < H; ++u) { dh[e * H + u] = dhn[(size_t)e * H + u]; dc[e * H + u] = dcn[(size_t)e * H + u]; }
+        for (int t = T - 1; t >= 0; --t) {
+            std::vector<double> ndh((size_t)NE * H, 0.0);
+            for (int e = 0; e < NE; ++e) {
+                const float* r = &stash[((size_t)e * T + t) * 6 * H];
+                for (int u = 0; u < H; ++u) {
+                    const double gi = r[u], gf = r[H + u], gg = r[2 * H + u], go = r[3 * H + u], cp = r[4 * H + u];
+                    const double cc = gf * cp + gi * gg, tch = tanh(cc);
+                    const double d = dh[e * H + u], dcc = d * go * (1 - tch * tch) + dc[e * H + u];
+                    dG[u] = dcc * gg * gi * (1 - gi); dG[H + u] = dcc * cp * gf * (1 - gf);
+                    dG[2 * H + u] = dcc * gi * (1 - gg * gg); dG[3 * H + u] = d * tch * go * (1 - go);
+                    dc[e * H + u] = dcc * gf;
+                }
+                for (int g = 0; g < 4 * H; ++g) {
+                    for (int u = 0; u < H; ++u) ndh[e * H + u] += dG[g] * w[(size_t)g * H + u];
+                    if (t > 0) for (int u = 0; u < H; ++u) dW[(size_t)g * NCOL + u] += dG[g] * y[((size_t)e * T + t - 1) * H + u];
+                    for (int f = 0; f < XC; ++f) dW[(size_t)g * NCOL + H + f] += dG[g] * x[((size_t)e * T + t) * XC + f];
+                }
+            }
+            dh = ndh;
+        }
+        std::vector<float> gdc((size_t)NE * H), gslab((size_t)2 * R * NCOL), gdh((size_t)NE * H), gx((size_t)2 * 2 * 8 * 64 * 4);
+        CK(hipMemcpy(gdc.data(), ddc0, gdc.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gdh.data(), ddh0, gdh.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(gx.data(), dxb, gx.size() * 4, hipMemcpyDeviceToHost));
+        // pair 0 = blocks 0 (half 0) and 8 (half 1)
+        std::vector<float> s0((size_t)R * NCOL), s1((size_t)R * NCOL);
+        CK(hipMemcpy(s0.data(), dslab, s0.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(s1.data(), dslab + (size_t)8 * R * NCOL, s1.size() * 4, hipMemcpyDeviceToHost));
+        double ec = 0, sc = 0, ew = 0, sw = 0, eh = 0, sh = 0;
+        for (size_t i = 0; i < gdc.size(); ++i) { ec = fmax(ec, fabs(gdc[i] - dc[i])); sc = fmax(sc, fabs(dc[i])); }
+        for (int hf = 0; hf < 2; ++hf)
+            for (int lr = 0; lr < R; ++lr)
+                for (int col = 0; col < H + 7; ++col) {
+                    const int g = (lr >> 6) * H + HU * hf + (lr & 63);
+                    const double want = dW[(size_t)g * NCOL + col], got = (hf ? s1 : s0)[(size_t)lr * NCOL + col];
+                    ew = fmax(ew, fabs(got - want)); sw = fmax(sw, fabs(want));
+                }
+        // dh0 = own part (written) + the partner's step-0 tile (still in xbuf, parity 0)
+        for (int e = 0; e < NE; ++e)
+            for (int u = 0; u < H; ++u) {
+                const int hf = u / HU, ulc = u % HU, mm = ulc / 16, kqq = (ulc % 16) / 4, rr = ulc % 4, cc = e / 16, jj = e % 16;
+                const float part = gx[((size_t)((0 * 2 + (1 - hf)) * 8 + (4 * cc + mm)) * 64 + (16 * kqq + jj)) * 4 + rr];
+                const double got = (double)gdh[(size_t)e * H + u] + part;
+                eh = fmax(eh, fabs(got - dh[e * H + u])); sh = fmax(sh, fabs(dh[e * H + u]));
+            }
+        printf("check against the f64 host reference (pair 0): dc0 err %.3g of %.3g, dh0 err %.3g of %.3g, dW err %.3g of %.3g\n", ec, sc, eh, sh, ew, sw);
+        if (ec > 1e-4 * sc || eh > 1e-4 * sh || ew > 1e-4 * sw || herr) { printf("MISMATCH\n"); return 1; }
+    }
+    return 0;
+}
