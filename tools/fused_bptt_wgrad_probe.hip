@@ -71,6 +71,8 @@ struct Args {
     unsigned* err;
     int N, T;
     float gscale;         // fixed power-of-two scale of dG for the weight-gradient operand
+    unsigned abl;         // ablations (timing only, results wrong): 1 no hand-off wait / partner tile, 2 no dW products, 4 no second
+                          // split + plane set, 8 no stash DMA, 16 no [h_prev | x | 1] staging, 32 no dh product
 };
 
 __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
     float* ring = reinterpret_cast<float*>(pH + 2 * PLH);                  // [8 waves][5][256]
     f32x4* hop = reinterpret_cast<f32x4*>(ring + 8 * 5 * 256);             // [4][64]: own tile (m, c = 1) from wave m to wave m + 4
     float* unsc = reinterpret_cast<float*>(hop + 4 * 64);                  // [32] per-env unscale of the dh product
+    float* emax = unsc + 32;                                               // [4 m][32 envs] per-wave maxima of |dG|
 
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, kq = lane >> 4;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
         const int par = t & 1;
         // ---- the partner's contribution to dh of this tile, produced by its step t + 1
         f32x4 theirs = {0.f, 0.f, 0.f, 0.f};
-        if (t < T - 1) {
+        if (t < T - 1 && !(a.abl & 1u)) {
             if (!dead) {
                 unsigned spins = 0;
                 while (__hip_atomic_load(fl + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)(t + 1)) {
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) pf[q] = *reinterpret_cast<const float4*>(sl + q * 256);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t > 0) issue(t - 1);
+        if (t > 0 && !(a.abl & 8u)) issue(t - 1);
         // ---- pointwise of tile (m, c)
         const float gi[4] = {pf[0].x, pf[0].y, pf[0].z, pf[0].w}, gf[4] = {pf[1].x, pf[1].y, pf[1].z, pf[1].w};
         const float gg[4] = {pf[2].x, pf[2].y, pf[2].z, pf[2].w}, go[4] = {pf[3].x, pf[3].y, pf[3].z, pf[3].w};
@@ -241,11 +244,12 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
             const auto s32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
             mx = fmaxf(__builtin_bit_cast(float, (unsigned)s32[0]), __builtin_bit_cast(float, (unsigned)s32[1]));
         }
-        // (one scale per ENV over all 256 rows is needed because K runs over all of them: a fixed exponent bound stands in for
-        //  the cross-wave max, which costs one more LDS exchange of 32 floats in the product kernel)
-        (void)mx;
-        const int ex = 12;                                            // synthetic data: |dG| < 1
+        // one scale per ENV over all 256 own rows (K runs over all of them): the four waves of an env tile agree through LDS
+        if (kq == 0) emax[m * 32 + 16 * c + j] = mx;
         lds_barrier();          // B3: every wave has finished reading the planes of step t + 1 (dh product and dW product)
+        mx = fmaxf(fmaxf(emax[16 * c + j], emax[32 + 16 * c + j]), fmaxf(emax[64 + 16 * c + j], emax[96 + 16 * c + j]));
+        int ex = 14 - __builtin_amdgcn_frexp_expf(mx);
+        ex = mx > 0.f ? min(max(ex, -100), 100) : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             unsigned short ba[2][4], bb[2][4];
@@ -253,22 +257,27 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
             for (int r = 0; r < 4; ++r) {
                 _Float16 p0, p1, q0, q1;
                 split2h(__builtin_amdgcn_ldexpf(dg[q][r], ex), p0, p1);
-                split2u(dg[q][r] * a.gscale, q0, q1);
+                if (!(a.abl & 4u)) split2u(dg[q][r] * a.gscale, q0, q1);
+                else { q0 = p0; q1 = p1; }
                 ba[0][r] = hb(p0); ba[1][r] = hb(p1); bb[0][r] = hb(q0); bb[1][r] = hb(q1);
             }
             const int off = (16 * c + j) * RSA + q * HU + ul;
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) {
                 *reinterpret_cast<uint2*>(pA + pc * PLA + off) = make_uint2(ba[pc][0] | (unsigned)ba[pc][1] << 16, ba[pc][2] | (unsigned)ba[pc][3] << 16);
-                *reinterpret_cast<uint2*>(pB + pc * PLA + off) = make_uint2(bb[pc][0] | (unsigned)bb[pc][1] << 16, bb[pc][2] | (unsigned)bb[pc][3] << 16);
+                if (!(a.abl & 4u))
+                    *reinterpret_cast<uint2*>(pB + pc * PLA + off) = make_uint2(bb[pc][0] | (unsigned)bb[pc][1] << 16, bb[pc][2] | (unsigned)bb[pc][3] << 16);
             }
         }
         if (m == 0 && kq == 0) unsc[16 * c + j] = __builtin_amdgcn_ldexpf(1.0f, -ex);
-        hx_commit();
-        if (t > 0) hx_load(t - 1);
+        if (!(a.abl & 16u)) {
+            hx_commit();
+            if (t > 0) hx_load(t - 1);
+        }
         lds_barrier();          // B1: planes of step t complete
         // ---- dh product: unit tile w x both env tiles, K = 256 own rows
         f32x4 d0[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, d1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (!(a.abl & 32u))
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
 #pragma unroll
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
         for (int cc2 = 0; cc2 < 2; ++cc2) res[cc2] = (d0[cc2] + d1[cc2] * LO) * unsc[16 * cc2 + j];
         if (w < 4) {
             hop[w * 64 + lane] = res[1];                              // own tile (m = w, c = 1) -> wave w + 4
-        } else {
+        } else if (!(a.abl & 1u)) {
             float* dst = my_x + ((size_t)(par * 2 + half) * 8 + (w - 4)) * 64 * 4 + lane * 4;       // partner tile (m = w - 4), c = 0 | 1
 #pragma unroll
             for (int cc2 = 0; cc2 < 2; ++cc2) {
@@ -310,6 +319,7 @@ __global__ __launch_bounds__(512) void fused_pair_kernel(Args a) {
             for (int r = 0; r < 4; ++r) dh_rec[r] = v[r];
         }
         // ---- dW += dG^T [h_prev | x | 1]: off the dh chain, under the hand-off's latency
+        if (!(a.abl & 2u))
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             const f16x8 a0 = tr_frag(pB + 16 * (2 * w + rt), RSA, lane);
@@ -345,6 +355,7 @@ static double sig(double v) { return 1.0 / (1.0 + exp(-v)); }
 
 int main(int argc, char** argv) {
     const int pairs = argc > 1 ? atoi(argv[1]) : 128, T = argc > 2 ? atoi(argv[2]) : 128;
+    const bool ablate = argc > 3 && atoi(argv[3]) != 0;
     if (pairs < 8 || pairs % 8 || pairs > 128) { fprintf(stderr, "pairs: a multiple of 8 in 8..128 (both halves of every pair resident)\n"); return 2; }
     const int N = pairs * E;
     unsigned s = 777u;
@@ -353,7 +364,7 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < (size_t)N * T; ++i) {
         float* r = &stash[i * 6 * H];
         for (int u = 0; u < H; ++u) {
-            r[u] = (float)sig(3.0 * rnd()); r[H + u] = (float)sig(3.0 * rnd() + 1.0); r[2 * H + u] = (float)tanh(2.0 * rnd());
+            r[u] = (float)sig(3.0 * rnd()); r[H + u] = (float)sig(2.0 * rnd() + 4.0); r[2 * H + u] = (float)tanh(2.0 * rnd());
             r[3 * H + u] = (float)sig(3.0 * rnd()); r[4 * H + u] = rnd(); r[5 * H + u] = 0.f;
         }
         for (int u = 0; u < H; ++u) y[i * H + u] = rnd();
@@ -379,8 +390,8 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(ddcn, dcn.data(), dcn.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(derr, 0, 4));
     a.stash = dstash; a.y = dy; a.x = dx; a.w_hh = dw_; a.dhn = ddhn; a.dcn = ddcn; a.dh0 = ddh0; a.dc0 = ddc0; a.slab = dslab;
-    a.xbuf = dxb; a.flags = dfl; a.err = derr; a.N = N; a.T = T; a.gscale = 4096.0f;
-    const size_t lds = (size_t)(4 * PLA + 2 * PLH) * 2 + (8 * 5 * 256 + 4 * 64 * 4 + 32) * 4;
+    a.xbuf = dxb; a.flags = dfl; a.err = derr; a.N = N; a.T = T; a.gscale = 4096.0f; a.abl = 0;
+    const size_t lds = (size_t)(4 * PLA + 2 * PLH) * 2 + (8 * 5 * 256 + 4 * 64 * 4 + 32 + 128) * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     auto launch = [&]() {
         std::vector<unsigned> init(pairs * 2, 0xffffffffu);          // flag = the step whose tiles are ready (counts DOWN from T)
@@ -410,6 +421,34 @@ int main(int argc, char** argv) {
     printf("fused pair schedule: %d pairs (%d envs), T = %d: %.3f ms = %.3f us per step; ~%.2f GB requested -> %.2f TB/s\n", pairs, N, T, ms,
            1e3 * ms / T, gb, gb / ms);
     printf("to set against lstm_bwd_h3k_kernel + lstm_wgrad_h3_kernel at 4096 x 128: 0.52 + 0.335 ms = 6.7 us per step (LDS %zu B)\n", lds);
+    if (ablate) {
+        const unsigned masks[] = {1, 2, 4, 6, 8, 16, 32, 1 | 2 | 4 | 16, 63};
+        const char* names[] = {"no hand-off (wait, partner tile)", "no dW products", "no second split / plane set", "no dW products, no second split",
+                               "no stash DMA", "no [h_prev | x | 1] staging", "no dh product", "BPTT only (no hand-off, no dW side at all)",
+                               "nothing but pointwise + barriers"};
+        for (int k = 0; k < 9; ++k) {
+            a.abl = masks[k];
+            std::vector<float> tt;
+            for (int rep = 0; rep < 5; ++rep) {
+                std::vector<unsigned> init(pairs * 2, 0xffffffffu);
+                CK(hipMemcpy(dfl, init.data(), init.size() * 4, hipMemcpyHostToDevice));
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(fused_pair_kernel, dim3(2 * pairs), dim3(512), lds, 0, a);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float m2;
+                CK(hipEventElapsedTime(&m2, e0, e1));
+                tt.push_back(m2);
+            }
+            std::sort(tt.begin(), tt.end());
+            printf("  ablation %-48s: %.3f ms = %.3f us per step (%+.3f)\n", names[k], tt[2], 1e3 * tt[2] / T, 1e3 * (tt[2] - ms) / T);
+        }
+        a.abl = 0;
+        std::vector<unsigned> init(pairs * 2, 0xffffffffu);
+        CK(hipMemcpy(dfl, init.data(), init.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(fused_pair_kernel, dim3(2 * pairs), dim3(512), lds, 0, a);       // leave correct results for the check
+        CK(hipDeviceSynchronize());
+    }
     unsigned herr = 0;
     CK(hipMemcpy(&herr, derr, 4, hipMemcpyDeviceToHost));
     printf("partner time-outs: %u\n", herr);
