@@ -96,7 +96,7 @@ def _fake_launch(tmp_path, monkeypatch, mode, backend="gloo", cap=5):
     real = bench.spawn_ranks
     monkeypatch.setattr(bench, "spawn_ranks", lambda n, cmd, **kw: real(n, cmd, **dict(kw, timeout=min(kw.get("timeout") or cap, cap))))
     args = argparse.Namespace(gpus=2, scaling="weak", no_strong_phase=False, steps=4, warmup=1, config="c2", backend=backend,
-                              headline_timeout=0.0, collectives="torch", pg_timeout=300.0)
+                              headline_timeout=0.0, collectives="torch", pg_timeout=600.0)
     return bench.launch(args, ["--gpus", "2", "--config", "c2", f"--backend={backend}"])
 
 

@@ -233,3 +233,19 @@ def test_c3_whole_iteration_matches_oracle():
     assert tr._rollout_forward_valid                    # epoch 0 will adopt the rollout's stash, as in the bench
     m = update_vs_oracle(tr, "c3")
     assert m["samples"] == 524288 and len(m["steps"]) == 5
+
+
+def test_c3_minibatched_iteration_matches_oracle():
+    """U1 at full size (train_ppo2.0.py:43-53 with M = 8): the same 4096 x 128 buffers updated in eight minibatches of 512 whole env
+    sequences per epoch (no rollout-forward reuse, minibatch-sized work buffers, h0 / c0 slices, loss mean over the minibatch) for two
+    epochs = 16 optimiser steps, against the oracle update that slices the same way -- every step's gradient at the same parameters,
+    clip + Adam on the same gradients, the free-running loss curve."""
+    from _iteration_check import update_vs_oracle
+    from uavppo.trainer import VecPPOTrainer
+    tr = VecPPOTrainer(N, T, "lstm", hidden=H, device=DEV, seed=4321, use_curriculum=False, num_minibatches=8, epochs=2)
+    tr.radius = 120.0                                   # episodes end inside the rollout: restarts in most minibatches
+    tr.reset()
+    tr.collect()
+    assert not tr._rollout_forward_valid
+    m = update_vs_oracle(tr, "c3_m8")
+    assert len(m["steps"]) == 16 and m["episode_ends"] >= 500
