@@ -202,3 +202,52 @@ def test_writer_layout_matches_the_reference_schema_dump(tmp_path):
             got = d[name][3]
             got = got[got != 0] if name == "is_source" else got
             assert np.all(got >= v["min"]) and np.all(got <= v["max"]), name      # the constants the reference logs
+
+
+def test_classic_netcdf_file_follows_the_reference_schema_and_round_trips(tmp_path):
+    """Without the netCDF4 package a path that does not end in .npz becomes a REAL netCDF file in the classic format (scipy.io):
+    dimensions, variable names, shapes, dtypes, `_FillValue` and text attributes as PPOV2.1/nc_info.txt:1-46 shows them for the
+    reference's training_data.nc (tests/golden/nc_schema.json), and both loaders read it back exactly like the .npz back end."""
+    import json
+    from scipy.io import netcdf_file
+    schema = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nc_schema.json"), encoding="utf-8"))
+    nw, dl = _product_modules()
+    try:
+        import netCDF4  # noqa: F401
+        pytest.skip("netCDF4 is installed: the writer takes the reference's own NETCDF4 path")
+    except ImportError:
+        pass
+    rng = np.random.RandomState(3)
+    files = {}
+    for ext in ("nc", "npz"):
+        path = str(tmp_path / f"training_data.{ext}")
+        w = nw.NetCDFWriter(path, 500)
+        for ep, steps in ((0, 25), (3, 40), (1999, 1000)):
+            xs, ys, cs = rng.rand(steps) * 499, rng.rand(steps) * 499, rng.rand(steps) * 100
+            w.write_episode_data(ep, steps, xs, ys, cs, 449.0 - ep * 0.1, 51.0, 100.0, sigma=15.0, peak=100.0)
+        rng = np.random.RandomState(3)                   # the same episodes into both files
+        w.close()
+        files[ext] = path
+    assert open(files["nc"], "rb").read(3) == b"CDF"
+    with netcdf_file(files["nc"], "r", mmap=False) as nc:
+        assert dict(nc.dimensions) == schema["dimensions"] and int(nc.GRID_SIZE) == 500
+        assert set(nc.variables) == set(schema["variables"])
+        for name, v in schema["variables"].items():
+            var = nc.variables[name]
+            assert list(var.shape) == v["shape"] and str(var[:].dtype.newbyteorder("=")) == v["dtype"], name
+            for k, val in v["attrs"].items():
+                if k == "_FillValue":
+                    got = var._FillValue
+                    assert np.isnan(got) if val == "nan" else int(got) == int(val), name
+                else:
+                    assert getattr(var, k).decode() == val, (name, k)
+        assert nc.variables["is_source"][3, 39] == 1 and nc.variables["x"][3, 39] == np.float32(449.0 - 0.3)      # last step = source
+        assert np.isnan(nc.variables["x"][5]).all()                                                             # unwritten episode
+    a, sa = dl.load_raw_sequences(files["nc"])
+    b, sb = dl.load_raw_sequences(files["npz"])
+    assert [len(s) for s in a] == [25, 40, 1000] and a == b and np.array_equal(sa, sb)
+    sega, segb = dl.load_trajectory_segments(files["nc"]), dl.load_trajectory_segments(files["npz"])
+    assert len(sega) == len(segb) == 6 + 21 + 981
+    for p, q in zip(sega[::97], segb[::97]):
+        assert np.array_equal(p["positions"], q["positions"]) and np.array_equal(p["concentrations"], q["concentrations"])
+        assert np.array_equal(p["source_pos"], q["source_pos"]) and p["sigma"] == q["sigma"]

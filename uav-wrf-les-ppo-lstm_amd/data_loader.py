@@ -1,17 +1,37 @@
 """data_loader.py -- counterpart of the reference's PPOV2.0/data_loader.py:5-22 (concentration sequences and source
 concentrations of the logged episodes) and of load_trajectory_segments, PPOV2.1/model.py:68-90 (sliding windows).  Reads the reference's netCDF file when netCDF4 is installed, or an .npz with the
-same variable names (x, concentration, source_concentration; NaN = unused step) otherwise."""
+same variable names (x, concentration, source_concentration; NaN = unused step); without netCDF4 a CLASSIC-format netCDF
+file (what netcdf_writer.py writes in that case, or any NetCDF-3 file with these variables) is read through scipy.io."""
 import numpy as np
+
+
+def _nc_variables(path, names):
+    """{name: float/int array with fills as NaN} for the variables of `names` the file holds."""
+    try:
+        from netCDF4 import Dataset          # same calls as the reference
+    except ImportError:
+        from scipy.io import netcdf_file     # classic format only (an HDF5-based NETCDF4 file needs the netCDF4 package)
+        with netcdf_file(path, "r", mmap=False) as nc:
+            out = {}
+            for k in names:
+                if k in nc.variables:
+                    v = nc.variables[k]
+                    a = np.array(v[:])
+                    fill = getattr(v, "_FillValue", None)
+                    if fill is not None and a.dtype.kind == "f" and not np.isnan(fill):
+                        a = np.where(a == fill, np.nan, a)
+                    out[k] = a
+            return out
+    with Dataset(path, "r") as nc:
+        return {k: np.ma.filled(nc[k][:], np.nan) for k in names if k in nc.variables}
 
 
 def _arrays(path):
     if str(path).endswith(".npz"):
         d = np.load(path)
         return d["x"], d["concentration"], d["source_concentration"]
-    from netCDF4 import Dataset          # same calls as the reference
-    with Dataset(path, "r") as nc:
-        return (np.ma.filled(nc["x"][:], np.nan), np.ma.filled(nc["concentration"][:], np.nan),
-                np.ma.filled(nc["source_concentration"][:], np.nan))
+    v = _nc_variables(path, ("x", "concentration", "source_concentration"))
+    return v["x"], v["concentration"], v["source_concentration"]
 
 
 def load_raw_sequences(nc_path):
@@ -33,10 +53,7 @@ def load_trajectory_segments(nc_path, tail_steps=60, window_size=20):
         d = np.load(nc_path)
         get = lambda k: d[k] if k in d.files else None
     else:
-        from netCDF4 import Dataset
-        with Dataset(nc_path, "r") as nc:
-            held = {k: np.ma.filled(nc[k][:], np.nan) for k in ("x", "y", "concentration", "source_x", "source_y", "gaussian_sigma")
-                    if k in nc.variables}
+        held = _nc_variables(nc_path, ("x", "y", "concentration", "source_x", "source_y", "gaussian_sigma"))
         get = held.get
     x, y, conc, sx, sy, sig = (get(k) for k in ("x", "y", "concentration", "source_x", "source_y", "gaussian_sigma"))
     segments = []

@@ -3,9 +3,14 @@ hands successful episodes from PPO training to the LSTM stage (loaded back by da
 
 Same constructor, variables (episode, step, x, y, concentration, is_source, source_concentration, source_x, source_y),
 dtypes, fill values and write_episode_data() semantics (the last step's x / y are overwritten with the source coordinates
-and flagged in is_source).  With netCDF4 installed and a filename not ending in .npz the file is a real NETCDF4 file written
-through the reference's own calls; otherwise (this image has no netCDF4) the arrays are kept in memory and close() writes
-an .npz with the same variable names.  PPOV2.1 keeps the same class in model.py:355-423 with two more per-episode variables,
+and flagged in is_source).  Three back ends, chosen by what is installed and by the file name:
+  * netCDF4 installed, name not ending in .npz: a real NETCDF4 file written through the reference's own calls;
+  * no netCDF4 (this image), name not ending in .npz: the arrays are kept in memory and close() writes a real netCDF file in the
+    CLASSIC format (NetCDF-3, 64-bit offsets) through scipy.io.netcdf_file -- same dimensions, variable names, dtypes,
+    `_FillValue` / `long_name` / `units` attributes and GRID_SIZE global attribute; the netCDF library (hence the reference's
+    `netCDF4.Dataset(path)` in data_loader.py:5-22 and PPOV2.1/model.py:68-90) reads classic files transparently, only zlib
+    compression and the HDF5 container are missing;
+  * name ending in .npz: an .npz with the same variable names (tests, quick runs).  PPOV2.1 keeps the same class in model.py:355-423 with two more per-episode variables,
 gaussian_sigma and peak_concentration, and two more write_episode_data() arguments: both are here, optional."""
 from __future__ import annotations
 
@@ -41,7 +46,7 @@ class NetCDFWriter:
                 from netCDF4 import Dataset
                 self._nc = Dataset(filename, mode="w", format="NETCDF4")
             except ImportError:
-                self.filename = str(filename) + ".npz"
+                pass                    # classic-format file through scipy at close()
         E, S = max_episodes, max_steps
         if self._nc is not None:
             nc = self._nc
@@ -92,9 +97,36 @@ class NetCDFWriter:
         if peak is not None:
             self.peak_var[episode_idx] = peak
 
+    def _write_classic(self):
+        """NetCDF-3 classic (64-bit offset) image of the arrays: what netCDF4.Dataset(path, "r") reads back as the same
+        variables (masked where the value equals `_FillValue`, as with the NETCDF4 file)."""
+        from scipy.io import netcdf_file
+        fills = {"x": np.float32(np.nan), "y": np.float32(np.nan), "concentration": np.float32(np.nan), "is_source": np.int8(0),
+                 "source_concentration": np.float32(np.nan), "source_x": np.float32(np.nan), "source_y": np.float32(np.nan)}
+        data = {"episode": (self.episode_var, ("episode",)), "step": (self.step_var, ("step",)),
+                "x": (self.x_var, ("episode", "step")), "y": (self.y_var, ("episode", "step")),
+                "concentration": (self.conc_var, ("episode", "step")), "is_source": (self.source_var, ("episode", "step")),
+                "source_concentration": (self.source_conc_var, ("episode",)), "source_x": (self.source_x_var, ("episode",)),
+                "source_y": (self.source_y_var, ("episode",)), "gaussian_sigma": (self.sigma_var, ("episode",)),
+                "peak_concentration": (self.peak_var, ("episode",))}
+        with netcdf_file(self.filename, "w", version=2) as nc:
+            nc.createDimension("episode", self.max_episodes)
+            nc.createDimension("step", self.max_steps)
+            nc.GRID_SIZE = np.int32(self.grid_size)
+            for name, (arr, dims) in data.items():
+                v = nc.createVariable(name, arr.dtype.char if arr.dtype != np.int8 else "b", dims)
+                if name in fills:
+                    v._FillValue = fills[name]
+                for k, val in ATTRS[name].items():
+                    setattr(v, k, val)
+                v[:] = arr
+
     def close(self):
         if self._nc is not None:
             self._nc.close()
+            return
+        if not str(self.filename).endswith(".npz"):
+            self._write_classic()
             return
         np.savez_compressed(self.filename, episode=self.episode_var, step=self.step_var, x=self.x_var, y=self.y_var,
                             concentration=self.conc_var, is_source=self.source_var,
