@@ -701,7 +701,7 @@ def main():
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip timing the iteration's collectives after the timed region")
     ap.add_argument("--collectives", default="torch", choices=("torch", "abi"),
                     help="carrier of the iteration's exchanges: torch.distributed (default) or the C ABI's own RCCL communicator (uav_allreduce)")
-    ap.add_argument("--pg-timeout", type=float, default=600.0, help="seconds before a stuck collective (or a rendezvous nobody joins: a fresh box can take 1-2 min to import torch) aborts the rank")
+    ap.add_argument("--pg-timeout", type=float, default=600.0, help="seconds before a stuck collective (or a rendezvous nobody joins: a fresh box can take 1-2 min to load PyTorch) aborts the rank")
     ap.add_argument("--headline-timeout", type=float, default=0.0, help="launcher mode: seconds before the headline rank set is terminated (0 = config-dependent default)")
     args = ap.parse_args()
 
