@@ -50,6 +50,23 @@ def test_loads_and_reports_version_without_gpu():
     assert lib.uav_env_state_bytes(4096) > 4096 * 200
 
 
+def test_collectives_bind_rccl_at_run_time_and_refuse_without_a_communicator():
+    """comm.hip: libuavppo.so has NO link-time dependency on RCCL (it must load on a box without it); the version query binds
+    librccl with dlopen, and the no-communicator answers need neither a GPU nor RCCL."""
+    import ctypes as C
+    from uavppo import _lib
+    lib = _lib.lib()
+    ldd = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in ldd and "nccl" not in ldd, ldd
+    assert lib.uav_comm_world(None) == 0 and lib.uav_comm_rank(None) == -1
+    v = C.c_int(0)
+    rc = lib.uav_rccl_version(C.byref(v))
+    if rc == 0:
+        assert v.value > 20000                                    # e.g. 22606 = RCCL 2.26.6
+    else:
+        assert b"RCCL unavailable" in lib.uav_last_error()        # loud, with the reason
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback: on a GPU-less host the first op raises instead of computing something else."""
     import torch
