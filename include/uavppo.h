@@ -432,7 +432,10 @@ int uav_rollout_tail(uav_ctx* ctx, void* env_state, int n_env, const uav_env_cfg
  *   uav_allgather_bytes recv [world][bytes_per_rank] <- every rank's send [bytes_per_rank]: uav_pack_success_bits' message,
  *                       consumed in rank order by uav_curriculum_update (model.py:131-164 replicated)
  * All are asynchronous on `stream` and ordered with the kernels around them; errors (no RCCL, no communicator, RCCL's own)
- * return non-zero with uav_last_error(). */
+ * return non-zero with uav_last_error().  Issue a handle's collectives on ONE stream (or order them with events identically on
+ * every rank): RCCL executes them in the order each device reaches them, and two ranks that reach two collectives of one
+ * communicator in opposite orders wait for each other (uavppo/trainer.py moves its side-stream all-gather to the main stream
+ * under this carrier for that reason). */
 #define UAV_COMM_ID_BYTES 128
 int uav_rccl_version(int* out /*host*/);
 int uav_comm_unique_id(void* id_out /*host, UAV_COMM_ID_BYTES*/);

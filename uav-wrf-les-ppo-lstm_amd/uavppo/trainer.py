@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dist_utils import (SUCC_CAP, allreduce_adv_stats, allreduce_grad, allreduce_sum, collectives_on, env_shard, exchange_successes, pack_local_successes,
+from .dist_utils import (SUCC_CAP, abi_collectives, allreduce_adv_stats, allreduce_grad, allreduce_sum, collectives_on, env_shard, exchange_successes, pack_local_successes,
                          unpack_episode_successes)
 from .curriculum import Curriculum
 from .policy import LSTMActorCritic, MLPActorCritic
@@ -174,6 +174,7 @@ class VecPPOTrainer:
         self._succ_ev = torch.cuda.Event()
         self._pack_ev = torch.cuda.Event()
         self._roll_ev = torch.cuda.Event()
+        self._gather_ev = torch.cuda.Event()
         self._succ_pending = False
         self._succ_exchanged = False
         self._succ_msg = None
@@ -436,8 +437,22 @@ class VecPPOTrainer:
         """All-gather of the packed success bits + copy to pinned host memory, on the side stream.  With several ranks it is
         issued from update(), BEHIND the advantage-statistics all-reduce in program order: RCCL runs a rank's collectives
         in the order they were issued, and that all-reduce must not queue behind the pack kernel."""
+        msgs_main = None
+        if abi_collectives() and self._coll:
+            # ABI carrier: ONE communicator on raw streams.  RCCL runs a rank's collectives in the order its device reaches them, so
+            # the all-gather must not sit on another stream than the all-reduces (two ranks could then reach the two collectives in
+            # opposite orders and wait for each other): it goes on the MAIN stream, behind the pack kernel, and the side stream
+            # picks the gathered messages up again.  (torch.distributed serialises a group's collectives on its own stream.)
+            main = torch.cuda.current_stream()
+            main.wait_event(self._pack_ev)
+            msgs_main = exchange_successes(self._succ_msg)
+            self._gather_ev.record(main)
         with torch.cuda.stream(self._side):
-            msgs = exchange_successes(self._succ_msg)
+            if msgs_main is not None:
+                self._side.wait_event(self._gather_ev)
+                msgs = msgs_main
+            else:
+                msgs = exchange_successes(self._succ_msg)
             if tuple(msgs.shape) != tuple(self._succ_host.shape):       # e.g. world_size > 1 without a process group
                 raise RuntimeError(f"success exchange returned {tuple(msgs.shape)}, expected {tuple(self._succ_host.shape)}: "
                                    "is torch.distributed initialised for world_size > 1?")
