@@ -97,3 +97,20 @@ def test_graft_entry_build_runs():
     declared = int(re.search(r"#define UAV_ABI_VERSION (\d+)", header).group(1))
     src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert f"uav_abi_version() == {declared}" in src
+
+
+def test_abi_carrier_needs_a_host_channel_for_the_unique_id():
+    """dist_utils.use_abi_collectives: rank 0 draws the communicator's 128-byte id (host-only call) and needs a channel to hand it to
+    the other ranks -- without an initialised torch.distributed group and without an explicit `uid` it must refuse, not guess."""
+    import ctypes as C
+    from uavppo import _lib, dist_utils, ops
+    v = C.c_int(0)
+    if _lib.lib().uav_rccl_version(C.byref(v)) != 0:
+        pytest.skip("no RCCL on this host")
+    uid = ops.comm_unique_id()
+    assert isinstance(uid, bytes) and len(uid) == 128 and uid != ops.comm_unique_id()      # a fresh id per draw
+    with pytest.raises(RuntimeError, match="pass `uid`"):
+        dist_utils.use_abi_collectives(0, 2)
+    assert not dist_utils.abi_collectives() and dist_utils.world() == 1
+    with pytest.raises(RuntimeError, match="128 bytes"):
+        ops.comm_init(b"short", 0, 1)
