@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 8   /* 8: uav_lstm_wgrad db_hh; uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 9   /* 9: uav_lstm_dgates_bytes / uav_lstm_dgates_f32: at h = 256 on the fp16-split arithmetic `dgates` is an opaque buffer (the BPTT's fp16 piece chunks, stored once) -- size it with uav_lstm_dgates_bytes; UAV_DEBUG_DG_F32; 8: uav_lstm_wgrad db_hh; uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -75,6 +75,7 @@ int uav_get_lstm_arith(const uav_ctx* ctx);
  * Every flag leaves results bit-identical or within f32 tolerance; nothing here can make an entry point return garbage. */
 #define UAV_DEBUG_STEP_F32 1u
 #define UAV_DEBUG_X_F32    2u
+#define UAV_DEBUG_DG_F32   4u          /* h = 256 step path: gate gradients ALSO written as f32 rows and the weight gradients taken from those (the round-4 form; an A/B switch, results within f32 tolerance) */
 #define UAV_DEBUG_GEMM_TN_OFF 0x10u   /* the dW-shaped split-fp16 products on the older one-slab-in-flight kernel (same results; an A/B switch) */
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags);
 /* out[0] (f32, device) = max |x[i]| over n floats, a NaN counting as +inf: the range probe for the modes above. */
@@ -268,12 +269,20 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
 /* BPTT sequence kernel.  Gradient of y comes either as dy [N][T][H], or -- for the actor-critic
  * heads, fused -- as dheads [N][T][n_heads] with w_head [n_heads][H] (dy = dheads . w_head is
  * formed in registers, never written to HBM); exactly one of dy / dheads is non-NULL.  dhn,dcn
- * [N][H] or NULL.  Writes dgates f32 [N][T][4H] (per-step gate gradients, the input of
- * uav_lstm_wgrad) and dh0, dc0 [N][H] (or NULL). */
+ * [N][H] or NULL.  Writes dgates (per-step gate gradients, the input of uav_lstm_wgrad: uav_lstm_dgates_bytes(ctx, N, T, H)
+ * bytes -- f32 [N][T][4H], except at H = 256 on the fp16-split arithmetic, where the buffer is OPAQUE: the two fp16 pieces per
+ * row the recurrent product consumes, scaled per (env, step) by a power of two, in MFMA fragment order + one f32 scale per
+ * (env, step), i.e. 4 bytes per (env, step) more than the f32 rows, N rounded up to 64; uav_lstm_wgrad reads that form
+ * directly and uav_lstm_dgates_f32 converts it to f32 rows) and dh0, dc0 [N][H] (or NULL).  The arithmetic mode and debug
+ * flags must not change between uav_lstm_bwd and the uav_lstm_wgrad that consumes its dgates. */
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh,
                  const float* dy, const float* dheads, const float* w_head, int n_heads,
                  const float* dhn, const float* dcn, int N, int T, int H, float* dgates, float* dh0,
                  float* dc0, const float* w_ih, int I, float* dx, uav_stream stream);
+/* Bytes of the `dgates` buffer of uav_lstm_bwd / _bwd_stack / _wgrad for this shape under the handle's arithmetic (0 on a bad
+ * argument), and its contents as f32 rows out [N][T][4H] (a copy where the buffer already is f32 rows). */
+size_t uav_lstm_dgates_bytes(uav_ctx* ctx, int N, int T, int H);
+int uav_lstm_dgates_f32(uav_ctx* ctx, const float* dgates, int N, int T, int H, float* out, uav_stream stream);
 /* What uav_lstm_bwd can do for this layer shape under the handle's arithmetic (a bit mask):
  *   UAV_BWD_FUSES_DX      dx [N][T][I] = dG W_ih (the gradient of the layer's input, for the layer below) is formed by
  *                         uav_lstm_bwd itself -- its per-step recurrent product multiplies the same dG fragments (H = 256 = I
@@ -296,7 +305,7 @@ typedef struct uav_lstm_bwd_layer {
     const float* stash;    /* [N][T][6H] */
     const float* w_hh;     /* [4H][H] */
     const float* w_ih;     /* [4H][H]; NULL for the last layer */
-    float* dgates;         /* [N][T][4H] out */
+    float* dgates;         /* out: uav_lstm_dgates_bytes(ctx, N, T, H) bytes */
     float* dx;             /* [N][T][H] out; NULL for the last layer */
     const float* dhn;      /* [N][H] or NULL */
     const float* dcn;      /* [N][H] or NULL */

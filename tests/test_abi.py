@@ -44,7 +44,7 @@ def test_ctypes_table_matches_header():
 def test_loads_and_reports_version_without_gpu():
     from uavppo import _lib
     lib = _lib.lib()
-    assert lib.uav_abi_version() == 8
+    assert lib.uav_abi_version() == 9
     assert lib.uav_mlp_param_count(6, 256, 128, 5) == 36230      # 36,230 parameters
     assert lib.uav_mlp_stash_floats(256, 128) == 2 * 256 + 2 * 128 + 2
     assert lib.uav_env_state_bytes(4096) > 4096 * 200

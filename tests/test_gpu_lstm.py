@@ -492,13 +492,55 @@ def test_lstm_bwd_stack_three_layers_equals_per_layer_calls(ops):
         ref_dg[l], ref_dx[l] = r["dgates"].clone(), None if r["dx"] is None else r["dx"].clone()
         cur = r["dx"]
     specs = [{"stash": stashes[l], "w_hh": W[l][1], "w_ih": W[l][0] if l > 0 else None,
-              "dgates": torch.zeros(N, T, 4 * H, device=DEV), "dx": torch.zeros(N, T, H, device=DEV) if l > 0 else None} for l in (2, 1, 0)]
+              "dgates": ops.lstm_dgates(N, T, H, DEV), "dx": torch.zeros(N, T, H, device=DEV) if l > 0 else None} for l in (2, 1, 0)]
     ops.lstm_bwd_stack(specs, keep, dy=dy)
     torch.cuda.synchronize()
     for s, l in zip(specs, (2, 1, 0)):
         assert torch.equal(s["dgates"], ref_dg[l]), l
         if l > 0:
             assert torch.equal(s["dx"], ref_dx[l]), l
+
+
+@pytest.mark.parametrize("N,T,I", [(80, 19, 8), (33, 9, 256), (64, 12, 256), (5, 6, 6), (130, 7, 3)])
+def test_h256_gate_gradients_stored_once_equal_the_f32_rows_form(ops, N, T, I):
+    """h = 256 on the fp16-split arithmetic keeps the gate gradients ONCE, as the fp16 piece chunks the BPTT's recurrent product
+    consumes (+ one power-of-two scale per env and step; common.h DgPack, uav_lstm_dgates_bytes), and the weight-gradient pass
+    reads that form directly (csrc/wgrad_pc.hip: LDS-DMA + transposed fragment reads, the scales riding on h_prev / x).  Against the
+    round-4 form kept behind UAV_DEBUG_DG_F32 (f32 rows written as well, weight gradients through gemm_h3_tn8_kernel):
+    the recurrent results are the same bits (same pieces, same kernel), the unpacked gate gradients equal the f32 rows to the
+    pieces' 2^-22 of each row's largest magnitude, the weight gradients agree to f32 round-off of their largest element --
+    ragged env counts (rows past N are zero pieces with scale 0), narrow and hidden-wide inputs, restart masks."""
+    H = 256
+    g = torch.Generator().manual_seed(N * 7 + T)
+    mk = lambda *shape, s=0.1: (torch.randn(*shape, generator=g) * s).to(DEV)
+    keep = (torch.rand(N, T, generator=g) > 0.2).float().to(DEV)
+    x = mk(N, T, I, s=1.0)
+    w_ih, w_hh, b_ih, b_hh = mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)
+    h0, c0 = mk(N, H, s=0.3), mk(N, H, s=0.3)
+    y, _, _, stash = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
+    # gradients spanning many binades across envs: the per-(env, step) scales are what keeps the small rows' bits
+    dy = mk(N, T, H, s=1.0) * torch.logspace(-9, 0, N, device=DEV).view(N, 1, 1)
+    dheads = mk(N, T, 6, s=1.0)
+    need_dx = I == H
+    out = {}
+    for mode in ("packed", "rows"):
+        ops.set_debug_flags(*(("dg_f32",) if mode == "rows" else ()))
+        assert (ops.lstm_dgates_bytes(N, T, H, DEV) == N * T * 4 * H * 4) == (mode == "rows")
+        r = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=dy, dhn=mk(N, H) * 0, dcn=None, need_dx=need_dx, wgrad_dheads=dheads)
+        r["rows"] = ops.lstm_dgates_f32(r["dgates"], N, T, H)
+        torch.cuda.synchronize()
+        out[mode] = r
+    ops.set_debug_flags()
+    a, b = out["packed"], out["rows"]
+    for k in ("dh0", "dc0") + (("dx",) if need_dx else ()):
+        assert torch.equal(a[k], b[k]), k
+    rowmax = b["rows"].abs().amax(dim=2, keepdim=True)
+    assert ((a["rows"] - b["rows"]).abs() <= rowmax * 2.0 ** -21 + 1e-37).all()
+    assert torch.equal(a["dw_head"], b["dw_head"])
+    for k in ("db", "dw_hh", "dw_ih"):
+        want = b[k].double().cpu()
+        err = (a[k].double().cpu() - want).abs().max().item()
+        assert err <= 2e-6 * want.abs().max().item(), (k, err, want.abs().max().item())
 
 
 def test_lstm_bwd_stack_rejects_a_bad_layer_before_queueing_work(ops):
@@ -515,9 +557,9 @@ def test_lstm_bwd_stack_rejects_a_bad_layer_before_queueing_work(ops):
     dy = (torch.randn(N, T, H, generator=g) * 1e-4).to(DEV)
 
     def specs(bad):
-        return [{"stash": st1, "w_hh": W[1][1], "w_ih": None if bad else W[1][0], "dgates": torch.zeros(N, T, 4 * H, device=DEV),
+        return [{"stash": st1, "w_hh": W[1][1], "w_ih": None if bad else W[1][0], "dgates": ops.lstm_dgates(N, T, H, DEV),
                  "dx": None if bad else torch.zeros(N, T, H, device=DEV)},
-                {"stash": st0, "w_hh": W[0][1], "w_ih": None, "dgates": torch.zeros(N, T, 4 * H, device=DEV), "dx": None}]
+                {"stash": st0, "w_hh": W[0][1], "w_ih": None, "dgates": ops.lstm_dgates(N, T, H, DEV), "dx": None}]
     good = specs(False)
     ops.lstm_bwd_stack(good, None, dy=dy)
     torch.cuda.synchronize()

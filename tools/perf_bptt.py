@@ -23,7 +23,7 @@ stash = out["stash"] if isinstance(out, dict) else out[-1]
 dheads = r(N, T, 6) * 1e-3
 w_head = r(6, H) * 0.1
 dy = r(N, T, H) * 1e-3
-dgates = torch.empty(N, T, 4 * H, device=dev)
+dgates = ops.lstm_dgates(N, T, H, dev)
 dx = torch.empty(N, T, H, device=dev)
 
 

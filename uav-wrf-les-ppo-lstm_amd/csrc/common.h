@@ -126,6 +126,29 @@ __device__ __forceinline__ void split2h(float a, _Float16& p0, _Float16& p1) {
 }
 __device__ __forceinline__ unsigned short h_bits(_Float16 v) { return __builtin_bit_cast(unsigned short, v); }
 
+// ---- gate gradients of the h = 256 fp16-split step path, stored ONCE (round 5): the `dgates` buffer that travels from
+// uav_lstm_bwd / _bwd_stack to uav_lstm_wgrad holds what the BPTT's recurrent product consumes -- the two fp16 pieces of
+// every row, scaled per (env, step) by the power of two that puts the row's largest magnitude in [2^13, 2^14), in MFMA
+// fragment order (lstm_generic.hip: frag_index) -- and the weight-gradient pass reads THAT (wgrad_pc.hip) instead of a second,
+// f32 copy (8 of the 17 KB the gate-gradient kernel moved per env-step; -10 % of a C5 iteration by ablation,
+// profiles/r05_c5_no_f32_dgates_ablation.log).  Layout, time-major so that a step's block and the GEMM's K walk are linear:
+//   halves  pieces[t][rt][s][piece][512]      rt < RT = NP / 16 (16-env row tiles, NP = N rounded up to 64; rows >= N zero),
+//                                             s < NS = 4H / 32 (32 gate rows), 512 = (kq * 16 + env) * 8 + i, row 32 s + 8 kq + i
+//   floats  isc[t][NP]                        2^-e of (env, step): dG = (p0 + 2^-11 p1) * isc; 0 for rows >= N
+// The same byte count as f32 [N][T][4H] plus 4 bytes per (env, step): uav_lstm_dgates_bytes.
+struct DgPack {
+    static constexpr int H = 256, NS = 4 * H / 32;
+    int N, T, NP, RT;
+    __host__ __device__ DgPack(int n, int t) : N(n), T(t), NP((n + 63) / 64 * 64), RT(NP / 16) {}
+    __host__ __device__ size_t step_halves() const { return (size_t)RT * NS * 1024; }
+    __host__ __device__ size_t piece_bytes() const { return (size_t)T * step_halves() * 2; }
+    __host__ __device__ size_t bytes() const { return piece_bytes() + (size_t)T * NP * sizeof(float); }
+    __host__ __device__ unsigned short* pieces(void* base, int t) const { return (unsigned short*)base + (size_t)t * step_halves(); }
+    __host__ __device__ const unsigned short* pieces(const void* base, int t) const { return (const unsigned short*)base + (size_t)t * step_halves(); }
+    __host__ __device__ float* isc(void* base, int t) const { return (float*)((char*)base + piece_bytes()) + (size_t)t * NP; }
+    __host__ __device__ const float* isc(const void* base, int t) const { return (const float*)((const char*)base + piece_bytes()) + (size_t)t * NP; }
+};
+
 // ---- wave / block reductions (deterministic: fixed tree, no atomics) -------------------------
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

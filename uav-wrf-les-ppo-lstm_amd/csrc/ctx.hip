@@ -55,7 +55,8 @@ int uav_create(uav_ctx** out, int device, size_t ws_bytes) {
     c->comm_world = 0;
     // process-level override of the default arithmetic, read here once (never on a call path)
     c->lstm_arith = getenv("UAV_LSTM_F32_MFMA") ? UAV_ARITH_F32_MFMA : (getenv("UAV_LSTM_BF16X6") ? UAV_ARITH_BF16X6 : UAV_ARITH_FP16X3);
-    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u);
+    c->debug = (getenv("UAV_LSTM_STEP_F32") ? UAV_DEBUG_STEP_F32 : 0u) | (getenv("UAV_LSTM_X_F32") ? UAV_DEBUG_X_F32 : 0u) |
+               (getenv("UAV_LSTM_DG_F32") ? UAV_DEBUG_DG_F32 : 0u);
     if (hipMalloc(&c->ws, ws_bytes) != hipSuccess) {
         (void)hipFree(c->ws);
         delete c;
@@ -82,7 +83,7 @@ int uav_set_lstm_arith(uav_ctx* ctx, int mode) {
 int uav_get_lstm_arith(const uav_ctx* ctx) { return ctx ? ctx->lstm_arith : -1; }
 
 int uav_set_debug_flags(uav_ctx* ctx, unsigned flags) {
-    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_GEMM_TN_OFF)) == 0, "uav_set_debug_flags: bad argument");
+    UAV_REQUIRE(ctx && (flags & ~(UAV_DEBUG_STEP_F32 | UAV_DEBUG_X_F32 | UAV_DEBUG_DG_F32 | UAV_DEBUG_GEMM_TN_OFF)) == 0, "uav_set_debug_flags: bad argument");
     ctx->debug = flags;
     return 0;
 }

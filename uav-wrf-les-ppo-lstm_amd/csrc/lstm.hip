@@ -54,6 +54,10 @@ int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const 
                      const float* w_ih, int I, float* dx, hipStream_t st);
 int lstm_generic_bwd_caps(int I, int H);
 bool lstm_h3_stack_ok(int H);
+bool lstm_h3_dg_packed(int H);
+int lstm_pc_unpack(const void* dgates, int N, int T, float* out, hipStream_t st);
+int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* stash, const void* dgates, int N, int T, int I, float* dw_ih,
+                  float* dw_hh, float* db, float* db_hh, hipStream_t st);
 int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
                       const float* w_head, int n_heads, int N, int T, hipStream_t st);
 int lstm_wgrad_fused(uav_ctx* ctx, const float* dgates, const float* y_prev_src, const float* keep, const float* h0,
@@ -1566,6 +1570,21 @@ int uav_lstm_bwd_caps(uav_ctx* ctx, int I, int H) {
     return lstm_generic_bwd_caps(I, H);
 }
 
+size_t uav_lstm_dgates_bytes(uav_ctx* ctx, int N, int T, int H) {
+    if (!ctx || N <= 0 || T <= 0 || H <= 0) return 0;
+    uav_enter(ctx);
+    if (H == DgPack::H && lstm_h3_dg_packed(H)) return DgPack(N, T).bytes();
+    return (size_t)N * T * 4 * H * sizeof(float);
+}
+
+int uav_lstm_dgates_f32(uav_ctx* ctx, const float* dgates, int N, int T, int H, float* out, uav_stream stream) {
+    UAV_REQUIRE(ctx && dgates && out && N > 0 && T > 0 && H > 0, "uav_lstm_dgates_f32: bad argument");
+    uav_enter(ctx);
+    if (H == DgPack::H && lstm_h3_dg_packed(H)) return lstm_pc_unpack(dgates, N, T, out, as_stream(stream));
+    UAV_CHECK_HIP(hipMemcpyAsync(out, dgates, (size_t)N * T * 4 * H * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return 0;
+}
+
 int uav_lstm_bwd_stack(uav_ctx* ctx, int n_layers, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
                        const float* w_head, int n_heads, int N, int T, int H, uav_stream stream) {
     UAV_REQUIRE(ctx && layers, "uav_lstm_bwd_stack: NULL argument");
@@ -1617,26 +1636,46 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         float* red = (float*)((char*)ctx->ws + ctx->ws_bytes) - red_floats;
         uav_ctx sub = *ctx;
         sub.ws_bytes = ctx->ws_bytes - red_floats * sizeof(float);
+        // h = 256 on the fp16-split step path: `dgates` is the BPTT's piece chunks (common.h: DgPack), read as they are by
+        // wgrad_pc.hip -- db, dw_hh and dw_ih for a narrow (I <= 8) or hidden-wide (I = 256) input.  Any other request (another
+        // width, dx) first unpacks to f32 rows in the workspace and takes the products below.
+        bool done = false;
+        if (lstm_h3_dg_packed(H)) {
+            if ((I <= 8 || I == H) && !dx) {
+                if ((rc = lstm_pc_wgrad(ctx, x, stash, dgates, N, T, I, dw_ih, dw_hh, db, db_hh, st))) return rc;
+                done = true;
+            } else {
+                const size_t f32_bytes = (size_t)NT * 4 * H * sizeof(float);
+                UAV_REQUIRE(sub.ws_bytes >= f32_bytes + (64u << 20), "uav_lstm_wgrad (h=256, I=%d%s): needs %zu bytes of workspace for "
+                            "the gate gradients as f32 rows", I, dx ? ", dx" : "", f32_bytes + (64u << 20));
+                float* rows = (float*)((char*)sub.ws + sub.ws_bytes - f32_bytes);
+                sub.ws_bytes -= f32_bytes;
+                if ((rc = lstm_pc_unpack(dgates, N, T, rows, st))) return rc;
+                dgates = rows;
+            }
+        }
         // The large products go to the 16-bit matrix pipe as three fp16 piece products (gemm_h3.hip) unless exact f32 or
         // the bf16 split was asked for: dG is block-scaled by one power of two from its absolute maximum, which the bias
         // gradient's column-sum pass (it reads all of dG anyway) delivers; h_prev, x and W_ih are inside fp16's range
         // under the same preconditions as the sequence kernels' (include/uavppo.h, uav_set_lstm_arith).
         const bool h3 = !uav_want_f32_mfma() && !uav_want_bf16x6() && (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
         unsigned* amax = h3 ? reinterpret_cast<unsigned*>(red + (size_t)1024 * 9 * 4 * H) : nullptr;
-        // a narrow input (layer 1: obs + trend, I <= 8): dW_ih = dG^T x rides on the bias gradient's pass over dG
-        const bool narrow = I <= 8 && (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
-        if (narrow) rc = colsum_xw(&sub, dgates, NT, 4 * H, x, I, db, dw_ih, red, amax, st);
-        else rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st);
-        if (rc) return rc;
-        if (db_hh) UAV_CHECK_HIP(hipMemcpyAsync(db_hh, db, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
         auto product = [&](int64_t M, int64_t Nn, int64_t K, const float* A, int64_t sa_m, int64_t sa_k, const float* B,
                            int64_t sb_k, int64_t sb_n, float* C, int64_t ldc) {
             if (h3 && gemm_h3_ok(M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n))
                 return gemm_h3(&sub, M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, nullptr, 0, amax, st);
             return gemm_f32(&sub, M, Nn, K, A, sa_m, sa_k, B, sb_k, sb_n, C, ldc, nullptr, 0, st);
         };
-        if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H))) return rc;
-        if (!narrow && (rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
+        if (!done) {
+            // a narrow input (layer 1: obs + trend, I <= 8): dW_ih = dG^T x rides on the bias gradient's pass over dG
+            const bool narrow = I <= 8 && (reinterpret_cast<uintptr_t>(dgates) & 15) == 0;
+            if (narrow) rc = colsum_xw(&sub, dgates, NT, 4 * H, x, I, db, dw_ih, red, amax, st);
+            else rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st);
+            if (rc) return rc;
+            if (db_hh) UAV_CHECK_HIP(hipMemcpyAsync(db_hh, db, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H))) return rc;
+            if (!narrow && (rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
+        }
         if (dheads) {        // dW_head = dheads^T y [n_heads][H]: a stream over y with the few dheads columns riding along
             if (H % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
                 rc = colsum_xw(&sub, y, NT, H, dheads, n_heads, nullptr, dw_head, red, nullptr, st, 1);

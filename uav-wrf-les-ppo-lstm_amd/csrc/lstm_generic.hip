@@ -428,9 +428,10 @@ __global__ void add2v_kernel(const float* a0, const float* a1, float* b, int n) 
 }
 
 // Gate gradients of step t (gen_cell_bwd's arithmetic).  One WAVE per env (H = 256: lane l owns units 4 l .. 4 l + 3):
-// dgates f32 [n][t][4H] for the weight-gradient pass AND, for the recurrent product, the same row as two fp16 planes in MFMA
-// fragment order, scaled by the power of two that puts the row's largest magnitude in [2^13, 2^14) (gradients span dozens
-// of binades; scaled back exactly by step_bwd_h3_kernel).
+// the row as two fp16 planes in MFMA fragment order, scaled by the power of two that puts the row's largest magnitude in
+// [2^13, 2^14) (gradients span dozens of binades; scaled back exactly by step_bwd_h3_kernel) -- for the recurrent product AND,
+// kept for all steps (common.h: DgPack), for the weight-gradient pass.  dgates != NULL (UAV_DEBUG_DG_F32, the round-4 form kept
+// as an A/B switch): the pieces are one step's scratch and the weight-gradient pass gets f32 rows [n][t][4H] as well.
 // A workgroup = the 16 envs of one fragment row tile (16 waves): every wave parks its row's pieces in LDS and the workgroup
 // then writes the tile's 64 KB of piece chunks as ONE linear block -- lanes writing their own 8 bytes straight to the
 // fragment order scattered 16-byte segments over 32 lines per store, and the 16.8 MB of pieces cost 7.5 us of the step's
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
                                                           const float* __restrict__ w_head, int NH, int N, int T, int t,
                                                           const float* __restrict__ dh_rec, float* __restrict__ dc_next,
                                                           float* __restrict__ dgates, unsigned short* __restrict__ dgp,
-                                                          float* __restrict__ inv_scale) {
+                                                          float* __restrict__ inv_scale, float* __restrict__ isc_out) {
     static_assert(H == 256, "one wave per env: 64 lanes x 4 units");
     extern __shared__ __attribute__((aligned(16))) unsigned short cb_lds[];
     const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 6;
@@ -491,13 +492,11 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(g4[q][r]));
     }
-    float* gp = dgates + row * (4 * H) + u;
-#if CELL_ABL != 2 && CELL_ABL != 3
+    if (dgates) {
+        float* gp = dgates + row * (4 * H) + u;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(gp + q * H) = float4{g4[q][0], g4[q][1], g4[q][2], g4[q][3]};
-#else
-    if (m == 123.456f) gp[0] = g4[0][0];
-#endif
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(gp + q * H) = float4{g4[q][0], g4[q][1], g4[q][2], g4[q][3]};
+    }
     *reinterpret_cast<float4*>(dc_next + i) = float4{dcn[0], dcn[1], dcn[2], dcn[3]};
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -510,7 +509,7 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
     const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
     if (lane == 0) {
         inv_scale[n] = isc * kp;                            // dh_{t-1}: the mask of step t rides on the scale
-        inv_scale[(N + 63) / 64 * 64 + n] = isc;            // dx_t (the gradient of the step's input) is not masked
+        isc_out[n] = isc;                                   // dx_t (the gradient of the step's input) and dW are not masked
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -535,6 +534,7 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
             *reinterpret_cast<uint2*>(lp + (size_t)(16 * q) * CB_CH) = uint2{0u, 0u};
             *reinterpret_cast<uint2*>(lp + (size_t)(16 * q + 1) * CB_CH) = uint2{0u, 0u};
         }
+        if (lane == 0) isc_out[n] = 0.f;                    // (the grid covers whole 64-row tiles: n < NP)
     }
     __syncthreads();
 #if CELL_ABL != 1 && CELL_ABL != 3
@@ -556,7 +556,8 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
 template <int H, bool DX>
 __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* __restrict__ wtp,
                                                           const unsigned short* __restrict__ dgp,
-                                                          const float* __restrict__ inv_scale, int N,
+                                                          const float* __restrict__ inv_scale,
+                                                          const float* __restrict__ isc_t, int N,
                                                           float* __restrict__ dh, const unsigned short* __restrict__ wxtp,
                                                           float* __restrict__ dx, int T, int t) {
     // four waves, each TWO 16-unit row tiles x TWO 16-env column tiles of the 64 x 64 workgroup tile: 8 KB of fragments per
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* 
             const f32x4 v = (acc[r][c] + acl[r][c] * H3_LO) * is;
             *reinterpret_cast<float4*>(dh + (size_t)n * H + u0 + 16 * r + 4 * kq) = float4{v[0], v[1], v[2], v[3]};
             if (DX) {
-                const f32x4 vx = (xcc[r][c] + xcl[r][c] * H3_LO) * inv_scale[(N + 63) / 64 * 64 + n];
+                const f32x4 vx = (xcc[r][c] + xcl[r][c] * H3_LO) * isc_t[n];
                 *reinterpret_cast<float4*>(dx + ((size_t)n * T + t) * H + u0 + 16 * r + 4 * kq) = float4{vx[0], vx[1], vx[2], vx[3]};
             }
         }
@@ -827,29 +828,34 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
 
 }  // extern "C"
 
+// the gate gradients stay in the packed form only (common.h: DgPack) unless the A/B switch asks for the round-4 f32 rows too
+static bool h3_dg_packed(int H) { return h3_step_ok(H) && !uav_debug(UAV_DEBUG_DG_F32); }
+bool lstm_h3_dg_packed(int H) { return h3_dg_packed(H); }
+
 // One layer's BPTT on the step path: its slice of the workspace, the launches before the time loop, one time step, the end.
 struct H3Bwd {
     static constexpr int H = 256;
     const float *keep, *stash, *dy, *dheads, *w_head;
     int n_heads, N, T;
     float *dgates, *dx;
+    bool packed;
     float *dh, *dc, *inv_scale;
     unsigned short *dgp, *wtp, *wxtp;
-    // dh, dc f32 | dG pieces [2][N][4H] | inverse scales [masked | unmasked][N] | W_hh^T, W_ih^T pieces [2][H][4H] each
+    // dh, dc f32 | inverse scales [masked | unmasked][NP] | W_hh^T, W_ih^T pieces [2][H][4H] each | (f32-rows form only) one step's
+    // dG pieces [2][NP][4H]
     static size_t need(int N) {
-        const size_t NH = (size_t)N * H, NP = (size_t)(N + 63) / 64 * 64 * H;
-        return (2 * NH) * 4 + (2 * 4 * NP) * 2 + (size_t)((N + 63) / 64 * 64) * 4 * 2 + (size_t)2 * 2 * 4 * H * H * 2;
+        const size_t NH = (size_t)N * H, NP = (size_t)(N + 63) / 64 * 64;
+        return (2 * NH) * 4 + NP * 4 * 2 + (size_t)2 * 2 * 4 * H * H * 2 + (2 * 4 * NP * H) * 2;
     }
     int prepare(char* base, const float* w_hh, const float* w_ih, const float* dhn, const float* dcn, hipStream_t st) {
-        const int64_t NH = (int64_t)N * H, NP = (int64_t)(N + 63) / 64 * 64 * H;
+        const int64_t NH = (int64_t)N * H, NP = (int64_t)(N + 63) / 64 * 64;
         dh = (float*)base;
         dc = dh + NH;
-        dgp = (unsigned short*)(dc + NH);
-        inv_scale = (float*)(dgp + 2 * 4 * NP);
-        wtp = (unsigned short*)(inv_scale + 2 * ((N + 63) / 64 * 64));
+        inv_scale = dc + NH;
+        wtp = (unsigned short*)(inv_scale + 2 * NP);
         wxtp = wtp + (size_t)2 * 4 * H * H;
+        dgp = wxtp + (size_t)2 * 4 * H * H;
         const unsigned nb = (unsigned)((NH + 255) / 256);
-        UAV_CHECK_HIP(hipMemsetAsync(dgp, 0, (size_t)2 * 4 * NP * 2, st));
         hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_hh, 4 * H, H, H, 1, wtp);
         if (dx) hipLaunchKernelGGL(split_weights_kernel, dim3(4 * H * H / 256), dim3(256), 0, st, w_ih, 4 * H, H, H, 1, wxtp);
         hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dh, dhn, NH);
@@ -858,10 +864,14 @@ struct H3Bwd {
     }
     void step(int t, hipStream_t st) const {
         const dim3 grid((N + 63) / 64, H / 64);
-        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3((N + 15) / 16), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head,
-                           n_heads, N, T, t, dh, dc, dgates, dgp, inv_scale);
-        if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh, wxtp, dx, T, t);
-        else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, dgp, inv_scale, N, dh,
+        const DgPack P(N, T);
+        // the gate-gradient kernel's grid covers whole 64-env tiles: rows past N are written as zero pieces, scale 0
+        unsigned short* pc = packed ? P.pieces((void*)dgates, t) : dgp;
+        float* isc_t = packed ? P.isc((void*)dgates, t) : inv_scale + P.NP;
+        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3(P.RT), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head,
+                           n_heads, N, T, t, dh, dc, packed ? (float*)nullptr : dgates, pc, inv_scale, isc_t);
+        if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, pc, inv_scale, isc_t, N, dh, wxtp, dx, T, t);
+        else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, pc, inv_scale, isc_t, N, dh,
                                 (const unsigned short*)nullptr, (float*)nullptr, T, t);
     }
     void finish(float* dh0, float* dc0, hipStream_t st) const {
@@ -884,7 +894,7 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
     UAV_REQUIRE(need + (64u << 20) <= ctx->ws_bytes, "lstm (h=256): workspace too small");
     int rc;
     if ((rc = h3_bwd_attr())) return rc;
-    H3Bwd L{keep, stash, dy, dheads, w_head, n_heads, N, T, dgates, dx};
+    H3Bwd L{keep, stash, dy, dheads, w_head, n_heads, N, T, dgates, dx, h3_dg_packed(H3Bwd::H)};
     if ((rc = L.prepare((char*)ctx->ws + ctx->ws_bytes - need, w_hh, w_ih, dhn, dcn, st))) return rc;
     for (int t = T - 1; t >= 0; --t) L.step(t, st);
     L.finish(dh0, dc0, st);
@@ -930,7 +940,7 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
     for (int l = 0; l < nl; ++l) {
         const uav_lstm_bwd_layer& a = layers[l];
         L[l] = H3Bwd{a.keep, a.stash, l == 0 ? dy : layers[l - 1].dx, l == 0 ? dheads : nullptr, l == 0 ? w_head : nullptr,
-                     l == 0 ? n_heads : 0, N, T, a.dgates, a.dx};
+                     l == 0 ? n_heads : 0, N, T, a.dgates, a.dx, h3_dg_packed(H3Bwd::H)};
         if ((rc = L[l].prepare((char*)ctx->ws + ctx->ws_bytes - (size_t)(l + 1) * need, a.w_hh, a.w_ih, a.dhn, a.dcn, str[l]))) {
             (void)join();
             return rc;

@@ -75,6 +75,8 @@ SIGNATURES = {
     "uav_lstm_fwd": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, P, P, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd": (I32, [P, P, P, P, P, P, P, I32, P, P, I32, I32, I32, P, P, P, P, I32, P, P]),
     "uav_lstm_bwd_caps": (I32, [P, I32, I32]),
+    "uav_lstm_dgates_bytes": (SZ, [P, I32, I32, I32]),
+    "uav_lstm_dgates_f32": (I32, [P, P, I32, I32, I32, P, P]),
     "uav_lstm_bwd_stack": (I32, [P, I32, P, P, P, P, I32, I32, I32, I32, P]),
     "uav_lstm_wgrad": (I32, [P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P, P, P]),
     "uav_env_state_bytes": (SZ, [I32]),

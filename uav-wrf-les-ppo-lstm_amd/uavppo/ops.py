@@ -316,7 +316,7 @@ class lstm_arith:
         set_lstm_arith(self.prev, self.device)
 
 
-DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "gemm_tn_off": 0x10}
+DEBUG_FLAGS = {"step_f32": 1, "x_f32": 2, "dg_f32": 4, "gemm_tn_off": 0x10}
 
 
 def set_debug_flags(*names, device=None):
@@ -605,6 +605,39 @@ class LstmStepper:
                                           _p(self.cn), _stream()), "uav_lstm_stepper_step")
 
 
+def lstm_dgates_bytes(N, T, H, device):
+    """uav_lstm_dgates_bytes: size of the gate-gradient buffer uav_lstm_bwd / _bwd_stack hand to uav_lstm_wgrad under the device
+    handle's CURRENT arithmetic mode and debug flags."""
+    n = int(lib().uav_lstm_dgates_bytes(Context.get(torch.device(device)).handle, int(N), int(T), int(H)))
+    if n <= 0:
+        raise RuntimeError(f"uav_lstm_dgates_bytes({N}, {T}, {H}) = {n}")
+    return n
+
+
+def lstm_dgates(N, T, H, device):
+    """A gate-gradient buffer for lstm_bwd / lstm_bwd_stack / lstm_wgrad: f32 rows [N, T, 4H] -- except at h = 256 on the fp16-split
+    arithmetic, where the library keeps the BPTT's fp16 piece chunks + one scale per (env, step) instead of f32 rows and the
+    buffer is an opaque flat f32 tensor (lstm_dgates_f32 converts)."""
+    nbytes = lstm_dgates_bytes(N, T, H, device)
+    if nbytes == N * T * 4 * H * 4:
+        return torch.empty(N, T, 4 * H, dtype=F32, device=device)
+    return torch.empty((nbytes + 3) // 4, dtype=F32, device=device)
+
+
+def _pdg(dgates, N, T, H):
+    need = lstm_dgates_bytes(N, T, H, dgates.device)
+    if dgates.numel() * 4 < need:
+        raise RuntimeError(f"dgates: {dgates.numel() * 4} bytes, uav_lstm_dgates_bytes({N}, {T}, {H}) = {need} (allocate with ops.lstm_dgates)")
+    return _p(dgates, F32, None, "dgates")
+
+
+def lstm_dgates_f32(dgates, N, T, H):
+    """uav_lstm_dgates_f32: the gate gradients as f32 rows [N, T, 4H], whatever form the buffer holds them in."""
+    out = torch.empty(N, T, 4 * H, dtype=F32, device=dgates.device)
+    check(lib().uav_lstm_dgates_f32(_h(dgates), _pdg(dgates, N, T, H), N, T, H, _p(out), _stream()), "uav_lstm_dgates_f32")
+    return out
+
+
 def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):
     """The weight-gradient pass alone, from given gate gradients: dW_ih, dW_hh, db (and dW_head = dheads^T y)."""
     N, T, I = x.shape
@@ -617,7 +650,7 @@ def lstm_wgrad(x, keep, h0, y, stash, dgates, w_ih, dheads=None):
     dw_head = torch.empty(nh, H, dtype=F32, device=dev) if nh else None
     check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"), _p(h0, F32, (N, H), "h0"),
                                _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"),
-                               _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                               _pdg(dgates, N, T, H), _p(w_ih, F32, (4 * H, I), "w_ih"),
                                _p(dheads, F32, (N, T, nh), "dheads"), nh, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
                                _p(db, F32, (4 * H,), "db"), None, _p(dw_head, F32, (nh, H), "dw_head"), _p(None), _stream()),
@@ -633,7 +666,7 @@ def lstm_bwd_caps(device, I, H):
 
 def lstm_bwd_stack(layers, keep, dy=None, dheads=None, w_head=None):
     """uav_lstm_bwd_stack: the BPTTs of a stack of h = 256 layers as one pipelined call.  layers: top first, dicts with
-    stash [N,T,6H], w_hh, w_ih (None for the last), dgates [N,T,4H] (distinct per layer), dx [N,T,H] (None for the last)."""
+    stash [N,T,6H], w_hh, w_ih (None for the last), dgates (ops.lstm_dgates; distinct per layer), dx [N,T,H] (None for the last)."""
     N, T, H6 = layers[0]["stash"].shape
     H = H6 // 6
     arr = (_lib.LstmBwdLayer * len(layers))()
@@ -642,7 +675,7 @@ def lstm_bwd_stack(layers, keep, dy=None, dheads=None, w_head=None):
         a.stash = _p(d["stash"], F32, (N, T, 6 * H), "stash").value
         a.w_hh = _p(d["w_hh"], F32, (4 * H, H), "w_hh").value
         a.w_ih = None if d.get("w_ih") is None else _p(d["w_ih"], F32, (4 * H, H), "w_ih").value
-        a.dgates = _p(d["dgates"], F32, (N, T, 4 * H), "dgates").value
+        a.dgates = _pdg(d["dgates"], N, T, H).value
         a.dx = None if d.get("dx") is None else _p(d["dx"], F32, (N, T, H), "dx").value
         a.dhn = a.dcn = a.dh0 = a.dc0 = None
     nh = 0 if dheads is None else dheads.shape[-1]
@@ -664,7 +697,7 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     N, T, I = x.shape
     H = w_hh.shape[1]
     dev = x.device
-    dgates = torch.empty(N, T, 4 * H, dtype=F32, device=dev) if dgates is None else dgates
+    dgates = lstm_dgates(N, T, H, dev) if dgates is None else dgates
     dx = torch.empty(N, T, I, dtype=F32, device=dev) if (need_dx and not bwd_done) else None
     dw_ih = torch.empty(4 * H, I, dtype=F32, device=dev) if dw_ih is None else dw_ih
     dw_hh = torch.empty(4 * H, H, dtype=F32, device=dev) if dw_hh is None else dw_hh
@@ -685,7 +718,7 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
                                  _p(w_hh, F32, (4 * H, H), "w_hh"), _p(dy, F32, (N, T, H), "dy"),
                                  _p(dheads, F32, (N, T, nh), "dheads"), _p(w_head, F32, (nh, H), "w_head"), nh,
                                  _p(dhn, F32, (N, H), "dhn"), _p(dcn, F32, (N, H), "dcn"), N, T, H,
-                                 _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(dh0), _p(dc0),
+                                 _pdg(dgates, N, T, H), _p(dh0), _p(dc0),
                                  _p(w_ih, F32, (4 * H, I), "w_ih") if dx_in_bwd else None, I, _p(dx) if dx_in_bwd else None,
                                  _stream()), "uav_lstm_bwd")
     if _t is not None:
@@ -693,7 +726,7 @@ def lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=None, dheads=None, w_head=Non
     _t = KERNEL_TIMER.bracket("lstm_wgrad")
     check(lib().uav_lstm_wgrad(_h(x), _p(x, F32, (N, T, I), "x"), _p(keep, F32, (N, T), "keep"), _p(h0, F32, (N, H), "h0"),
                                _p(y, F32, (N, T, H), "y"), _p(stash, F32, (N, T, 6 * H), "stash"),
-                               _p(dgates, F32, (N, T, 4 * H), "dgates"), _p(w_ih, F32, (4 * H, I), "w_ih"),
+                               _pdg(dgates, N, T, H), _p(w_ih, F32, (4 * H, I), "w_ih"),
                                _p(wgrad_dheads, F32, (N, T, nhw), "dheads"), nhw, N, T, I, H,
                                _p(dw_ih, F32, (4 * H, I), "dw_ih"), _p(dw_hh, F32, (4 * H, H), "dw_hh"),
                                _p(db, F32, (4 * H,), "db"), _p(db_hh, F32, (4 * H,), "db_hh"), _p(dw_head, F32, (nhw, H), "dw_head"),

@@ -309,9 +309,10 @@ class LSTMActorCritic(_FlatPolicy):
             for l in reversed(range(L)):
                 x, stash, y, h0 = saved[l]
                 key = f"dgates{l}"
-                if work.get(key) is None or work[key].shape[0] != N:
-                    work[key] = work["dgates"] if (l == L - 1 and work.get("dgates") is not None and work["dgates"].shape[0] == N) \
-                        else torch.empty(N, T, 4 * H, dtype=torch.float32, device=dheads.device)
+                dg_bytes = ops.lstm_dgates_bytes(N, T, H, dheads.device)          # opaque at h = 256 (fp16 piece chunks)
+                if work.get(key) is None or work[key].numel() * 4 < dg_bytes:
+                    work[key] = work["dgates"] if (l == L - 1 and work.get("dgates") is not None and work["dgates"].numel() * 4 >= dg_bytes) \
+                        else ops.lstm_dgates(N, T, H, dheads.device)
                 if l > 0 and (work.get(f"dx{l}") is None or work[f"dx{l}"].shape[0] != N):
                     work[f"dx{l}"] = torch.empty(N, T, H, dtype=torch.float32, device=dheads.device)
                 specs.append({"stash": stash, "w_hh": v[f"lstm.weight_hh_l{l}"], "w_ih": v[f"lstm.weight_ih_l{l}"] if l > 0 else None,

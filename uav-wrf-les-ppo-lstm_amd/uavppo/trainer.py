@@ -188,7 +188,7 @@ class VecPPOTrainer:
             self.h, self.c = self._state[0], self._state[1]
             self.h0, self.c0 = self._state0[0], self._state0[1]
             nb = N // self.num_minibatches
-            self.work = {"dgates": torch.empty(nb, T, 4 * H, **f32), "heads": torch.empty(nb, T, 6, **f32)}   # heads: logits | value, written by the sequence kernels
+            self.work = {"dgates": ops.lstm_dgates(nb, T, H, self.device), "heads": torch.empty(nb, T, 6, **f32)}   # heads: logits | value, written by the sequence kernels
             for l in range(L):
                 self.work[f"stash{l}"] = torch.empty(nb, T, 6 * H, **f32)
                 self.work[f"y{l}"] = torch.empty(nb, T, H, **f32)
