@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel stats of one C5 bench run under rocprofv3 -> gpurun_out/prof_c5/ (run on the GPU box: gpurun -- 'bash tools/prof_c5.sh')
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/prof_c5
+OUT=$ROOT/gpurun_out/prof_c5${TAG:+_$TAG}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --config c5 --steps 2 --warmup 1 --no-strong-phase --no-cpu-baseline > $OUT/bench.json 2> $OUT/stats.log || exit 1

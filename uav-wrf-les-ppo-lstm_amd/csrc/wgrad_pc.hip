@@ -22,6 +22,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef PC_ABL
+#define PC_ABL 0        // ablation builds of gemm_pc_kernel only (tools/ab_wgrad_pc.sh; wrong results, same launches): 1 no MFMAs, 2 no B
+#endif                  // loads in the loop, 3 no DMA in the loop, 4 no split / piece writes
+
 namespace {
 
 constexpr int H = DgPack::H, NS = DgPack::NS, G4 = 4 * H;
@@ -128,14 +132,22 @@ __global__ __launch_bounds__(512) void colsum_pc_kernel(const unsigned short* __
     }
 }
 
-// partial [nb][1 + I][4H] -> db [4H] (and db2, the same values) and dw_ih [4H][I]; fixed association
+// partial [nb][1 + I][4H] -> db [4H] (and db2, the same values) and dw_ih [4H][I]; fixed association.  A block = 32 columns x 8
+// groups of partial blocks (thread (g, col) sums blocks g, g + 8, ...; the eight group sums are added in order through LDS):
+// one thread per column walked all 256 partial blocks one dependent load after the other, 96 us for 9,216 sums.
 __global__ __launch_bounds__(256) void colsum_pc_reduce_kernel(const float* __restrict__ partial, int nb, int I, float* __restrict__ db,
                                                                float* __restrict__ db2, float* __restrict__ dw_ih) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (1 + I) * G4) return;
+    __shared__ float sm[8][32];
+    const int col = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + col;                       // (1 + I) * 4H is a multiple of 32
     const int c = idx / G4, m = idx % G4;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[((size_t)b * (1 + I) + c) * G4 + m];
+    for (int b = g; b < nb; b += 8) s += partial[((size_t)b * (1 + I) + c) * G4 + m];
+    sm[g][col] = s;
+    __syncthreads();
+    if (g != 0) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += sm[k][col];
     if (c == 0) { db[m] = s; if (db2) db2[m] = s; }
     else dw_ih[(size_t)m * I + (c - 1)] = s;
 }
@@ -235,14 +247,15 @@ __global__ __launch_bounds__(512) void gemm_pc_kernel(const PcArgs a) {
     // gate rows 4 p .. 4 p + 3 of the 16-row tile; octet 2 (i & 1) + (p >> 1)
     const int tq = (lane & 15) >> 2, tp = lane & 3;
     const unsigned a_lo = (unsigned)((kq >> 1) * 8192 + (((tp >> 1) * 16 + ((8 * (kq & 1) + tq) ^ ((tp >> 1) << 2))) * 16) + 8 * (tp & 1));
-    const unsigned a_hi = a_lo ^ 64u;
-    auto a_frag = [&](const unsigned char* stage, int i, int piece) -> f16x8 {
-        const unsigned char* c = stage + (wm * 2 + (i >> 1)) * 2048 + piece * 1024 + (i & 1) * 512;
-        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(c + a_lo));
-        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(c + a_hi));
+    // (32-bit LDS addresses: one base register per read kind, the fragment's (row tile, piece) as an instruction offset)
+    auto a_frag = [&](unsigned stage_lo, unsigned stage_hi, int i, int piece) -> f16x8 {
+        const unsigned c = (unsigned)((i >> 1) * 2048 + piece * 1024 + (i & 1) * 512);
+        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4s*>(stage_lo + c));
+        const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4s*>(stage_hi + c));
         const v8s r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(f16x8, r);
     };
+    const unsigned a_rd0 = a_lds_base + a_lo + (unsigned)(wm * 4096);      // stage 0, this lane's `lo` read; stages are A_STAGE apart (bit 6 untouched)
 
     // ---- B: as gemm_h3_tn8_kernel (thread = 4 columns x 4 envs, dwordx4 along the row), the envs of a slab being rows
     // (32 j + k) T + t of the operand; a slab that reaches past N (ragged last tile) clamps per lane
@@ -303,40 +316,97 @@ __global__ __launch_bounds__(512) void gemm_pc_kernel(const PcArgs a) {
         }
 #define PC_MFMA(ACC, FA, FB) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(FA), "v"(FB))
 
-    // one slab: the DMA of slab sl + 2 goes out first; 4 column tiles x 12 MFMAs with a value pair of slab sl + 1 split after
-    // MFMAs 1, 3, 5 of tiles 0 .. 2 (8 pairs), B's loads of slab sl + 3 behind them; then the wait that covers the DMA of slab sl + 1
+    // One slab.  Its A fragments and the first column tile's B fragments are ALREADY in registers (read in the tail of the
+    // previous body).  The DMA of slab sl + 2 goes out first; column tiles 0 .. 2: 12 MFMAs each, a value pair of slab sl + 1 split
+    // after MFMAs 1, 3, 5 (8 pairs), B's loads of slab sl + 3 behind them; then the ONE barrier of the slab (behind it slab sl + 1's
+    // stage and piece planes are complete, and nobody reads slab sl's any more: the last tile's operands are in registers); the
+    // last column tile runs row-tile pair by row-tile pair and re-fills each fragment register with slab sl + 1's as it falls free,
+    // so the LDS latency of the next slab's first reads hides under this slab's last 12 MFMAs instead of in front of the first.
     Pos pa = pos_of(q0 + 2), pb = pos_of(q0 + 3);       // the DMA's next slab (sl + 2) and B's (sl + 3)
-    auto slab_body = [&](PcRegs& r, int buf, int sl) {
-        issue_dma(pa, (sl + 2) % A_STAGES);
-        const unsigned char* as = a_lds + (sl % A_STAGES) * A_STAGE;
-        const unsigned short* bp = b_lds + buf * (B_BUF / 2);
-        unsigned short* np = b_lds + (buf ^ 1) * (B_BUF / 2);
-        const unsigned short* b0p = bp + (wn * 64 + fi) * PKP + 8 * kq;
-        f16x8 a0[4], a1[4], bq[2][2];
+    f16x8 a0[4], a1[4], bq[2][2];
+    auto read_frags = [&](int stage, int buf) {
+        const unsigned as = a_rd0 + (unsigned)(stage * A_STAGE), ah = as ^ 64u;
+        const unsigned short* b0p = b_lds + buf * (B_BUF / 2) + (wn * 64 + fi) * PKP + 8 * kq;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { a0[i] = a_frag(as, i, 0); a1[i] = a_frag(as, i, 1); }
+        for (int i = 0; i < 4; ++i) { a0[i] = a_frag(as, ah, i, 0); a1[i] = a_frag(as, ah, i, 1); }
         bq[0][0] = *reinterpret_cast<const f16x8*>(b0p);
         bq[0][1] = *reinterpret_cast<const f16x8*>(b0p + B_PLANE);
+    };
+    auto slab_body = [&](PcRegs& r, int buf, int sl) {
+#if PC_ABL != 3
+        issue_dma(pa, (sl + 2) % A_STAGES);
+#endif
+        unsigned short* np = b_lds + (buf ^ 1) * (B_BUF / 2);
+        const unsigned short* b0p = b_lds + buf * (B_BUF / 2) + (wn * 64 + fi) * PKP + 8 * kq;
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            if (j + 1 < NTW) {
-                bq[(j + 1) & 1][0] = *reinterpret_cast<const f16x8*>(b0p + (j + 1) * 16 * PKP);
-                bq[(j + 1) & 1][1] = *reinterpret_cast<const f16x8*>(b0p + B_PLANE + (j + 1) * 16 * PKP);
-            }
+        for (int j = 0; j < NTW - 1; ++j) {
+            bq[(j + 1) & 1][0] = *reinterpret_cast<const f16x8*>(b0p + (j + 1) * 16 * PKP);
+            bq[(j + 1) & 1][1] = *reinterpret_cast<const f16x8*>(b0p + B_PLANE + (j + 1) * 16 * PKP);
 #pragma unroll
             for (int m = 0; m < 12; ++m) {
                 const int i = m & 3;
+#if PC_ABL != 1
                 if (m < 4) PC_MFMA(acc0[i][j], a0[i], bq[j & 1][0]);
                 else if (m < 8) PC_MFMA(acc1[i][j], a0[i], bq[j & 1][1]);
                 else PC_MFMA(acc1[i][j], a1[i], bq[j & 1][0]);
+#else
+                asm volatile("" :: "v"(a0[i]), "v"(a1[i]), "v"(bq[j & 1][0]), "v"(bq[j & 1][1]));
+#endif
+#if PC_ABL != 4
                 if (m < 6 && (m & 1) && 3 * j + (m >> 1) < 8) commit_pair(r, np, 3 * j + (m >> 1));
+#else
+                if (m == 0 && j == 0) asm volatile("" :: "v"(r.b[0]), "v"(r.b[1]), "v"(r.b[2]), "v"(r.b[3]), "v"(r.sc));
+#endif
+#if PC_ABL != 2
                 if (j == 2 && m >= 4 && (m & 1) == 0) load_b(r, pb, (m - 4) >> 1);          // m = 4, 6, 8, 10
-                if (j == 3 && m == 1) load_sc(r, pb, sl + 3 < nslab);
+#endif
                 if (m % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // vector-memory operations behind the DMA of slab sl + 1 (issued at the top of the previous body): 5 + 2 + 5
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        // vector-memory operations of this wave behind slab sl + 2's B loads and scales (previous body): this body's DMA (2) and
+        // four B loads -- with those six in flight, slab sl + 1's DMA (older still) has landed as well
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        lds_barrier();
+        {
+            constexpr int j = NTW - 1;
+            // (opaque to the optimiser: left alone it re-associates base + stage + offset, hoists one address register per
+            //  (stage-independent) fragment offset out of the loop and spills them)
+            unsigned as = a_rd0 + (unsigned)(((sl + 1) % A_STAGES) * A_STAGE), ah = as ^ 64u;
+            asm volatile("" : "+v"(as), "+v"(ah));
+            const unsigned short* n0p = np + (wn * 64 + fi) * PKP + 8 * kq;
+            bq[0][0] = *reinterpret_cast<const f16x8*>(n0p);                    // free since tile 2
+            bq[0][1] = *reinterpret_cast<const f16x8*>(n0p + B_PLANE);
+            // (the empty asm statements with a memory clobber pin the reads in the IR: the MFMA statements clobber nothing, and
+            //  the first body's reads -- whose uses are further down the same iteration -- were sunk behind all twelve of them)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i0 = 2 * h, i1 = 2 * h + 1;
+#if PC_ABL != 1
+                PC_MFMA(acc0[i0][j], a0[i0], bq[1][0]);
+                PC_MFMA(acc0[i1][j], a0[i1], bq[1][0]);
+                PC_MFMA(acc1[i0][j], a0[i0], bq[1][1]);
+                PC_MFMA(acc1[i1][j], a0[i1], bq[1][1]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                a0[i0] = a_frag(as, ah, i0, 0);
+                a0[i1] = a_frag(as, ah, i1, 0);
+#if PC_ABL != 2
+                if (h == 0) load_sc(r, pb, sl + 3 < nslab);
+#endif
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#if PC_ABL != 1
+                PC_MFMA(acc1[i0][j], a1[i0], bq[1][0]);
+                PC_MFMA(acc1[i1][j], a1[i1], bq[1][0]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                a1[i0] = a_frag(as, ah, i0, 1);
+                a1[i1] = a_frag(as, ah, i1, 1);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         advance(pa);
         advance(pb);
     };
@@ -359,13 +429,12 @@ __global__ __launch_bounds__(512) void gemm_pc_kernel(const PcArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
+    read_frags(0, 0);
     // iteration s: slab s out of B buffer s & 1 and A stage s % 3; slab s + 1's B into the other buffer from the register set
     // that then takes slab s + 3.  A rolled loop of two bodies; an odd count runs one slab of zeros.
     for (int s = 0; s < nslab; s += 2) {
         slab_body(r1, 0, s);
-        lds_barrier();
         slab_body(r0, 1, s + 1);
-        lds_barrier();
     }
 #undef PC_MFMA
     asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -442,7 +511,7 @@ int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* stash, const void* 
         default: PC_COLSUM(8); break;
     }
 #undef PC_COLSUM
-    hipLaunchKernelGGL(colsum_pc_reduce_kernel, dim3(((1 + CI) * G4 + 255) / 256), dim3(256), 0, st, partial, nbu, CI, db, db_hh, dw_ih);
+    hipLaunchKernelGGL(colsum_pc_reduce_kernel, dim3((1 + CI) * G4 / 32), dim3(256), 0, st, partial, nbu, CI, db, db_hh, dw_ih);
 
     PcArgs a;
     a.pieces = P.pieces(dgates, 0);
