@@ -530,6 +530,9 @@ def test_h256_gate_gradients_stored_once_equal_the_f32_rows_form(ops, N, T, I):
         r["rows"] = ops.lstm_dgates_f32(r["dgates"], N, T, H)
         torch.cuda.synchronize()
         out[mode] = r
+    # a buffer written in one form is refused by a weight-gradient call that would read the other (mode changed in between)
+    with pytest.raises(RuntimeError, match="must not change between"):
+        ops.lstm_wgrad(x, keep, h0, y, stash, out["packed"]["dgates"], w_ih)       # flags still say f32 rows
     ops.set_debug_flags()
     a, b = out["packed"], out["rows"]
     for k in ("dh0", "dc0") + (("dx",) if need_dx else ()):

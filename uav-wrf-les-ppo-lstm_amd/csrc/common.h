@@ -21,7 +21,22 @@ struct uav_ctx {
     hipEvent_t side_ev[8];    // fork / join + a small ring of per-step hand-off events per side stream
     void* comm;               // ncclComm_t of this process's rank (comm.hip: uav_comm_init), or NULL
     int comm_rank, comm_world;
+    // form of the last few gate-gradient buffers uav_lstm_bwd / _bwd_stack wrote (1 = fp16 piece chunks, 0 = f32 rows): uav_lstm_wgrad
+    // refuses a buffer whose recorded form is not the one the handle's CURRENT mode would read (mode changed in between)
+    struct { const void* p; int packed; } dg_form[8];
+    int dg_next;
 };
+static inline void uav_dg_record(uav_ctx* ctx, const void* p, int packed) {
+    for (auto& e : ctx->dg_form)
+        if (e.p == p) { e.packed = packed; return; }
+    ctx->dg_form[ctx->dg_next] = {p, packed};
+    ctx->dg_next = (ctx->dg_next + 1) % 8;
+}
+static inline int uav_dg_form(const uav_ctx* ctx, const void* p) {       // -1 = not recorded (a buffer filled by the caller)
+    for (auto& e : ctx->dg_form)
+        if (e.p == p) return e.packed;
+    return -1;
+}
 
 // arithmetic / debug switches of the call in flight on this thread (set from the handle by the LSTM entry points; the
 // launch helpers below them have no ctx argument).  No getenv on any call path: the UAV_LSTM_BF16X6 / UAV_LSTM_F32_MFMA

@@ -1580,7 +1580,8 @@ size_t uav_lstm_dgates_bytes(uav_ctx* ctx, int N, int T, int H) {
 int uav_lstm_dgates_f32(uav_ctx* ctx, const float* dgates, int N, int T, int H, float* out, uav_stream stream) {
     UAV_REQUIRE(ctx && dgates && out && N > 0 && T > 0 && H > 0, "uav_lstm_dgates_f32: bad argument");
     uav_enter(ctx);
-    if (H == DgPack::H && lstm_h3_dg_packed(H)) return lstm_pc_unpack(dgates, N, T, out, as_stream(stream));
+    const int form = H == DgPack::H ? uav_dg_form(ctx, dgates) : 0;          // as recorded by the call that wrote it, else by the mode
+    if (form > 0 || (form < 0 && H == DgPack::H && lstm_h3_dg_packed(H))) return lstm_pc_unpack(dgates, N, T, out, as_stream(stream));
     UAV_CHECK_HIP(hipMemcpyAsync(out, dgates, (size_t)N * T * 4 * H * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
     return 0;
 }
@@ -1640,6 +1641,12 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         // wgrad_pc.hip -- db, dw_hh and dw_ih for a narrow (I <= 8) or hidden-wide (I = 256) input.  Any other request (another
         // width, dx) first unpacks to f32 rows in the workspace and takes the products below.
         bool done = false;
+        {
+            const int form = uav_dg_form(ctx, dgates), want = lstm_h3_dg_packed(H) ? 1 : 0;
+            UAV_REQUIRE(form < 0 || H != DgPack::H || form == want, "uav_lstm_wgrad: this dgates buffer was written as %s but the handle's "
+                        "arithmetic mode / debug flags now read %s (they must not change between uav_lstm_bwd and uav_lstm_wgrad)",
+                        form ? "fp16 piece chunks" : "f32 rows", want ? "fp16 piece chunks" : "f32 rows");
+        }
         if (lstm_h3_dg_packed(H)) {
             if ((I <= 8 || I == H) && !dx) {
                 if ((rc = lstm_pc_wgrad(ctx, x, stash, dgates, N, T, I, dw_ih, dw_hh, db, db_hh, st))) return rc;

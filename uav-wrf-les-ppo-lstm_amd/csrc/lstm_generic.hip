@@ -895,6 +895,7 @@ static int lstm_h3_bwd(uav_ctx* ctx, const float* keep, const float* stash, cons
     int rc;
     if ((rc = h3_bwd_attr())) return rc;
     H3Bwd L{keep, stash, dy, dheads, w_head, n_heads, N, T, dgates, dx, h3_dg_packed(H3Bwd::H)};
+    uav_dg_record(ctx, dgates, L.packed);
     if ((rc = L.prepare((char*)ctx->ws + ctx->ws_bytes - need, w_hh, w_ih, dhn, dcn, st))) return rc;
     for (int t = T - 1; t >= 0; --t) L.step(t, st);
     L.finish(dh0, dc0, st);
@@ -941,6 +942,7 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
         const uav_lstm_bwd_layer& a = layers[l];
         L[l] = H3Bwd{a.keep, a.stash, l == 0 ? dy : layers[l - 1].dx, l == 0 ? dheads : nullptr, l == 0 ? w_head : nullptr,
                      l == 0 ? n_heads : 0, N, T, a.dgates, a.dx, h3_dg_packed(H3Bwd::H)};
+        uav_dg_record(ctx, a.dgates, L[l].packed);
         if ((rc = L[l].prepare((char*)ctx->ws + ctx->ws_bytes - (size_t)(l + 1) * need, a.w_hh, a.w_ih, a.dhn, a.dcn, str[l]))) {
             (void)join();
             return rc;
@@ -1001,6 +1003,7 @@ int lstm_generic_bwd(uav_ctx* ctx, const float* keep, const float* stash, const 
     if (h3_step_ok(H)) return lstm_h3_bwd(ctx, keep, stash, w_hh, dy, dheads, w_head, n_heads, dhn, dcn, N, T, dgates, dh0, dc0, w_ih, dx, st);
     const int64_t NH = (int64_t)N * H;
     UAV_REQUIRE((size_t)(2 * NH) * sizeof(float) + (64u << 20) <= ctx->ws_bytes, "lstm (generic): workspace too small");
+    uav_dg_record(ctx, dgates, 0);
     float* dh = (float*)((char*)ctx->ws + ctx->ws_bytes) - 2 * NH;
     float* dc = dh + NH;
     uav_ctx sub = *ctx;
