@@ -256,7 +256,10 @@ int uav_mlp_ppo_grad(uav_ctx* ctx, const float* params, const float* obs, const 
  * PPOV2.0/model.py:206-212, PPOV2.1/model.py:263).  One layer per call.
  * x [N][T][I], keep [N][T] (1 = carry the recurrent state into step t, 0 = restart from zero;
  * NULL = all ones), h0,c0 [N][H].  Outputs y [N][T][H], hn,cn [N][H] and, when stash != NULL,
- * the BPTT stash f32 [N][T][6H] = gates(i,f,g,o after activation) | c_prev | h_prev.
+ * the BPTT stash f32 [N][T][6H] = gates(i,f,g,o after activation) | c_prev | h_prev.  The h_prev slot [.., 5H:6H] is opaque scratch:
+ * it is written only where uav_lstm_wgrad reads h_prev from it (H other than 64 / 128 / 256, the wide-range arithmetic modes at
+ * H = 256, UAV_DEBUG_DG_F32); with I <= 6 at H = 64 / 128 and at H = 256 on the fp16-split arithmetic the weight gradients take
+ * h_prev[n][t] = y[n][t-1] keep[n][t] (h0 at t = 0) from y and the slot stays untouched.
  * w_ih [4H][I], w_hh [4H][H], b_ih,b_hh [4H].
  * heads != NULL: also heads [N][T][n_heads] = y W_head^T + b_head (the actor | critic Linear layers of
  * model.py:44,52 applied to the top layer; w_head [n_heads][H], b_head [n_heads], n_heads <= 8), computed inside

@@ -18,6 +18,14 @@ def ops():
     return o
 
 
+def _stash_equal(a, b):
+    """The BPTT stash rows [.., 6H] = gates i, f, g, o | c_prev | h_prev.  The h_prev slot is part of the contract only where the
+    weight-gradient pass reads it from there (the f32-rows forms); with I <= 6 at h = 64 / 128 and on the h = 256 fp16-split path
+    (h_prev = y one step back under the restart mask, csrc/wgrad_pc.hip) it is not written at all."""
+    H5 = a.shape[-1] // 6 * 5
+    return torch.equal(a[..., :H5], b[..., :H5])
+
+
 def _close(a, b, rtol=2e-4, atol=2e-5):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     scale = b.abs().max().item() + 1e-12
@@ -371,7 +379,7 @@ def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     y, stash = torch.zeros(N, T, H, device=DEV), torch.zeros(N, T, 6 * H, device=DEV)
     for t in range(T):
         sp.step(x, t, y, stash, keep=keep[:, t].contiguous())
-    assert torch.equal(y, y_ref) and torch.equal(stash, stash_ref)
+    assert torch.equal(y, y_ref) and _stash_equal(stash, stash_ref)
     assert torch.equal(sp.hn, hn_ref) and torch.equal(sp.cn, cn_ref)
     # a second rollout from the handed-over state: begin() again, some envs restarting at step 0
     sp.begin(w_ih, w_hh, b_ih, b_hh, hn_ref, cn_ref)
@@ -380,7 +388,7 @@ def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     keep2[:, 0] = k0
     y2_ref, _, _, st2_ref = ops.lstm_fwd(x, keep2, hn_ref, cn_ref, w_ih, w_hh, b_ih, b_hh)
     sp.step(x, 0, y, stash, keep=k0)
-    assert torch.equal(y[:, 0], y2_ref[:, 0]) and torch.equal(stash[:, 0], st2_ref[:, 0])
+    assert torch.equal(y[:, 0], y2_ref[:, 0]) and _stash_equal(stash[:, 0], st2_ref[:, 0])
 
 
 @pytest.mark.parametrize("mode", ["bf16x6", "f32_mfma"])
@@ -450,7 +458,7 @@ def test_lstm_stepper_two_layers_through_piece_planes(ops):
         y2f, _, _, st2f = ops.lstm_fwd(y1, keep, h0[1], c0[1], *W[1])
     finally:
         ops.set_debug_flags()
-    assert torch.equal(y2, y2f) and torch.equal(st2, st2f)
+    assert torch.equal(y2, y2f) and _stash_equal(st2, st2f)
     # stepped: both layers per time step, layer 2 fed from layer 1's piece planes
     sp = [ops.LstmStepper(N, I, H, DEV), ops.LstmStepper(N, H, H, DEV)]
     for l in range(2):
@@ -461,8 +469,8 @@ def test_lstm_stepper_two_layers_through_piece_planes(ops):
         kt = keep[:, t].contiguous()
         sp[0].step(x, t, ys[0], ss[0], keep=kt)
         sp[1].step(ys[0], t, ys[1], ss[1], below=sp[0], keep=kt)
-    assert torch.equal(ys[0], y1) and torch.equal(ss[0], st1)
-    assert torch.equal(ys[1], y2) and torch.equal(ss[1], st2)
+    assert torch.equal(ys[0], y1) and _stash_equal(ss[0], st1)
+    assert torch.equal(ys[1], y2) and _stash_equal(ss[1], st2)
     assert torch.equal(sp[1].hn, hn2) and torch.equal(sp[1].cn, cn2)
 
 
@@ -517,7 +525,6 @@ def test_h256_gate_gradients_stored_once_equal_the_f32_rows_form(ops, N, T, I):
     x = mk(N, T, I, s=1.0)
     w_ih, w_hh, b_ih, b_hh = mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)
     h0, c0 = mk(N, H, s=0.3), mk(N, H, s=0.3)
-    y, _, _, stash = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
     # gradients spanning many binades across envs: the per-(env, step) scales are what keeps the small rows' bits
     dy = mk(N, T, H, s=1.0) * torch.logspace(-9, 0, N, device=DEV).view(N, 1, 1)
     dheads = mk(N, T, 6, s=1.0)
@@ -525,6 +532,8 @@ def test_h256_gate_gradients_stored_once_equal_the_f32_rows_form(ops, N, T, I):
     out = {}
     for mode in ("packed", "rows"):
         ops.set_debug_flags(*(("dg_f32",) if mode == "rows" else ()))
+        # (the forward pass belongs to the mode too: only the f32-rows form writes -- and reads -- the stash's h_prev slot)
+        y, _, _, stash = ops.lstm_fwd(x, keep, h0, c0, w_ih, w_hh, b_ih, b_hh)
         assert (ops.lstm_dgates_bytes(N, T, H, DEV) == N * T * 4 * H * 4) == (mode == "rows")
         r = ops.lstm_bwd(x, keep, stash, w_ih, w_hh, y, h0, dy=dy, dhn=mk(N, H) * 0, dcn=None, need_dx=need_dx, wgrad_dheads=dheads)
         r["rows"] = ops.lstm_dgates_f32(r["dgates"], N, T, H)

@@ -12,7 +12,7 @@ def main():
     stash = torch.rand(N, T, 6 * H, device=dev) * 0.8 + 0.1
     dy = torch.randn(N, T, H, device=dev) * 1e-6
     w_hh = torch.randn(4 * H, H, device=dev) * 0.05
-    dg = torch.empty(N, T, 4 * H, device=dev)
+    dg = ops.lstm_dgates(N, T, H, dev)
     def run():
         check(lib().uav_lstm_bwd(ops._h(dy), None, ops._p(stash), ops._p(w_hh), ops._p(dy), None, None, 0, None, None, N, T, H,
                                  ops._p(dg), None, None, None, 0, None, ops._stream()), "uav_lstm_bwd")

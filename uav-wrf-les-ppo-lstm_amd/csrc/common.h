@@ -150,18 +150,23 @@ __device__ __forceinline__ unsigned short h_bits(_Float16 v) { return __builtin_
 //   halves  pieces[t][rt][s][piece][512]      rt < RT = NP / 16 (16-env row tiles, NP = N rounded up to 64; rows >= N zero),
 //                                             s < NS = 4H / 32 (32 gate rows), 512 = (kq * 16 + env) * 8 + i, row 32 s + 8 kq + i
 //   floats  isc[t][NP]                        2^-e of (env, step): dG = (p0 + 2^-11 p1) * isc; 0 for rows >= N
-// The same byte count as f32 [N][T][4H] plus 4 bytes per (env, step): uav_lstm_dgates_bytes.
+//   floats  iscm[t][NP]                       isc * keep[env][step]: the scale under which dW_hh = dG^T h_prev takes h_prev[n][t] = y[n][t-1]
+//                                             * keep[n][t] straight from the layer's output y (h0 at t = 0) -- the forward pass then
+//                                             need not write an h_prev slot into the stash at all
+// The same byte count as f32 [N][T][4H] plus 8 bytes per (env, step): uav_lstm_dgates_bytes.
 struct DgPack {
     static constexpr int H = 256, NS = 4 * H / 32;
     int N, T, NP, RT;
     __host__ __device__ DgPack(int n, int t) : N(n), T(t), NP((n + 63) / 64 * 64), RT(NP / 16) {}
     __host__ __device__ size_t step_halves() const { return (size_t)RT * NS * 1024; }
     __host__ __device__ size_t piece_bytes() const { return (size_t)T * step_halves() * 2; }
-    __host__ __device__ size_t bytes() const { return piece_bytes() + (size_t)T * NP * sizeof(float); }
+    __host__ __device__ size_t bytes() const { return piece_bytes() + 2 * (size_t)T * NP * sizeof(float); }
     __host__ __device__ unsigned short* pieces(void* base, int t) const { return (unsigned short*)base + (size_t)t * step_halves(); }
     __host__ __device__ const unsigned short* pieces(const void* base, int t) const { return (const unsigned short*)base + (size_t)t * step_halves(); }
     __host__ __device__ float* isc(void* base, int t) const { return (float*)((char*)base + piece_bytes()) + (size_t)t * NP; }
     __host__ __device__ const float* isc(const void* base, int t) const { return (const float*)((const char*)base + piece_bytes()) + (size_t)t * NP; }
+    __host__ __device__ float* iscm(void* base, int t) const { return isc(base, T) + (size_t)t * NP; }
+    __host__ __device__ const float* iscm(const void* base, int t) const { return isc(base, T) + (size_t)t * NP; }
 };
 
 // ---- wave / block reductions (deterministic: fixed tree, no atomics) -------------------------

@@ -56,7 +56,8 @@ int lstm_generic_bwd_caps(int I, int H);
 bool lstm_h3_stack_ok(int H);
 bool lstm_h3_dg_packed(int H);
 int lstm_pc_unpack(const void* dgates, int N, int T, float* out, hipStream_t st);
-int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* stash, const void* dgates, int N, int T, int I, float* dw_ih,
+int lstm_pc_hprev_rows(const float* y, const float* keep, const float* h0, int N, int T, float* out, hipStream_t st);
+int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* y, const float* h0, const void* dgates, int N, int T, int I, float* dw_ih,
                   float* dw_hh, float* db, float* db_hh, hipStream_t st);
 int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, const float* dy, const float* dheads,
                       const float* w_head, int n_heads, int N, int T, hipStream_t st);
@@ -1641,6 +1642,8 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         // wgrad_pc.hip -- db, dw_hh and dw_ih for a narrow (I <= 8) or hidden-wide (I = 256) input.  Any other request (another
         // width, dx) first unpacks to f32 rows in the workspace and takes the products below.
         bool done = false;
+        const float* hprev = stash + 5 * H;                 // rows of h_prev: the stash's slot, stride 6H
+        int64_t ld_hprev = 6 * H;
         {
             const int form = uav_dg_form(ctx, dgates), want = lstm_h3_dg_packed(H) ? 1 : 0;
             UAV_REQUIRE(form < 0 || H != DgPack::H || form == want, "uav_lstm_wgrad: this dgates buffer was written as %s but the handle's "
@@ -1649,16 +1652,20 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
         }
         if (lstm_h3_dg_packed(H)) {
             if ((I <= 8 || I == H) && !dx) {
-                if ((rc = lstm_pc_wgrad(ctx, x, stash, dgates, N, T, I, dw_ih, dw_hh, db, db_hh, st))) return rc;
+                if ((rc = lstm_pc_wgrad(ctx, x, y, h0, dgates, N, T, I, dw_ih, dw_hh, db, db_hh, st))) return rc;
                 done = true;
             } else {
-                const size_t f32_bytes = (size_t)NT * 4 * H * sizeof(float);
+                const size_t f32_bytes = (size_t)NT * 5 * H * sizeof(float);       // gate gradients 4H + h_prev H (this mode's forward
                 UAV_REQUIRE(sub.ws_bytes >= f32_bytes + (64u << 20), "uav_lstm_wgrad (h=256, I=%d%s): needs %zu bytes of workspace for "
-                            "the gate gradients as f32 rows", I, dx ? ", dx" : "", f32_bytes + (64u << 20));
+                            "the gate gradients and h_prev as f32 rows", I, dx ? ", dx" : "", f32_bytes + (64u << 20));   // writes no slot)
                 float* rows = (float*)((char*)sub.ws + sub.ws_bytes - f32_bytes);
                 sub.ws_bytes -= f32_bytes;
                 if ((rc = lstm_pc_unpack(dgates, N, T, rows, st))) return rc;
+                float* hp = rows + (size_t)NT * 4 * H;
+                if ((rc = lstm_pc_hprev_rows(y, keep, h0, N, T, hp, st))) return rc;
                 dgates = rows;
+                hprev = hp;
+                ld_hprev = H;
             }
         }
         // The large products go to the 16-bit matrix pipe as three fp16 piece products (gemm_h3.hip) unless exact f32 or
@@ -1680,7 +1687,7 @@ int uav_lstm_wgrad(uav_ctx* ctx, const float* x, const float* keep, const float*
             else rc = colsum_absmax(&sub, dgates, NT, 4 * H, db, red, amax, st);
             if (rc) return rc;
             if (db_hh) UAV_CHECK_HIP(hipMemcpyAsync(db_hh, db, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
-            if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, stash + 5 * H, 6 * H, 1, dw_hh, H))) return rc;
+            if ((rc = product(4 * H, H, NT, dgates, 1, 4 * H, hprev, ld_hprev, 1, dw_hh, H))) return rc;
             if (!narrow && (rc = product(4 * H, I, NT, dgates, 1, 4 * H, x, I, 1, dw_ih, I))) return rc;
         }
         if (dheads) {        // dW_head = dheads^T y [n_heads][H]: a stream over y with the few dheads columns riding along

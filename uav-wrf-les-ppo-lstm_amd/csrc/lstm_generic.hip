@@ -19,8 +19,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CELL_ABL 0      // ablation builds of cell_bwd_h3_kernel only (tools/ab_step_fwd.sh): 1 no piece stores, 2 no f32 dG stores, 3 neither
 #endif
 #ifndef STEP_ABL
-#define STEP_ABL 0      // ablation builds of step_fwd_h3_kernel only (tools/ab_step_fwd.sh): 1 no MFMAs, 2 no recurrent loads, 3 no epilogue
-#endif
+#define STEP_ABL 0      // ablation builds of the step kernels only (tools/ab_step_fwd.sh): step_fwd_h3_kernel 1 no MFMAs, 2 no recurrent loads,
+#endif                  // 3 no epilogue, 4 each wave loads ONE of the four B column tiles (what sharing B through LDS would leave on the L1
+                        // path); 5 step_bwd_h3_kernel: each wave loads one of its two A and one of its two B tiles (the same question)
 
 int gemm_f32(uav_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_m, int64_t sa_k,
              const float* B, int64_t sb_k, int64_t sb_n, float* C, int64_t ldc, const float* bias,
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
                                                           const float* __restrict__ keep, int64_t keep_sn, int64_t keep_off,
                                                           int N, int T, int t,
                                                           float* __restrict__ y, float* __restrict__ hn,
-                                                          float* __restrict__ cn) {
+                                                          float* __restrict__ cn, int hslot) {
     constexpr int NS = H / 32, NC = 4;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar bases
     const unsigned lo = lane * 8;                      // this lane's 16 bytes of a 1 KB fragment chunk
@@ -248,6 +249,9 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
             }
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
+#if STEP_ABL == 4
+                if (c != w) continue;
+#endif
                 const unsigned short* p = rec ? bp[c] : bxp[c];
                 b[buf][c][0] = ldh8(p + (1024 * q + lo));
                 b[buf][c][1] = ldh8(p + (1024 * q + 512 + lo));
@@ -285,7 +289,12 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
 #pragma unroll
             for (int g = 0; g < 4; ++g) { a[buf][g][0] = ldh8(ap[g] + (1024 * s + lo)); a[buf][g][1] = ldh8(ap[g] + (1024 * s + 512 + lo)); }
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo)); }
+            for (int c = 0; c < NC; ++c) {
+#if STEP_ABL == 4
+                if (c != w) continue;
+#endif
+                b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo));
+            }
         };
 #pragma unroll
         for (int d = 0; d < DEPTH - 1; ++d) fetch(d, d);
@@ -370,8 +379,11 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
         // the state entering step t: from (hs, cs) at t = 0, afterwards from this row's own c_prev | h_prev slots, where
         // step t - 1 left it (the state travels through the stash rows the BPTT needs anyway: no separate f32 state
         // array is written and read back on every step)
+        // (hslot = 0: the h_prev slot of the stash is neither read nor written -- the weight gradients then take h_prev from y,
+        //  DgPack's iscm; 2 of the 10 KB a step moves per env and layer)
         float4 cp4 = *reinterpret_cast<const float4*>(t == 0 ? cs + i0 : sp + 4 * H);
-        float4 hp4 = *reinterpret_cast<const float4*>(t == 0 ? hs + i0 : sp + 5 * H);
+        float4 hp4 = float4{0.f, 0.f, 0.f, 0.f};
+        if (hslot) hp4 = *reinterpret_cast<const float4*>(t == 0 ? hs + i0 : sp + 5 * H);
         const float kc = kin[c];
         cp4.x *= kc; cp4.y *= kc; cp4.z *= kc; cp4.w *= kc;
         hp4.x *= kc; hp4.y *= kc; hp4.z *= kc; hp4.w *= kc;
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
         *reinterpret_cast<float4*>(sp + 3 * H) = float4{go[0], go[1], go[2], go[3]};
         if (t == 0 || kc == 0.f) {                  // the row holds the MASKED state (what the BPTT and dW_hh read): step t - 1
             *reinterpret_cast<float4*>(sp + 4 * H) = cp4;   // left it unmasked, so a restarted env's slots are rewritten (rare)
-            *reinterpret_cast<float4*>(sp + 5 * H) = hp4;
+            if (hslot) *reinterpret_cast<float4*>(sp + 5 * H) = hp4;
         }
         *reinterpret_cast<float4*>(y + row * H + u0 + 4 * kq) = float4{hh[0], hh[1], hh[2], hh[3]};
         if (t == T - 1) {
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
             }
             if (t < T - 1) {                           // state (unmasked: step t + 1 applies its own mask) -> the next row's c_prev | h_prev slots
                 *reinterpret_cast<float4*>(sp + 6 * H + 4 * H) = float4{cc[0], cc[1], cc[2], cc[3]};
-                *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hh[0], hh[1], hh[2], hh[3]};
+                if (hslot) *reinterpret_cast<float4*>(sp + 6 * H + 5 * H) = float4{hh[0], hh[1], hh[2], hh[3]};
             }
             uint2 v0, v1;
             v0.x = (unsigned)q0[0] | ((unsigned)q0[1] << 16); v0.y = (unsigned)q0[2] | ((unsigned)q0[3] << 16);
@@ -445,7 +457,8 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
                                                           const float* __restrict__ w_head, int NH, int N, int T, int t,
                                                           const float* __restrict__ dh_rec, float* __restrict__ dc_next,
                                                           float* __restrict__ dgates, unsigned short* __restrict__ dgp,
-                                                          float* __restrict__ inv_scale, float* __restrict__ isc_out) {
+                                                          float* __restrict__ inv_scale, float* __restrict__ isc_out,
+                                                          float* __restrict__ iscm_out) {
     static_assert(H == 256, "one wave per env: 64 lanes x 4 units");
     extern __shared__ __attribute__((aligned(16))) unsigned short cb_lds[];
     const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 6;
@@ -509,7 +522,8 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
     const float sc = __uint_as_float((unsigned)(127 + e) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
     if (lane == 0) {
         inv_scale[n] = isc * kp;                            // dh_{t-1}: the mask of step t rides on the scale
-        isc_out[n] = isc;                                   // dx_t (the gradient of the step's input) and dW are not masked
+        isc_out[n] = isc;                                   // dx_t (the gradient of the step's input), db and dW_ih are not masked
+        if (iscm_out) iscm_out[n] = isc * kp;               // dW_hh = dG^T (y[t-1] keep[t])
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -534,7 +548,10 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
             *reinterpret_cast<uint2*>(lp + (size_t)(16 * q) * CB_CH) = uint2{0u, 0u};
             *reinterpret_cast<uint2*>(lp + (size_t)(16 * q + 1) * CB_CH) = uint2{0u, 0u};
         }
-        if (lane == 0) isc_out[n] = 0.f;                    // (the grid covers whole 64-row tiles: n < NP)
+        if (lane == 0) {                                    // (the grid covers whole 64-row tiles: n < NP)
+            isc_out[n] = 0.f;
+            if (iscm_out) iscm_out[n] = 0.f;
+        }
     }
     __syncthreads();
 #if CELL_ABL != 1 && CELL_ABL != 3
@@ -586,13 +603,28 @@ __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* 
     f16x8 a[DEPTH][NR][2], ax[DX ? DEPTH : 1][NR][2], b[DEPTH][NC][2];
     auto fetch = [&](int s, int buf) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { a[buf][r][0] = ldh8(ap[r] + (1024 * s + lo)); a[buf][r][1] = ldh8(ap[r] + (1024 * s + 512 + lo)); }
+        for (int r = 0; r < NR; ++r) {
+#if STEP_ABL == 5
+            if (r != (w >> 1)) continue;
+#endif
+            a[buf][r][0] = ldh8(ap[r] + (1024 * s + lo)); a[buf][r][1] = ldh8(ap[r] + (1024 * s + 512 + lo));
+        }
         if (DX) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) { ax[buf][r][0] = ldh8(axp[r] + (1024 * s + lo)); ax[buf][r][1] = ldh8(axp[r] + (1024 * s + 512 + lo)); }
+            for (int r = 0; r < NR; ++r) {
+#if STEP_ABL == 5
+                if (r != (w >> 1)) continue;
+#endif
+                ax[buf][r][0] = ldh8(axp[r] + (1024 * s + lo)); ax[buf][r][1] = ldh8(axp[r] + (1024 * s + 512 + lo));
+            }
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo)); }
+        for (int c = 0; c < NC; ++c) {
+#if STEP_ABL == 5
+            if (c != (w & 1)) continue;
+#endif
+            b[buf][c][0] = ldh8(bp[c] + (1024 * s + lo)); b[buf][c][1] = ldh8(bp[c] + (1024 * s + 512 + lo));
+        }
     };
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) fetch(d, d);
@@ -668,6 +700,10 @@ static bool h3_step_ok(int H) {
     return H == 256 && !uav_want_f32_mfma() && !uav_want_bf16x6() && !uav_debug(UAV_DEBUG_STEP_F32);
 }
 
+// the gate gradients stay in the packed form only (common.h: DgPack) unless the A/B switch asks for the round-4 f32 rows too
+static bool h3_dg_packed(int H) { return h3_step_ok(H) && !uav_debug(UAV_DEBUG_DG_F32); }
+bool lstm_h3_dg_packed(int H) { return h3_dg_packed(H); }
+
 // fp16-split step path of uav_lstm_fwd for h = 256 (input projection included: the caller does NOT pre-fill the stash)
 int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const float* b_ih, const float* b_hh,
                 const float* keep, const float* h0, const float* c0, const float* w_hh, int N, int T, float* y, float* hn,
@@ -697,6 +733,7 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
     hipLaunchKernelGGL(add2v_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, b_ih, b_hh, bsum, 4 * H);
     hipLaunchKernelGGL(h3_init_state, dim3(nb), dim3(256), 0, st, h0, c0, keep, N, T, H, hs, cs, hp0);
     const dim3 grid((N + 63) / 64, H / 64);
+    const int hslot = h3_dg_packed(H) ? 0 : 1;              // the stash's h_prev slot is only read by the f32-rows weight gradients
     // a wide input (the layer below's output, I = 64 .. 256): x is converted to piece planes a chunk of time steps at a
     // time (split_x_kernel, in front of the state in the workspace), so the step kernel's input projection streams
     // 1 KB fragment chunks like its recurrent product instead of gathering f32 rows and splitting them in every workgroup
@@ -721,7 +758,7 @@ int lstm_h3_fwd(uav_ctx* ctx, const float* x, int I, const float* w_ih, const fl
         }
 #define LAUNCH_STEP(IPS_)                                                                                                    \
     hipLaunchKernelGGL((step_fwd_h3_kernel<H, IPS_>), grid, dim3(256), 0, st, wxp, wp, bsum, x, I, xp, 0, (t & 1) ? hp1 : hp0, \
-                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep, (int64_t)T, (int64_t)t, N, T, t, y, hn, cn)
+                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep, (int64_t)T, (int64_t)t, N, T, t, y, hn, cn, hslot)
         switch (IP / 32) {
             case 1: LAUNCH_STEP(1); break;
             case 2: LAUNCH_STEP(2); break;
@@ -804,6 +841,7 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
     float* hs = (float*)(b + L.hs);
     float* cs = (float*)(b + L.cs);
     const dim3 grid((N + 63) / 64, 256 / 64);
+    const int hslot = h3_dg_packed(H) ? 0 : 1;
     // `below`: the stepper state of the layer below (same N, its H = this I = 256), already stepped to t: its piece
     // planes of h_t (parity (t + 1) & 1, not yet masked) ARE this layer's input in fragment order
     const unsigned short* xp = nullptr;
@@ -814,7 +852,7 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
     }
 #define LAUNCH_STEP(IPS_)                                                                                                     \
     hipLaunchKernelGGL((step_fwd_h3_kernel<256, IPS_>), grid, dim3(256), 0, st, wxp, wp, bsum, x, I, xp, 1, (t & 1) ? hp1 : hp0, \
-                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep_t, (int64_t)1, (int64_t)0, N, T, t, y, hn, cn)
+                       (t & 1) ? hp0 : hp1, hs, cs, stash, keep_t, (int64_t)1, (int64_t)0, N, T, t, y, hn, cn, hslot)
     switch (L.IP / 32) {
         case 1: LAUNCH_STEP(1); break;
         case 2: LAUNCH_STEP(2); break;
@@ -828,9 +866,6 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
 
 }  // extern "C"
 
-// the gate gradients stay in the packed form only (common.h: DgPack) unless the A/B switch asks for the round-4 f32 rows too
-static bool h3_dg_packed(int H) { return h3_step_ok(H) && !uav_debug(UAV_DEBUG_DG_F32); }
-bool lstm_h3_dg_packed(int H) { return h3_dg_packed(H); }
 
 // One layer's BPTT on the step path: its slice of the workspace, the launches before the time loop, one time step, the end.
 struct H3Bwd {
@@ -869,7 +904,8 @@ struct H3Bwd {
         unsigned short* pc = packed ? P.pieces((void*)dgates, t) : dgp;
         float* isc_t = packed ? P.isc((void*)dgates, t) : inv_scale + P.NP;
         hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3(P.RT), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head,
-                           n_heads, N, T, t, dh, dc, packed ? (float*)nullptr : dgates, pc, inv_scale, isc_t);
+                           n_heads, N, T, t, dh, dc, packed ? (float*)nullptr : dgates, pc, inv_scale, isc_t,
+                           packed ? P.iscm((void*)dgates, t) : (float*)nullptr);
         if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, pc, inv_scale, isc_t, N, dh, wxtp, dx, T, t);
         else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, pc, inv_scale, isc_t, N, dh,
                                 (const unsigned short*)nullptr, (float*)nullptr, T, t);

@@ -6,7 +6,9 @@
 //                       HBM-bound pass, 1 KB chunk per wave load.
 //   gemm_pc_kernel      dW = dG^T [h_prev | x]  as three fp16 piece products (gemm_h3.hip's arithmetic, tile and wave layout):
 //                       * K = (env, step) walks 32-env slabs (two 16-env row tiles) with the step index innermost, so a workgroup's
-//                         B rows advance by one row per slab and A comes in two 8 KB runs;
+//                         B rows advance by one row per slab and A comes in two 8 KB runs; the h_prev operand is read as rows of the
+//                         layer's OUTPUT y one step back (h0 at step 0) with the restart mask folded into its scales (iscm), so the
+//                         forward pass writes no h_prev slot into the stash;
 //                       * A = the piece chunks AS STORED: LDS-DMA (global_load_lds_dwordx4, no registers, no VALU), one 1 KB chunk
 //                         per wave instruction, the 16-byte granules permuted through the per-lane GLOBAL address so that the
 //                         transposed fragment reads (ds_read_b64_tr_b16: the chunks hold [env][gate row], the product sums over
@@ -173,8 +175,10 @@ struct PcArgs {
     const float* isc;
     const unsigned* iscmax_bits;
     int N, T, NP, RT, SPT;             // SPT = NP / 32 slabs per step
-    const float* B0; int64_t ldb0;     // columns [0, n_split): row (env, t) at B0 + (env T + t) ldb0
-    const float* B1; int64_t ldb1;     // columns [n_split, Ntot)
+    const float* iscm;                 // isc * keep: the scales of the h_prev columns
+    const float* y; const float* h0;   // columns [0, n_split): h_prev row (env, t) = y + (env T + t - 1) H for t > 0, h0 + env H at t = 0
+                                       // (unmasked: keep[env][t] rides on iscm)
+    const float* B1; int64_t ldb1;     // columns [n_split, Ntot): row (env, t) at B1 + (env T + t) ldb1
     int n_split, Ntot;
     float* slabs;                      // [S][4H][Ntot]
     int64_t sps, total;                // slabs per split, all slabs (SPT * T)
@@ -207,8 +211,10 @@ __global__ __launch_bounds__(512) void gemm_pc_kernel(const PcArgs a) {
     const int T = a.T;
     const int n0 = ni * PN;
     const bool second = n0 >= a.n_split;
-    const float* Bp = second ? a.B1 + (n0 - a.n_split) : a.B0 + n0;
-    const int64_t ldb = second ? a.ldb1 : a.ldb0;
+    const float* Bp = second ? a.B1 + (n0 - a.n_split) : a.y + n0;
+    const float* Hp = a.h0 + n0;                                            // (first operand only)
+    const int64_t ldb = second ? a.ldb1 : (int64_t)H;
+    const float* sc_arr = second ? a.isc : a.iscm;
     const float iscmax = __uint_as_float(*a.iscmax_bits);
     const float to_block = 1.0f / iscmax;                                   // a power of two: exact
 
@@ -262,21 +268,24 @@ __global__ __launch_bounds__(512) void gemm_pc_kernel(const PcArgs a) {
     const int brg = (lane & 7) | ((lane >> 4) & 3) << 3 | (w & 1) << 5;       // columns 4 brg .. (64 groups)
     const int bkl = (lane >> 3) & 1, bkg = bkl | (w >> 1) << 1;              // envs 4 bkg .. (8 groups)
     const unsigned obb = (unsigned)(((int64_t)(4 * bkl) * T * ldb + 4 * brg) * 4);
+    const unsigned obh = (unsigned)(((int64_t)(4 * bkl) * H + 4 * brg) * 4);            // rows of h0 (step 0 of the h_prev operand)
     auto load_b = [&](PcRegs& r, const Pos& p, int qq) {
         const int j = p.j, t = p.t;
         const int env = 32 * j + 8 * (w >> 1) + qq;                          // uniform; the lane adds 4 bkl
+        const bool from_h0 = !second && t == 0;                              // uniform
+        const int tr = second ? t : t - 1;
         if (env + 4 < a.N) {
-            const char* ub = reinterpret_cast<const char*>(Bp + ((int64_t)env * T + t) * ldb);
-            r.b[qq] = *reinterpret_cast<const f32x4*>(ub + obb);
+            const char* ub = reinterpret_cast<const char*>(from_h0 ? Hp + (int64_t)env * H : Bp + ((int64_t)env * T + tr) * ldb);
+            r.b[qq] = *reinterpret_cast<const f32x4*>(ub + (from_h0 ? obh : obb));
         } else {
             int e = env + 4 * bkl;
             e = e < a.N ? e : a.N - 1;
-            r.b[qq] = *reinterpret_cast<const f32x4*>(Bp + ((int64_t)e * T + t) * ldb + 4 * brg);
+            r.b[qq] = *reinterpret_cast<const f32x4*>((from_h0 ? Hp + (int64_t)e * H : Bp + ((int64_t)e * T + tr) * ldb) + 4 * brg);
         }
     };
     auto load_sc = [&](PcRegs& r, const Pos& p, bool live) {
         const int j = p.j, t = p.t;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.isc + (size_t)t * a.NP + 32 * j + 4 * bkg);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sc_arr + (size_t)t * a.NP + 32 * j + 4 * bkg);
         r.sc = v * (live ? to_block : 0.f);                                   // a slab past the split's end multiplies by zero
     };
     // the split of two values with their own scales (gemm_h3.hip: split_pair)
@@ -470,6 +479,25 @@ __global__ __launch_bounds__(256) void pc_reduce_kernel(const float* __restrict_
 
 }  // namespace
 
+// h_prev rows [N][T][H] = y one step back under the restart mask (h0 at t = 0): what the f32-rows fallback multiplies, since the
+// forward pass of this mode writes no h_prev slot into the stash
+__global__ __launch_bounds__(256) void hprev_rows_kernel(const float* __restrict__ y, const float* __restrict__ keep, const float* __restrict__ h0,
+                                                         int N, int T, float* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (int64_t)N * T * H) return;
+    const int64_t row = i / H;
+    const int c = (int)(i % H), t = (int)(row % T), n = (int)(row / T);
+    const float k = keep ? keep[row] : 1.f;
+    const float4 v = *reinterpret_cast<const float4*>(t ? y + (row - 1) * H + c : h0 + (int64_t)n * H + c);
+    *reinterpret_cast<float4*>(out + i) = float4{v.x * k, v.y * k, v.z * k, v.w * k};
+}
+int lstm_pc_hprev_rows(const float* y, const float* keep, const float* h0, int N, int T, float* out, hipStream_t st) {
+    const int64_t n4 = (int64_t)N * T * H / 4;
+    hipLaunchKernelGGL(hprev_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, y, keep, h0, N, T, out);
+    UAV_LAUNCH_CHECK();
+    return 0;
+}
+
 // dgates (packed) -> f32 rows [N][T][4H]
 int lstm_pc_unpack(const void* dgates, int N, int T, float* out, hipStream_t st) {
     const DgPack P(N, T);
@@ -480,9 +508,10 @@ int lstm_pc_unpack(const void* dgates, int N, int T, float* out, hipStream_t st)
     return 0;
 }
 
-// db (+ db_hh), dw_hh = dG^T h_prev, dw_ih = dG^T x for I <= 8 (on the column-sum pass) or I == 256 (second half of the
+// db (+ db_hh), dw_hh = dG^T h_prev (h_prev[n][t] = y[n][t-1] keep[n][t], h0[n] keep[n][0] at t = 0: rows of y / h0 under the masked
+// scales iscm -- the stash's h_prev slot is not read), dw_ih = dG^T x for I <= 8 (on the column-sum pass) or I == 256 (second half of the
 // product's columns) from the packed gate gradients.  Workspace: [slabs ... | partial sums, max isc word] (the tail).
-int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* stash, const void* dgates, int N, int T, int I, float* dw_ih,
+int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* y, const float* h0, const void* dgates, int N, int T, int I, float* dw_ih,
                   float* dw_hh, float* db, float* db_hh, hipStream_t st) {
     UAV_REQUIRE(I <= 8 || I == H, "lstm_pc_wgrad: input width %d (1..8 or 256)", I);
     const DgPack P(N, T);
@@ -518,12 +547,13 @@ int lstm_pc_wgrad(uav_ctx* ctx, const float* x, const float* stash, const void* 
     a.isc = P.isc(dgates, 0);
     a.iscmax_bits = iscmax;
     a.N = N; a.T = T; a.NP = P.NP; a.RT = P.RT; a.SPT = P.NP / 32;
-    a.B0 = stash + 5 * H; a.ldb0 = 6 * H;
+    a.iscm = P.iscm(dgates, 0);
+    a.y = y; a.h0 = h0;
     a.B1 = wide ? x : nullptr; a.ldb1 = I;
     a.n_split = H; a.Ntot = wide ? 2 * H : H;
     a.total = (int64_t)a.SPT * T;
     a.tm = G4 / PM; a.tn = a.Ntot / PN;
-    UAV_REQUIRE((int64_t)4 * T * (6 * H) * 4 < (1ll << 31), "uav_lstm_wgrad (h=256): T = %d too long for 32-bit lane offsets", T);
+    UAV_REQUIRE((int64_t)4 * T * H * 4 < (1ll << 31), "uav_lstm_wgrad (h=256): T = %d too long for 32-bit lane offsets", T);
     // split-K: whole groups of 8 splits (one per XCD), each split at least 16 slabs, the slabs inside the workspace
     const int tiles_mn = a.tm * a.tn;
     int64_t S = (ctx->num_cu + tiles_mn - 1) / tiles_mn;
