@@ -6,7 +6,8 @@
 //                         pre-split once per call, h_t handed from step to step as fp16 piece planes (ping-pong), every
 //                         workgroup a 64 units x 64 envs tile, operands straight from L2 into registers, no LDS, no barrier;
 //                         step_bwd_h3_kernel  = dh_{t-1} = dG_t W_hh the same way, dG block-scaled per env by a power of
-//                         two (cell_bwd_h3_kernel, which also writes the f32 dG rows uav_lstm_wgrad consumes).
+//                         two (cell_bwd_h3_kernel); since round 5 those pieces are KEPT for all steps and are what uav_lstm_wgrad
+//                         consumes (common.h: DgPack, wgrad_pc.hip) -- no f32 dG rows, no h_prev slot in the stash.
 //                         The launch boundary IS the cross-CU exchange of h_t (1.5-2 us): cheaper than any in-kernel
 //                         flag hand-off of 16 KB per CU and step (MI355X_MICROARCH.md price list: 4+ us).
 //   any other H:          gemm.hip's exact-f32 GEMM + a pointwise kernel per step (UAV_LSTM_F32_MFMA=1 forces this path).
