@@ -451,9 +451,15 @@ __global__ void add2v_kernel(const float* a0, const float* a1, float* b, int n) 
 // 20 (profiles/r02_cell_bwd_ablation.log).  LDS image: chunk (slab, piece) at CB_CH halves, kq rows at CB_KQ: strides chosen
 // so that the 32 (slab, kq) positions one store instruction touches fall on different banks (2-way at worst).
 constexpr int CB_KQ = 136, CB_CH = 592;                 // halves: 272 B per kq row (16 envs x 16 B + 16), 1184 B per chunk
+#ifndef BWD_DX_DEPTH
+#define BWD_DX_DEPTH 5                                  // prefetch ring of step_bwd_h3_kernel<DX>: 5 slabs = 364 registers, so that two
+#endif                                                  // cell_bwd waves (2 x 64) of the other layer's stream fit the SIMD's 512 beside it (6: 412)
+#ifndef CELL_EPW
+#define CELL_EPW 8                                      // envs per workgroup of cell_bwd_h3_kernel (16 = one workgroup per row tile)
+#endif
 constexpr size_t CELL_BWD_LDS = (size_t)64 * CB_CH * 2;
-template <int H>
-__global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
+template <int H, int EPW>
+__global__ __launch_bounds__(EPW * 64) void cell_bwd_h3_kernel(const float* __restrict__ stash, const float* __restrict__ keep,
                                                           const float* __restrict__ dy, const float* __restrict__ dheads,
                                                           const float* __restrict__ w_head, int NH, int N, int T, int t,
                                                           const float* __restrict__ dh_rec, float* __restrict__ dc_next,
@@ -461,9 +467,14 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
                                                           float* __restrict__ inv_scale, float* __restrict__ isc_out,
                                                           float* __restrict__ iscm_out) {
     static_assert(H == 256, "one wave per env: 64 lanes x 4 units");
+    static_assert(EPW == 16 || EPW == 8, "a workgroup = a whole 16-env fragment row tile, or half of one");
     extern __shared__ __attribute__((aligned(16))) unsigned short cb_lds[];
-    const int lane = threadIdx.x & 63, r16 = threadIdx.x >> 6;
-    const int n = blockIdx.x * 16 + r16, u = 4 * lane;
+    // EPW = 8: two workgroups of 8 waves per row tile (each writes its envs' 128-byte half of every 256-byte kq row of the tile's
+    // block): two waves per SIMD at 64 registers leave room for a step_bwd_h3_kernel wave of the OTHER layer's stream beside them
+    constexpr int TPB = 16 / EPW;
+    const int lane = threadIdx.x & 63, r16 = (blockIdx.x % TPB) * EPW + (threadIdx.x >> 6);
+    const int tile = blockIdx.x / TPB;
+    const int n = tile * 16 + r16, u = 4 * lane;
     const bool live = n < N;
     // this lane's 8 bytes of chunk (slab 8 q + lane / 8, piece): kq = (lane % 8) / 2, halves 4 (lane & 1) ..
     unsigned short* lp = cb_lds + (size_t)(2 * (lane >> 3)) * CB_CH + ((lane & 7) >> 1) * CB_KQ + r16 * 8 + 4 * (lane & 1);
@@ -557,12 +568,15 @@ __global__ __launch_bounds__(1024) void cell_bwd_h3_kernel(const float* __restri
     __syncthreads();
 #if CELL_ABL != 1 && CELL_ABL != 3
     // the tile's piece block is 64 chunks x 1 KB of consecutive memory (frag_index): a linear copy, 16 bytes per thread
-    unsigned short* gout = dgp + (size_t)blockIdx.x * 64 * 512;
+    // (EPW = 8: this workgroup's eight envs = one 128-byte line of each kq row)
+    unsigned short* gout = dgp + (size_t)tile * 64 * 512;
+    constexpr int LG = EPW == 16 ? 4 : 3;                  // log2(envs per workgroup)
+    const int e_first = (blockIdx.x % TPB) * EPW;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-        const int e8 = ps * 1024 + threadIdx.x, c = e8 >> 6, kq = (e8 >> 4) & 3, r = e8 & 15;
+        const int e8 = ps * (EPW * 64) + threadIdx.x, c = e8 >> (LG + 2), kq = (e8 >> LG) & 3, r = e_first + (e8 & (EPW - 1));
         const uint4 v = *reinterpret_cast<const uint4*>(cb_lds + (size_t)c * CB_CH + kq * CB_KQ + r * 8);
-        *reinterpret_cast<uint4*>(gout + (size_t)e8 * 8) = v;
+        *reinterpret_cast<uint4*>(gout + ((size_t)c * 64 + kq * 16 + r) * 8) = v;
     }
 #endif
 }
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256) void step_bwd_h3_kernel(const unsigned short* 
     // four waves, each TWO 16-unit row tiles x TWO 16-env column tiles of the 64 x 64 workgroup tile: 8 KB of fragments per
     // slab feed 12 MFMAs (one row tile x two column tiles per wave in eight waves loaded 6 KB for 6: the kernel is bound by
     // the L1 path, 48 KB per slab and workgroup then, 32 KB now); one wave per SIMD, so the ring can be deep
-    constexpr int K = 4 * H, NS = K / 32, DEPTH = DX ? 6 : 8, NR = 2, NC = 2;
+    constexpr int K = 4 * H, NS = K / 32, DEPTH = DX ? BWD_DX_DEPTH : 8, NR = 2, NC = 2;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const unsigned lo = lane * 8;
@@ -898,15 +912,23 @@ struct H3Bwd {
         hipLaunchKernelGGL(gen_fill, dim3(nb), dim3(256), 0, st, dc, dcn, NH);
         return 0;
     }
-    void step(int t, hipStream_t st) const {
-        const dim3 grid((N + 63) / 64, H / 64);
+    // a time step = the gate-gradient kernel (HBM-bound) + the recurrent product (latency-bound): two launches, so that the
+    // pipeline of a stack can put an event between them
+    void step(int t, hipStream_t st) const { cell(t, st); prod(t, st); }
+    void cell(int t, hipStream_t st) const {
         const DgPack P(N, T);
         // the gate-gradient kernel's grid covers whole 64-env tiles: rows past N are written as zero pieces, scale 0
         unsigned short* pc = packed ? P.pieces((void*)dgates, t) : dgp;
         float* isc_t = packed ? P.isc((void*)dgates, t) : inv_scale + P.NP;
-        hipLaunchKernelGGL((cell_bwd_h3_kernel<H>), dim3(P.RT), dim3(1024), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head,
+        hipLaunchKernelGGL((cell_bwd_h3_kernel<H, CELL_EPW>), dim3(P.RT * (16 / CELL_EPW)), dim3(CELL_EPW * 64), CELL_BWD_LDS, st, stash, keep, dy, dheads, w_head,
                            n_heads, N, T, t, dh, dc, packed ? (float*)nullptr : dgates, pc, inv_scale, isc_t,
                            packed ? P.iscm((void*)dgates, t) : (float*)nullptr);
+    }
+    void prod(int t, hipStream_t st) const {
+        const dim3 grid((N + 63) / 64, H / 64);
+        const DgPack P(N, T);
+        unsigned short* pc = packed ? P.pieces((void*)dgates, t) : dgp;
+        float* isc_t = packed ? P.isc((void*)dgates, t) : inv_scale + P.NP;
         if (dx) hipLaunchKernelGGL((step_bwd_h3_kernel<H, true>), grid, dim3(256), 0, st, wtp, pc, inv_scale, isc_t, N, dh, wxtp, dx, T, t);
         else hipLaunchKernelGGL((step_bwd_h3_kernel<H, false>), grid, dim3(256), 0, st, wtp, pc, inv_scale, isc_t, N, dh,
                                 (const unsigned short*)nullptr, (float*)nullptr, T, t);
@@ -919,7 +941,7 @@ struct H3Bwd {
     }
 };
 static int h3_bwd_attr() {
-    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<256>), (int)CELL_BWD_LDS));
+    UAV_CHECK_HIP(uav_dyn_lds(reinterpret_cast<const void*>(&cell_bwd_h3_kernel<256, CELL_EPW>), (int)CELL_BWD_LDS));
     return 0;
 }
 
@@ -985,7 +1007,11 @@ int lstm_h3_bwd_stack(uav_ctx* ctx, int nl, const uav_lstm_bwd_layer* layers, co
             return rc;
         }
     }
-    // the wave front: at round r layer l runs its step T - 1 - (r - l); the hand-off events form a ring per boundary
+    // the wave front: at round r layer l runs its step T - 1 - (r - l); the hand-off events form a ring per boundary.
+    // (The layers run in lockstep -- a layer's step t starts when the layer above ends its step t and starts its step t - 1, so
+    //  gate-gradient kernel meets gate-gradient kernel and product meets product.  Shifting the layer below by half a step with a
+    //  second event per step, so that an HBM-bound kernel always runs beside a latency-bound one, was measured in round 5 and is
+    //  SLOWER: 14.4 against 12.4 ms per C5 epoch -- the streaming kernel evicts the L2 lines the product lives on.)
     hipEvent_t* ring = ctx->side_ev + 2;                       // 6 events: two per boundary
     for (int r = 0; r < T + nl - 1; ++r)
         for (int l = 0; l < nl; ++l) {
