@@ -12,6 +12,9 @@ for c in mlp c4 c2; do python bench.py --config $c --steps 10 --warmup 3 --no-cp
 python bench.py --config c5 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 echo "configs done"
 fi
+# second pass of a round: `only-bench` after tools/collect_final.sh has copied this round's counters into profiles/, so that the bench
+# lines carry `roofline.traffic` of the CURRENT kernel sources (bench.py refuses counters whose digest is older than the tree)
+[ "$2" = "only-bench" ] && exit 0
 # six ranks: the pool's process guard allows at most 6 processes on a GPU (an 8-rank rehearsal is killed by it)
 timeout -k 10 300 python bench.py --gpus 6 --backend gloo --config c2 --steps 3 --warmup 1 --no-cpu-baseline --no-exchange-probe > $OUT/rehearsal_6rank_gloo_c2.json 2> $OUT/rehearsal_6rank_gloo_c2.err || echo "6-rank rehearsal failed"
 echo "rehearsal done"
