@@ -8,7 +8,7 @@ from uavppo import ops  # noqa: E402
 from uavppo._lib import lib, check  # noqa: E402
 
 def main():
-    dev, N, T, H = "cuda:0", 4096, 64, 256
+    dev, N, T, H = "cuda:0", int(os.environ.get("STEP_N", 4096)), 64, 256
     stash = torch.rand(N, T, 6 * H, device=dev) * 0.8 + 0.1
     dy = torch.randn(N, T, H, device=dev) * 1e-6
     w_hh = torch.randn(4 * H, H, device=dev) * 0.05

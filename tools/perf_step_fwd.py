@@ -7,7 +7,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "uav-wrf-les-ppo-lstm_amd")]
 from uavppo import ops  # noqa: E402
 
 def main():
-    dev, N, T, H = "cuda:0", 4096, 64, 256
+    dev, N, T, H = "cuda:0", int(os.environ.get("STEP_N", 4096)), 64, 256
     for I in (8, 256):
         x = torch.randn(N, T, I, device=dev) * 0.5
         h0, c0 = torch.zeros(N, H, device=dev), torch.zeros(N, H, device=dev)
