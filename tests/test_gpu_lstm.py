@@ -509,7 +509,7 @@ def test_lstm_bwd_stack_three_layers_equals_per_layer_calls(ops):
             assert torch.equal(s["dx"], ref_dx[l]), l
 
 
-@pytest.mark.parametrize("N,T,I", [(80, 19, 8), (33, 9, 256), (64, 12, 256), (5, 6, 6), (130, 7, 3)])
+@pytest.mark.parametrize("N,T,I", [(80, 19, 8), (33, 9, 256), (64, 12, 256), (5, 6, 6), (130, 7, 3), (16, 1, 8), (70, 2, 256), (256, 33, 256)])
 def test_h256_gate_gradients_stored_once_equal_the_f32_rows_form(ops, N, T, I):
     """h = 256 on the fp16-split arithmetic keeps the gate gradients ONCE, as the fp16 piece chunks the BPTT's recurrent product
     consumes (+ one power-of-two scale per env and step; common.h DgPack, uav_lstm_dgates_bytes), and the weight-gradient pass
