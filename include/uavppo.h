@@ -30,7 +30,7 @@ extern "C" {
 typedef struct uav_ctx uav_ctx;   /* opaque: device id, CU count, one scratch workspace */
 typedef void* uav_stream;         /* hipStream_t */
 
-#define UAV_ABI_VERSION 9   /* 9: uav_lstm_dgates_bytes / uav_lstm_dgates_f32: at h = 256 on the fp16-split arithmetic `dgates` is an opaque buffer (the BPTT's fp16 piece chunks, stored once) -- size it with uav_lstm_dgates_bytes; UAV_DEBUG_DG_F32; 8: uav_lstm_wgrad db_hh; uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
+#define UAV_ABI_VERSION 9   /* 9: uav_lstm_stepper_step_pair; uav_lstm_dgates_bytes / uav_lstm_dgates_f32: at h = 256 on the fp16-split arithmetic `dgates` is an opaque buffer (the BPTT's fp16 piece chunks, stored once) -- size it with uav_lstm_dgates_bytes; UAV_DEBUG_DG_F32; 8: uav_lstm_wgrad db_hh; uav_comm_* / uav_allreduce / uav_allreduce_f64 / uav_allgather_bytes / uav_rccl_version (RCCL behind the ABI); the h = 256 cluster kernels, uav_lstm_cluster_errors and UAV_DEBUG_CLUSTER* left the library (tools/experiments/lstm_cluster); 7: uav_env_cfg.curriculum, uav_curriculum_* (device-side curriculum), uav_episode_rows; 6: uav_lstm_cluster_errors, UAV_DEBUG_CLUSTER (h = 256 persistent cluster kernels); 5: uav_rollout_tail; 4: uav_set_debug_flags; the fused MLP kernels follow uav_set_lstm_arith (fp16 split by default); the UAV_LSTM_* environment variables are read once, by uav_create; procedural field / step noise in f64 (pinned by oracle/procedural_oracle.py); 3: uav_gemm_f16x3, uav_lstm_stepper_*, uav_policy_sample_at, uav_store_transition, uav_lstm_bwd (w_ih, I, dx), uav_lstm_bwd_caps, uav_lstm_bwd_stack; 2: uav_policy_sample index_offset, uav_clip_adam pmax_out, uav_set_lstm_arith, uav_absmax, uav_mlp_ppo_grad, uav_rollout policy_kind 0 */
 
 /* GAE modes (train_ppo2.0.py:18-32 vs PPOV1.0/ppo0.0.py:337-350) */
 #define UAV_GAE_REFERENCE_EXACT 0  /* mask from done[t+1], last step bootstraps from itself */
@@ -188,6 +188,17 @@ int uav_lstm_stepper_begin(uav_ctx* ctx, void* state, const float* w_ih, const f
                            const float* b_hh, const float* h0, const float* c0, int N, int I, int H, uav_stream stream);
 int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void* below, const float* keep_t, int N, int T,
                           int t, int I, int H, float* y, float* stash, float* hn, float* cn, uav_stream stream);
+/* Two INDEPENDENT stepper steps as one launch (their workgroups share the CUs: a step launch is mostly latency, two side by side
+ * take ~1.8 x one).  Meant for the forward pass over a stored sequence of a two-layer stack: a = layer 1's step t + 1, b = layer 2's
+ * step t with below = layer 1's state -- b reads the piece planes layer 1 wrote at step t, which step t + 1 only reads.  Neither
+ * call may read what the other writes.  Same kernels and bit-identical results to the two uav_lstm_stepper_step calls. */
+typedef struct uav_stepper_call {
+    void* state; const float* x; const void* below; const float* keep_t;
+    int t, I;
+    float *y, *stash, *hn, *cn;
+} uav_stepper_call;
+int uav_lstm_stepper_step_pair(uav_ctx* ctx, const uav_stepper_call* a, const uav_stepper_call* b, int N, int T, int H,
+                               uav_stream stream);
 
 /* ---- dense f32 building block (exact-f32 MFMA): C[M][N] (+)= op(A)[M][K] * op(B)[K][N] + bias[N].
  * Element (i,k) of op(A) is A[i*sa_m + k*sa_k]; element (k,j) of op(B) is B[k*sb_k + j*sb_n]

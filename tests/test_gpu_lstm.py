@@ -391,6 +391,42 @@ def test_lstm_stepper_equals_sequence_forward(ops, N, T, I):
     assert torch.equal(y[:, 0], y2_ref[:, 0]) and _stash_equal(stash[:, 0], st2_ref[:, 0])
 
 
+def test_stepper_step_pair_equals_the_two_steps(ops):
+    """uav_lstm_stepper_step_pair: layer 1's step t + 1 and layer 2's step t (reading layer 1's piece planes of step t) as ONE launch --
+    the update's forward pass over a stored sequence (uavppo/policy.py) -- gives the bits of the layer-by-layer stepper loop: y, the
+    BPTT stash, final states, for a ragged env count and with restart masks."""
+    H, N, T, I = 256, 100, 7, 8
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *shape, s=0.1: (torch.randn(*shape, generator=g) * s).to(DEV)
+    x = mk(N, T, I, s=1.0)
+    keep = (torch.rand(T, N, generator=g) > 0.2).float().to(DEV)
+    W = [(mk(4 * H, I), mk(4 * H, H), mk(4 * H), mk(4 * H)), (mk(4 * H, H), mk(4 * H, H), mk(4 * H), mk(4 * H))]
+    h0, c0 = [mk(N, H, s=0.3), mk(N, H, s=0.3)], [mk(N, H, s=0.3), mk(N, H, s=0.3)]
+
+    def run(pairs):
+        sp = [ops.LstmStepper(N, I, H, DEV), ops.LstmStepper(N, H, H, DEV)]
+        for l in range(2):
+            sp[l].begin(*W[l], h0[l], c0[l])
+        y = [torch.zeros(N, T, H, device=DEV) for _ in range(2)]
+        st = [torch.zeros(N, T, 6 * H, device=DEV) for _ in range(2)]
+        if pairs:
+            sp[0].step(x, 0, y[0], st[0], keep=keep[0])
+            for t in range(T - 1):
+                ops.lstm_stepper_step_pair((sp[0], x, t + 1, y[0], st[0], None, keep[t + 1]), (sp[1], y[0], t, y[1], st[1], sp[0], keep[t]))
+            sp[1].step(y[0], T - 1, y[1], st[1], below=sp[0], keep=keep[T - 1])
+        else:
+            for t in range(T):
+                sp[0].step(x, t, y[0], st[0], keep=keep[t])
+                sp[1].step(y[0], t, y[1], st[1], below=sp[0], keep=keep[t])
+        torch.cuda.synchronize()
+        return y, st, [s.hn.clone() for s in sp], [s.cn.clone() for s in sp]
+
+    a, b = run(True), run(False)
+    for l in range(2):
+        assert torch.equal(a[0][l], b[0][l]) and _stash_equal(a[1][l], b[1][l]), l
+        assert torch.equal(a[2][l], b[2][l]) and torch.equal(a[3][l], b[3][l]), l
+
+
 @pytest.mark.parametrize("mode", ["bf16x6", "f32_mfma"])
 def test_h256_wide_range_modes_leave_the_fp16_step_kernels(ops, mode):
     """The h = 256 step kernels exist in the fp16-split form only (|w| < 65504, |x| < 4096).  A caller that selects a

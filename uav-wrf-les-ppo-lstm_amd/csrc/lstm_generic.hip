@@ -156,18 +156,18 @@ __device__ __forceinline__ f16x8 ldh8(const unsigned short* p) { return *reinter
 // K runs over the input (IP = I rounded up to 32, x_t read as f32 and split in registers) and then over H (h_{t-1} as fp16
 // piece planes) in slabs of 32, next slab's fragments in flight while the current one multiplies.
 // A = weight pieces [2][4H][IP] and [2][4H][H], lane (r16, kq) reads 8 consecutive k of row r16 -- one dwordx4.
-template <int H, int IPS>
-__global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp,
-                                                          const unsigned short* __restrict__ wp,
-                                                          const float* __restrict__ bsum, const float* __restrict__ x, int I,
-                                                          const unsigned short* __restrict__ xp, int last_pieces,
-                                                          const unsigned short* __restrict__ hp_in,
-                                                          unsigned short* __restrict__ hp_out, float* __restrict__ hs,
-                                                          float* __restrict__ cs, float* __restrict__ stash,
-                                                          const float* __restrict__ keep, int64_t keep_sn, int64_t keep_off,
-                                                          int N, int T, int t,
-                                                          float* __restrict__ y, float* __restrict__ hn,
-                                                          float* __restrict__ cn, int hslot) {
+template <int H, int IPS, int RING>
+__device__ __forceinline__ void step_fwd_h3_body(const unsigned short* __restrict__ wxp,
+                                                 const unsigned short* __restrict__ wp,
+                                                 const float* __restrict__ bsum, const float* __restrict__ x, int I,
+                                                 const unsigned short* __restrict__ xp, int last_pieces,
+                                                 const unsigned short* __restrict__ hp_in,
+                                                 unsigned short* __restrict__ hp_out, float* __restrict__ hs,
+                                                 float* __restrict__ cs, float* __restrict__ stash,
+                                                 const float* __restrict__ keep, int64_t keep_sn, int64_t keep_off,
+                                                 int N, int T, int t,
+                                                 float* __restrict__ y, float* __restrict__ hn,
+                                                 float* __restrict__ cn, int hslot) {
     constexpr int NS = H / 32, NC = 4;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar bases
     const unsigned lo = lane * 8;                      // this lane's 16 bytes of a 1 KB fragment chunk
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
             bp[c] = hp_in + (size_t)((e0 + 16 * c) >> 4) * NS * 1024;
             bxp[c] = xp + (size_t)((e0 + 16 * c) >> 4) * IPS * 1024;
         }
-        constexpr int DEPTH = 3, NSL = NS + IPS;
+        constexpr int DEPTH = RING, NSL = NS + IPS;
         f16x8 a[DEPTH][4][2], b[DEPTH][NC][2];
         auto fetch = [&](int s, int buf) {
             const bool rec = s < NS;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
         // then runs at the L2 latency per slab (step_bwd_h3_kernel: 20.5 -> 14.4 us by the same change)
         // (only with a short input projection behind it: with IPS = 8 -- layer 2, whose time goes to the x gathers and
         // the stash stores -- the pinned ring measured 36.6 us per step against 34.2 for the plain double buffer)
-        constexpr int DEPTH = IPS <= 2 ? 3 : 2;
+        constexpr int DEPTH = IPS <= 2 ? RING : 2;
         f16x8 a[DEPTH][4][2], b[DEPTH][NC][2];         // [buffer][gate | col tile][piece]
         auto fetch = [&](int s, int buf) {
 #pragma unroll
@@ -433,6 +433,52 @@ __global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* 
             *reinterpret_cast<uint2*>(hp_out + frag_index(n, u, H, 1)) = v1;
         }
     }
+}
+
+template <int H, int IPS>
+__global__ __launch_bounds__(256) void step_fwd_h3_kernel(const unsigned short* __restrict__ wxp,
+                                                          const unsigned short* __restrict__ wp,
+                                                          const float* __restrict__ bsum, const float* __restrict__ x, int I,
+                                                          const unsigned short* __restrict__ xp, int last_pieces,
+                                                          const unsigned short* __restrict__ hp_in,
+                                                          unsigned short* __restrict__ hp_out, float* __restrict__ hs,
+                                                          float* __restrict__ cs, float* __restrict__ stash,
+                                                          const float* __restrict__ keep, int64_t keep_sn, int64_t keep_off,
+                                                          int N, int T, int t,
+                                                          float* __restrict__ y, float* __restrict__ hn,
+                                                          float* __restrict__ cn, int hslot) {
+    step_fwd_h3_body<H, IPS, 3>(wxp, wp, bsum, x, I, xp, last_pieces, hp_in, hp_out, hs, cs, stash, keep, keep_sn, keep_off, N, T, t, y, hn, cn,
+                                hslot);
+}
+
+// TWO independent steps as one launch (blockIdx.z picks): the update's forward pass runs layer 1's step t + 1 beside layer 2's
+// step t, so that two workgroups share every CU -- a step launch costs ~13-16 us of latency whatever its size
+// (profiles/r05_step_share_ablation.log) and two of them side by side take 1.75-1.8 x one, not 2 x.
+struct StepFwdArgs {
+    const unsigned short *wxp, *wp;
+    const float *bsum, *x;
+    int I;
+    const unsigned short* xp;
+    int last_pieces;
+    const unsigned short* hp_in;
+    unsigned short* hp_out;
+    float *hs, *cs, *stash;
+    const float* keep;
+    int64_t keep_sn, keep_off;
+    int N, T, t;
+    float *y, *hn, *cn;
+    int hslot;
+};
+// (the workgroups do not share a SIMD -- a wave takes 418 registers for its accumulators and three-slab ring, and held to 256 it
+//  spills 100 of them -- they follow one another on the CUs without a launch in between)
+template <int H, int IPS_A, int IPS_B>
+__global__ __launch_bounds__(256) void step_fwd_h3_pair_kernel(const StepFwdArgs a, const StepFwdArgs b) {
+    if (blockIdx.z == 0)
+        step_fwd_h3_body<H, IPS_A, 3>(a.wxp, a.wp, a.bsum, a.x, a.I, a.xp, a.last_pieces, a.hp_in, a.hp_out, a.hs, a.cs, a.stash, a.keep, a.keep_sn,
+                                   a.keep_off, a.N, a.T, a.t, a.y, a.hn, a.cn, a.hslot);
+    else
+        step_fwd_h3_body<H, IPS_B, 3>(b.wxp, b.wp, b.bsum, b.x, b.I, b.xp, b.last_pieces, b.hp_in, b.hp_out, b.hs, b.cs, b.stash, b.keep, b.keep_sn,
+                                   b.keep_off, b.N, b.T, b.t, b.y, b.hn, b.cn, b.hslot);
 }
 
 __global__ void add2v_kernel(const float* a0, const float* a1, float* b, int n) {
@@ -877,6 +923,46 @@ int uav_lstm_stepper_step(uav_ctx* ctx, void* state, const float* x, const void*
 #undef LAUNCH_STEP
     UAV_LAUNCH_CHECK();
     return 0;
+}
+
+// the arguments of one stepper step, as uav_lstm_stepper_step forms them
+static int stepper_args(const uav_stepper_call& c, int N, int T, int H, StepFwdArgs& A, int& IPS) {
+    UAV_REQUIRE(c.state && c.x && c.y && c.stash && c.hn && c.cn, "uav_lstm_stepper_step_pair: NULL argument");
+    UAV_REQUIRE(uav_lstm_stepper_bytes(N, c.I, H) != 0 && T > 0 && c.t >= 0 && c.t < T, "uav_lstm_stepper_step_pair: bad shape (N=%d T=%d t=%d I=%d H=%d)", N, T, c.t, c.I, H);
+    const StepperLayout L = stepper_layout(N, c.I);
+    char* b = (char*)c.state;
+    unsigned short* hp0 = (unsigned short*)(b + L.hp0);
+    unsigned short* hp1 = (unsigned short*)(b + L.hp1);
+    const unsigned short* xp = nullptr;
+    if (c.below) {
+        UAV_REQUIRE(c.I == 256, "uav_lstm_stepper_step_pair: `below` needs I = 256, got %d", c.I);
+        const StepperLayout LB = stepper_layout(N, 8);
+        xp = (const unsigned short*)((const char*)c.below + (((c.t + 1) & 1) ? LB.hp1 : LB.hp0));
+    }
+    A = StepFwdArgs{(const unsigned short*)(b + L.wxp), (const unsigned short*)(b + L.wp), (const float*)(b + L.bsum), c.x, c.I, xp, 1,
+                    (c.t & 1) ? hp1 : hp0, (c.t & 1) ? hp0 : hp1, (float*)(b + L.hs), (float*)(b + L.cs), c.stash, c.keep_t, (int64_t)1,
+                    (int64_t)0, N, T, c.t, c.y, c.hn, c.cn, h3_dg_packed(H) ? 0 : 1};
+    IPS = L.IP / 32;
+    return 0;
+}
+
+int uav_lstm_stepper_step_pair(uav_ctx* ctx, const uav_stepper_call* a, const uav_stepper_call* b, int N, int T, int H,
+                               uav_stream stream) {
+    UAV_REQUIRE(ctx && a && b, "uav_lstm_stepper_step_pair: NULL argument");
+    uav_enter(ctx);
+    UAV_REQUIRE(h3_step_ok(H), "uav_lstm_stepper_step_pair: only the fp16-split arithmetic steps (uav_set_lstm_arith)");
+    StepFwdArgs A, B;
+    int ia, ib, rc;
+    if ((rc = stepper_args(*a, N, T, H, A, ia)) || (rc = stepper_args(*b, N, T, H, B, ib))) return rc;
+    hipStream_t st = as_stream(stream);
+    if (ia == 1 && ib == 8) {                 // (layer 1 of a narrow input, layer 2 on the layer below's planes): the one instantiated pair
+        hipLaunchKernelGGL((step_fwd_h3_pair_kernel<256, 1, 8>), dim3((N + 63) / 64, 256 / 64, 2), dim3(256), 0, st, A, B);
+        UAV_LAUNCH_CHECK();
+        return 0;
+    }
+    // any other pair of widths: the two steps one after the other (same results)
+    if ((rc = uav_lstm_stepper_step(ctx, a->state, a->x, a->below, a->keep_t, N, T, a->t, a->I, H, a->y, a->stash, a->hn, a->cn, stream))) return rc;
+    return uav_lstm_stepper_step(ctx, b->state, b->x, b->below, b->keep_t, N, T, b->t, b->I, H, b->y, b->stash, b->hn, b->cn, stream);
 }
 
 }  // extern "C"

@@ -26,6 +26,12 @@ class EnvCfg(C.Structure):
                 ("seed", C.c_uint64), ("bank", C.c_void_p), ("bank_src", C.c_void_p), ("curriculum", C.c_void_p)]
 
 
+class StepperCall(C.Structure):
+    """uav_stepper_call (include/uavppo.h)"""
+    _fields_ = [("state", C.c_void_p), ("x", C.c_void_p), ("below", C.c_void_p), ("keep_t", C.c_void_p), ("t", C.c_int), ("I", C.c_int),
+                ("y", C.c_void_p), ("stash", C.c_void_p), ("hn", C.c_void_p), ("cn", C.c_void_p)]
+
+
 class LstmBwdLayer(C.Structure):
     """struct uav_lstm_bwd_layer (include/uavppo.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("keep", "stash", "w_hh", "w_ih", "dgates", "dx", "dhn", "dcn", "dh0", "dc0")]
@@ -62,6 +68,7 @@ SIGNATURES = {
     "uav_lstm_stepper_bytes": (SZ, [I32, I32, I32]),
     "uav_lstm_stepper_begin": (I32, [P, P, P, P, P, P, P, P, I32, I32, I32, P]),
     "uav_lstm_stepper_step": (I32, [P, P, P, P, P, I32, I32, I32, I32, I32, P, P, P, P, P]),
+    "uav_lstm_stepper_step_pair": (I32, [P, P, P, I32, I32, I32, P]),
     "uav_gemm_f32": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P]),
     "uav_gemm_f16x3": (I32, [P, I64, I64, I64, P, I64, I64, P, I64, I64, P, I64, P, I32, P, P]),
     "uav_colsum": (I32, [P, P, I64, I32, P, P]),

@@ -605,6 +605,30 @@ class LstmStepper:
                                           _p(self.cn), _stream()), "uav_lstm_stepper_step")
 
 
+def _stepper_call(sp, x, t, y, stash, below, keep):
+    N, I, H = sp.N, sp.I, sp.H
+    T = x.shape[1]
+    c = _lib.StepperCall()
+    c.state = _p(sp.state).value
+    c.x = _p(x, F32, (N, T, I), "x").value
+    c.below = None if below is None else _p(below.state).value
+    c.keep_t = None if keep is None else _p(keep, F32, (N,), "keep").value
+    c.t, c.I = int(t), I
+    c.y = _p(y, F32, (N, T, H), "y").value
+    c.stash = _p(stash, F32, (N, T, 6 * H), "stash").value
+    c.hn, c.cn = _p(sp.hn).value, _p(sp.cn).value
+    return c
+
+
+def lstm_stepper_step_pair(a, b):
+    """uav_lstm_stepper_step_pair: two INDEPENDENT stepper steps as one launch.  a, b: (stepper, x, t, y, stash, below, keep) as for
+    LstmStepper.step -- e.g. layer 1's step t + 1 and layer 2's step t (below = layer 1's stepper)."""
+    ca, cb = _stepper_call(*a), _stepper_call(*b)
+    sp, x = a[0], a[1]
+    check(lib().uav_lstm_stepper_step_pair(_h(sp.state), C.byref(ca), C.byref(cb), sp.N, x.shape[1], sp.H, _stream()),
+          "uav_lstm_stepper_step_pair")
+
+
 def lstm_dgates_bytes(N, T, H, device):
     """uav_lstm_dgates_bytes: size of the gate-gradient buffer uav_lstm_bwd / _bwd_stack hand to uav_lstm_wgrad under the device
     handle's CURRENT arithmetic mode and debug flags."""

@@ -172,8 +172,18 @@ class LSTMActorCritic(_FlatPolicy):
             # BIT-identical stash / y (tests/test_gpu_lstm.py::test_lstm_stepper_equals_sequence_forward)
             self.begin_steps(h0, c0)
             keep_t = None if keep is None else keep.t().contiguous()
-            for t in range(T):
-                self.step_layers_at(obs, t, work, keep=None if keep_t is None else keep_t[t])
+            kt = (lambda t: None) if keep_t is None else (lambda t: keep_t[t])
+            if self.num_layers == 2 and getattr(self, "use_step_pairs", True):
+                # layer 1's step t + 1 beside layer 2's step t, one launch (uav_lstm_stepper_step_pair): T + 1 launches for 2 T steps
+                s0, s1 = self._steppers
+                y0, y1, st0, st1 = work["y0"], work["y1"], work["stash0"], work["stash1"]
+                s0.step(obs, 0, y0, st0, keep=kt(0))
+                for t in range(T - 1):
+                    ops.lstm_stepper_step_pair((s0, obs, t + 1, y0, st0, None, kt(t + 1)), (s1, y0, t, y1, st1, s0, kt(t)))
+                s1.step(y0, T - 1, y1, st1, below=s0, keep=kt(T - 1))
+            else:
+                for t in range(T):
+                    self.step_layers_at(obs, t, work, keep=kt(t))
             for l in range(self.num_layers):
                 saved.append((x, work[f"stash{l}"], work[f"y{l}"], h0[l]))
                 x = work[f"y{l}"]
