@@ -285,8 +285,8 @@ int uav_lstm_fwd(uav_ctx* ctx, const float* x, const float* keep, const float* h
  * formed in registers, never written to HBM); exactly one of dy / dheads is non-NULL.  dhn,dcn
  * [N][H] or NULL.  Writes dgates (per-step gate gradients, the input of uav_lstm_wgrad: uav_lstm_dgates_bytes(ctx, N, T, H)
  * bytes -- f32 [N][T][4H], except at H = 256 on the fp16-split arithmetic, where the buffer is OPAQUE: the two fp16 pieces per
- * row the recurrent product consumes, scaled per (env, step) by a power of two, in MFMA fragment order + one f32 scale per
- * (env, step), i.e. 4 bytes per (env, step) more than the f32 rows, N rounded up to 64; uav_lstm_wgrad reads that form
+ * row the recurrent product consumes, scaled per (env, step) by a power of two, in MFMA fragment order + two f32 scales per
+ * (env, step) (plain and restart-masked), i.e. 8 bytes per (env, step) more than the f32 rows, N rounded up to 64; uav_lstm_wgrad reads that form
  * directly and uav_lstm_dgates_f32 converts it to f32 rows) and dh0, dc0 [N][H] (or NULL).  The arithmetic mode and debug
  * flags must not change between uav_lstm_bwd and the uav_lstm_wgrad that consumes its dgates. */
 int uav_lstm_bwd(uav_ctx* ctx, const float* keep, const float* stash, const float* w_hh,
